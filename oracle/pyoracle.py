@@ -1,0 +1,133 @@
+"""ctypes binding of the CPU oracle (oracle/liborc.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never by anything under pindel_amd/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liborc.so")
+
+MAX_READ_LEN = 500
+
+
+class OrcParams(C.Structure):
+    _fields_ = [
+        ("max_range_index", C.c_int32),
+        ("additional_mismatch", C.c_int32),
+        ("min_perfect_match", C.c_int32),
+        ("min_close", C.c_int32),
+        ("max_mismatch_rate", C.c_double),
+        ("spacer", C.c_uint32),
+        ("max_mismatch", C.c_uint32 * MAX_READ_LEN),
+    ]
+
+
+POINT_DTYPE = np.dtype(
+    [("abs_loc", "<u4"), ("length", "<i2"), ("mismatches", "<i2"), ("chr_id", "<i2"),
+     ("direction", "S1"), ("strand", "S1")], align=True)
+WINDOW_DTYPE = np.dtype([("chr_id", "<i4"), ("start", "<i4"), ("end", "<i4")], align=True)
+assert POINT_DTYPE.itemsize == 12 and WINDOW_DTYPE.itemsize == 12
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (seconds)."""
+    src = [os.path.join(_HERE, f) for f in ("pg_oracle.c", "pg_oracle.h")]
+    if force or not os.path.exists(_LIB_PATH) or any(
+            os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liborc.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_make_max_mismatch.argtypes = [C.c_double, C.c_double, C.POINTER(C.c_uint32)]
+        L.orc_default_params.argtypes = [C.POINTER(OrcParams)]
+        L.orc_search_batch.restype = C.c_int
+        L.orc_search_batch.argtypes = [
+            C.POINTER(OrcParams), C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64),
+            C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+            C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+            C.c_void_p, C.c_void_p, C.c_int]
+        _lib = L
+    return _lib
+
+
+def make_params(max_range_index=2, additional_mismatch=1, min_perfect_match=3, min_close=8,
+                max_mismatch_rate=0.02, seq_error_rate=0.01, sensitivity=0.95,
+                spacer=100000) -> OrcParams:
+    """Pindel flags -x -a -m -H -u -e -E (defaults = 0.2.5b9 defaults)."""
+    p = OrcParams()
+    p.max_range_index = max_range_index
+    p.additional_mismatch = max(1, additional_mismatch)        # pindel.cpp:927-930
+    p.min_perfect_match = min_perfect_match
+    p.min_close = min_close
+    p.max_mismatch_rate = max_mismatch_rate
+    p.spacer = spacer
+    lib().orc_make_max_mismatch(0.001 + seq_error_rate, sensitivity, p.max_mismatch)
+    return p
+
+
+def max_mismatch_table(seq_error_rate=0.01, sensitivity=0.95) -> np.ndarray:
+    t = (C.c_uint32 * MAX_READ_LEN)()
+    lib().orc_make_max_mismatch(0.001 + seq_error_rate, sensitivity, t)
+    return np.frombuffer(t, dtype=np.uint32).copy()
+
+
+def search_batch(params: OrcParams, chr_seqs, seq: np.ndarray, seq_off: np.ndarray,
+                 anchor_strand: np.ndarray, anchor_pos: np.ndarray, insert_size: np.ndarray,
+                 chr_id: np.ndarray, bd=None, bd_off=None, do_far=True, n_threads=0):
+    """Run close end (+ far end) for a batch.
+
+    chr_seqs: list of spacer-padded chromosome strings (bytes).
+    seq: uint8 array of concatenated read bases (copied; the possibly
+         reverse-complemented result is returned).
+    Returns dict(seq, rc_flag, close_cnt, close_pts, far_cnt, far_pts, stride).
+    """
+    L = lib()
+    n = len(seq_off) - 1
+    seq = np.ascontiguousarray(seq, dtype=np.uint8).copy()
+    seq_off = np.ascontiguousarray(seq_off, dtype=np.uint64)
+    lens = np.diff(seq_off.astype(np.int64))
+    stride = int(lens.max()) if n else 1
+    anchor_strand = np.ascontiguousarray(anchor_strand, dtype=np.uint8)
+    anchor_pos = np.ascontiguousarray(anchor_pos, dtype=np.int32)
+    insert_size = np.ascontiguousarray(insert_size, dtype=np.int16)
+    chr_id = np.ascontiguousarray(chr_id, dtype=np.int32)
+    n_chr = len(chr_seqs)
+    chr_arr = (C.c_char_p * n_chr)(*[bytes(s) for s in chr_seqs])
+    chr_len = (C.c_uint64 * n_chr)(*[len(s) for s in chr_seqs])
+    close_cnt = np.zeros(n, dtype=np.uint32)
+    far_cnt = np.zeros(n, dtype=np.uint32)
+    close_pts = np.zeros(n * stride, dtype=POINT_DTYPE)
+    far_pts = np.zeros(n * stride, dtype=POINT_DTYPE)
+    rc_flag = np.zeros(n, dtype=np.uint8)
+    bd_p = bd_off_p = None
+    if bd is not None:
+        bd = np.ascontiguousarray(bd, dtype=WINDOW_DTYPE)
+        bd_off = np.ascontiguousarray(bd_off, dtype=np.uint64)
+        bd_p, bd_off_p = bd.ctypes.data, bd_off.ctypes.data
+    rc = L.orc_search_batch(
+        C.byref(params), n_chr, chr_arr, chr_len, n, seq.ctypes.data, seq_off.ctypes.data,
+        anchor_strand.ctypes.data, anchor_pos.ctypes.data, insert_size.ctypes.data,
+        chr_id.ctypes.data, bd_p, bd_off_p, 1 if do_far else 0, stride,
+        close_cnt.ctypes.data, close_pts.ctypes.data, far_cnt.ctypes.data, far_pts.ctypes.data,
+        rc_flag.ctypes.data, n_threads)
+    if rc != 0:
+        raise RuntimeError(f"orc_search_batch failed: {rc}")
+    return dict(seq=seq, rc_flag=rc_flag, close_cnt=close_cnt,
+                close_pts=close_pts.reshape(n, stride) if n else close_pts,
+                far_cnt=far_cnt, far_pts=far_pts.reshape(n, stride) if n else far_pts,
+                stride=stride)
