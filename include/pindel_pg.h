@@ -1,0 +1,190 @@
+/*
+ * pindel_pg.h -- C ABI of the MI355X-native split-read pattern-growth engine.
+ *
+ * Drop-in boundary for Pindel 0.2.5b9's hot path.  The reference has no FFI
+ * layer; these entry points replace its two internal batch seams and the
+ * per-read primitives behind them:
+ *
+ *   pg_close_end_batch  <->  ReadBuffer::flush()           src/read_buffer.cpp:36-101
+ *                            (GetCloseEnd per read,        src/pindel.cpp:2531-2605,
+ *                             updateReadAfterCloseEndMapping src/reader.cpp:1531-1554)
+ *                            and the two loops in ReadInRead src/reader.cpp:248-255,300-305
+ *   pg_far_end_batch    <->  SearchFarEnds(chrSeq, reads, chr) src/pindel.cpp:1115-1138
+ *                            (SearchFarEnd per read,        src/pindel.cpp:1001-1074,
+ *                             SearchFarEndAtPos             src/farend_searcher.cpp:46-103)
+ *   pg_search_batch     <->  both of the above back to back (no BreakDancer hints)
+ *   pg_load_reference   <->  Genome::loadAll / Chromosome::getSeq()  src/pindel.cpp:236-312
+ *   pg_params           <->  the globals the path reads: g_maxMismatch (pindel.cpp:794-819),
+ *                            g_MinClose (:88), userSettings->{MaxRangeIndex, ADDITIONAL_MISMATCH,
+ *                            Min_Perfect_Match_Around_BP, MaximumAllowedMismatchRate,
+ *                            Seq_Error_Rate, sensitivity}, g_SpacerBeforeAfter (pindel.h:122)
+ *
+ * Conventions: plain pointers and sizes only; the caller owns every input
+ * buffer; result objects are owned by the library until pg_result_free.
+ * Every function returns 0 (PG_OK) or a negative pg_status; nothing calls
+ * exit().  One pg_ctx drives one GPU (HIP device ordinal in pg_params); use
+ * one process per GPU.  Calls on one ctx are synchronous and not re-entrant.
+ *
+ * Coordinates are the reference's AbsLoc: indices into the spacer-padded
+ * chromosome string (biological position + spacer).
+ */
+#ifndef PINDEL_PG_H
+#define PINDEL_PG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PG_ABI_VERSION 1
+#define PG_MAX_READ_LEN 499      /* g_maxMismatch has 500 entries (pindel.cpp:801) */
+#define PG_MAX_BD_WINDOWS 127    /* windows per BreakDancer cluster handled on device */
+
+typedef enum {
+    PG_OK = 0,
+    PG_E_INVALID = -1,       /* bad argument                                   */
+    PG_E_NOMEM = -2,         /* host or device allocation failed               */
+    PG_E_DEVICE = -3,        /* HIP runtime error (see pg_last_error)          */
+    PG_E_NO_REFERENCE = -4,  /* pg_load_reference not called                   */
+    PG_E_READ_TOO_LONG = -5, /* a read is longer than PG_MAX_READ_LEN          */
+    PG_E_UNSUPPORTED = -6    /* parameter outside what the device path handles */
+} pg_status;
+
+typedef struct pg_ctx pg_ctx;
+typedef struct pg_result pg_result;
+typedef struct pg_device_batch pg_device_batch;
+
+/* Pindel command-line flags the path reads (defaults of 0.2.5b9 in brackets). */
+typedef struct {
+    int32_t  abi_version;                 /* PG_ABI_VERSION                              */
+    int32_t  device;                      /* HIP device ordinal                          */
+    int32_t  max_range_index;             /* -x [2], capped at 9 (pindel.cpp:125,921)    */
+    int32_t  additional_mismatch;         /* -a [1], raised to >=1 (pindel.cpp:927)      */
+    int32_t  min_perfect_match_around_bp; /* -m [3]                                      */
+    int32_t  min_close;                   /* -H [8]  g_MinClose                          */
+    double   max_allowed_mismatch_rate;   /* -u [0.02]                                   */
+    double   seq_error_rate;              /* -e [0.01]                                   */
+    double   sensitivity;                 /* -E [0.95]                                   */
+    uint32_t spacer;                      /* g_SpacerBeforeAfter [100000]                */
+    uint32_t reserved;
+} pg_params;
+
+/* One batch of one-end-anchored reads: the SPLIT_READ fields the path reads
+ * (src/pindel.h:265-383), structure-of-arrays. */
+typedef struct {
+    uint32_t        n_reads;
+    const uint8_t  *seq;            /* concatenated UnmatchedSeq, ASCII, as after setUnmatchedSeq */
+    const uint64_t *seq_off;        /* n_reads+1 offsets into seq                                  */
+    const uint8_t  *anchor_strand;  /* MatchedD: '+' or '-'                                        */
+    const int32_t  *anchor_pos;     /* MatchedRelPos (biological coordinate)                       */
+    const int16_t  *insert_size;    /* InsertSize (short, pindel.h:318)                            */
+    const int32_t  *chr_id;         /* index of FragName in the loaded reference                   */
+} pg_read_batch;
+
+/* A SearchWindow (src/pindel.h:665-716) in AbsLoc coordinates. */
+typedef struct {
+    int32_t chr_id;
+    int32_t start;   /* may be < 0: then start = end-1 (farend_searcher.cpp:69-71) */
+    int32_t end;
+} pg_window;
+
+/* Per-read BreakDancer clusters (result of BDData::getCorrespondingSearchWindowCluster,
+ * src/bddata.cpp:949-971), CSR.  NULL / n = 0 means "no hints". */
+typedef struct {
+    const uint64_t  *offset;   /* n_reads+1 */
+    const pg_window *windows;
+} pg_windows;
+
+/* Run-length-encoded UniquePoints (src/pindel.h:137-158).  A run stands for
+ * the points  LengthStr = len_first..len_last  with
+ * AbsLoc = abs_loc_first + (LengthStr-len_first)  for direction '+' (FORWARD)
+ * AbsLoc = abs_loc_first - (LengthStr-len_first)  for direction '-' (BACKWARD),
+ * all with the same Mismatches / Direction / Strand / chromosome. */
+typedef struct {
+    uint32_t abs_loc_first;
+    uint16_t len_first;
+    uint16_t len_last;
+    uint8_t  mismatches;
+    uint8_t  flags;          /* bit0: Direction BACKWARD, bit1: Strand ANTISENSE */
+    int16_t  chr_id;
+} pg_run;
+
+#define PG_RUN_BACKWARD  0x1u
+#define PG_RUN_ANTISENSE 0x2u
+
+/* An expanded UniquePoint. */
+typedef struct {
+    uint32_t abs_loc;
+    int16_t  length;       /* LengthStr  */
+    int16_t  mismatches;
+    int16_t  chr_id;
+    char     direction;    /* '+' FORWARD / '-' BACKWARD */
+    char     strand;       /* '+' SENSE   / '-' ANTISENSE */
+} pg_point;
+
+/* What a search leaves behind for each read (host memory, owned by the result). */
+typedef struct {
+    uint32_t        n_reads;
+    const uint64_t *close_off;   /* n_reads+1: UP_Close runs of read i are close_runs[close_off[i]..close_off[i+1]) */
+    const pg_run   *close_runs;  /* after CleanUniquePoints (pindel.cpp:2904-2941)                                  */
+    const uint64_t *far_off;     /* n_reads+1 (all zero after pg_close_end_batch)                                   */
+    const pg_run   *far_runs;    /* UP_Far                                                                          */
+    const uint8_t  *rc_flag;     /* 1: GetCloseEnd left UnmatchedSeq reverse-complemented (pindel.cpp:2545)         */
+} pg_result_view;
+
+/* ---- lifetime ---------------------------------------------------------- */
+void pg_default_params(pg_params *p);
+int  pg_create(const pg_params *p, pg_ctx **out);
+void pg_destroy(pg_ctx *ctx);
+const char *pg_last_error(const pg_ctx *ctx);
+/* g_maxMismatch as the library computed it (500 entries). */
+int  pg_get_max_mismatch(const pg_ctx *ctx, uint32_t *table500);
+
+/* ---- reference --------------------------------------------------------- */
+/* seq_padded[c] is Chromosome::getSeq(): spacer N's + sequence + spacer N's, ASCII,
+ * upper case ACGTN (anything else is taken as N).  Packs to 2-bit planes + N plane
+ * and uploads to the ctx's GPU. */
+int  pg_load_reference(pg_ctx *ctx, int32_t n_chr, const char *const *names,
+                       const uint8_t *const *seq_padded, const uint64_t *len_padded);
+/* FASTA loader with Genome::loadChromosome's semantics (pindel.cpp:272-312). */
+int  pg_load_fasta(pg_ctx *ctx, const char *path);
+int  pg_reference_n_chr(const pg_ctx *ctx);
+const char *pg_reference_name(const pg_ctx *ctx, int32_t chr_id);
+uint64_t pg_reference_comp_size(const pg_ctx *ctx, int32_t chr_id);   /* getCompSize() */
+/* Unpack [start, start+n) of a chromosome back to ASCII (tests, reporters). */
+int  pg_reference_fetch(const pg_ctx *ctx, int32_t chr_id, uint64_t start, uint64_t n, uint8_t *out);
+
+/* ---- the path, host buffers in / host results out ---------------------- */
+int  pg_close_end_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_result **out);
+/* `close` must be the result of pg_close_end_batch on the same reads (it carries
+ * UP_Close and the rc flags); it is extended in place with UP_Far. */
+int  pg_far_end_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_result *close,
+                      const pg_windows *bd_hints /* nullable */);
+int  pg_search_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_result **out);
+
+int  pg_result_view_get(const pg_result *r, pg_result_view *view);
+void pg_result_free(pg_result *r);
+/* Expand runs to UniquePoints; returns the number of points (call with out = NULL to count). */
+uint64_t pg_expand_runs(const pg_run *runs, uint64_t n_runs, pg_point *out);
+
+/* ---- the path, device-resident (what bench.py times) ------------------- */
+int  pg_device_batch_upload(pg_ctx *ctx, const pg_read_batch *reads, pg_device_batch **out);
+/* Close end + far end for every read of the batch; results stay on the GPU.
+ * Synchronous: returns when the kernels have finished. */
+int  pg_device_batch_search(pg_ctx *ctx, pg_device_batch *b);
+int  pg_device_batch_download(pg_ctx *ctx, pg_device_batch *b, pg_result **out);
+void pg_device_batch_free(pg_ctx *ctx, pg_device_batch *b);
+/* HIP-event duration (ms) of the kernel of the last search on this ctx (events recorded on
+ * the ctx's own stream around the launch) and the number of runs it produced. */
+int  pg_last_search_stats(const pg_ctx *ctx, double *kernel_ms, uint64_t *n_runs);
+/* Algorithmic bytes of the last search of this batch (SURVEY.md 8d formula, accumulated per
+ * read by the kernel; DESIGN.md "roofline accounting").  Copies n x 4 bytes back: call it
+ * outside any timed region. */
+int  pg_device_batch_algorithmic_bytes(pg_ctx *ctx, pg_device_batch *b, double *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PINDEL_PG_H */

@@ -1,0 +1,790 @@
+// pg_api.cpp -- host side of the C ABI declared in include/pindel_pg.h.
+// Owns the GPU context, packs the reference into bit planes, moves read batches
+// to HBM, launches the search kernel (pg_kernels.hip) and turns its pooled runs
+// back into per-read CSR results.  There is NO CPU implementation of the search
+// here: without a working HIP device every entry point fails with PG_E_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "pg_device.h"
+#include "pindel_pg.h"
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct pg_ctx {
+    pg_params prm{};
+    uint32_t mm[512]{};
+    uint16_t thr[512]{};
+    uint8_t *d_mm = nullptr;
+    uint16_t *d_thr = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // reference
+    std::vector<std::string> names;
+    std::vector<uint64_t> comp_size;
+    std::vector<uint64_t> word_off;   // index of the word holding AbsLoc 0
+    std::vector<uint32_t> h_lo, h_hi, h_nn;
+    uint32_t *d_lo = nullptr, *d_hi = nullptr, *d_nn = nullptr;
+    uint64_t *d_word_off = nullptr;
+    uint32_t *d_chr_size = nullptr;
+    // stats of the last search
+    double last_ms = 0.0;
+    uint64_t last_runs = 0;
+    std::string err;
+};
+
+struct pg_device_batch {
+    uint32_t n = 0;
+    uint32_t max_len = 0, levels = 0;
+    uint8_t *seq = nullptr;
+    uint64_t *seq_off = nullptr;
+    uint8_t *strand = nullptr;
+    int32_t *pos = nullptr;
+    int16_t *isz = nullptr;
+    int32_t *chr = nullptr;
+    uint8_t *rc_flag = nullptr;
+    uint32_t *close_last = nullptr;
+    uint16_t *close_max = nullptr;
+    uint64_t *bd_off = nullptr;
+    pg_window *bd = nullptr;
+    uint32_t *close_off = nullptr, *close_cnt = nullptr, *far_off = nullptr, *far_cnt = nullptr;
+    uint32_t *alg = nullptr;
+    pg_run *pool = nullptr;
+    uint32_t pool_cap = 0;
+    uint32_t *pool_used = nullptr;
+    int modes_done = 0;
+};
+
+struct pg_result {
+    uint32_t n = 0;
+    std::vector<uint64_t> close_off, far_off;
+    std::vector<pg_run> close_runs, far_runs;
+    std::vector<uint8_t> rc_flag;
+    std::vector<uint32_t> close_last;
+    std::vector<uint16_t> close_max;
+};
+
+namespace {
+
+int fail(pg_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                   \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? PG_E_NOMEM : PG_E_DEVICE,           \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                  \
+    } while (0)
+
+template <typename T>
+int dev_alloc(pg_ctx *ctx, T **p, size_t n)
+{
+    *p = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T)));
+    return PG_OK;
+}
+
+template <typename T>
+int dev_upload(pg_ctx *ctx, T **p, const T *src, size_t n)
+{
+    int rc = dev_alloc(ctx, p, n);
+    if (rc) return rc;
+    if (n) HIP_TRY(ctx, hipMemcpy(*p, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return PG_OK;
+}
+
+// probOfReadWithTheseErrors / createProbTable, src/pindel.cpp:781-819
+double prob_of_read_with_these_errors(unsigned length, unsigned n_err, double rate)
+{
+    double chance_correct = 1.0 - rate;
+    unsigned n_correct = length - n_err;
+    double matched = pow(chance_correct, (double)n_correct);
+    double mismatched = 1.0;
+    for (unsigned i = 0; i < n_err; i++) mismatched *= (((length - i) * rate) / (n_err - i));
+    return matched * mismatched;
+}
+
+void make_tables(pg_ctx *ctx)
+{
+    const double rate = 0.001 + ctx->prm.seq_error_rate;   // pindel.cpp:856
+    for (unsigned length = 0; length < 500; length++) {
+        double total = 0.0;
+        ctx->mm[length] = 0;
+        for (unsigned n_err = 0; n_err <= length; n_err++) {
+            total += prob_of_read_with_these_errors(length, n_err, rate);
+            if (total > ctx->prm.sensitivity) {
+                ctx->mm[length] = n_err + 1;
+                break;
+            }
+        }
+    }
+    ctx->mm[0] = ctx->mm[1] = ctx->mm[2] = ctx->mm[3] = 0;
+    for (unsigned length = 500; length < 512; length++) ctx->mm[length] = ctx->mm[499];
+    // CheckMismatches: (float)NumMismatches >= (float)(len * MaximumAllowedMismatchRate),
+    // src/searcher.cpp:366,383 -> smallest integer that passes, per read length
+    for (unsigned length = 0; length < 512; length++) {
+        float max_allowed = (float)((double)(size_t)length * ctx->prm.max_allowed_mismatch_rate);
+        unsigned n = 0;
+        while (!((float)n >= max_allowed) && n < 65535) n++;
+        ctx->thr[length] = (uint16_t)n;
+    }
+}
+
+void free_reference(pg_ctx *ctx)
+{
+    if (ctx->d_lo) hipFree(ctx->d_lo);
+    if (ctx->d_hi) hipFree(ctx->d_hi);
+    if (ctx->d_nn) hipFree(ctx->d_nn);
+    if (ctx->d_word_off) hipFree(ctx->d_word_off);
+    if (ctx->d_chr_size) hipFree(ctx->d_chr_size);
+    ctx->d_lo = ctx->d_hi = ctx->d_nn = nullptr;
+    ctx->d_word_off = nullptr;
+    ctx->d_chr_size = nullptr;
+    ctx->names.clear();
+    ctx->comp_size.clear();
+    ctx->word_off.clear();
+    ctx->h_lo.clear();
+    ctx->h_hi.clear();
+    ctx->h_nn.clear();
+}
+
+PgDevRef dev_ref(const pg_ctx *ctx)
+{
+    PgDevRef r;
+    r.lo = ctx->d_lo;
+    r.hi = ctx->d_hi;
+    r.nn = ctx->d_nn;
+    r.chr_word_off = ctx->d_word_off;
+    r.chr_size = ctx->d_chr_size;
+    r.n_chr = (int32_t)ctx->names.size();
+    return r;
+}
+
+PgDevParams dev_params(const pg_ctx *ctx)
+{
+    PgDevParams p;
+    p.max_range_index = ctx->prm.max_range_index;
+    p.add_mm = ctx->prm.additional_mismatch;
+    p.min_perfect = ctx->prm.min_perfect_match_around_bp;
+    p.min_close = ctx->prm.min_close;
+    p.spacer = ctx->prm.spacer;
+    p.mm_tab = ctx->d_mm;
+    p.thr_tab = ctx->d_thr;
+    return p;
+}
+
+void free_batch_buffers(pg_device_batch *b)
+{
+    void *ptrs[] = { b->seq, b->seq_off, b->strand, b->pos, b->isz, b->chr, b->rc_flag,
+                     b->close_last, b->close_max, b->bd_off, b->bd, b->close_off, b->close_cnt,
+                     b->far_off, b->far_cnt, b->alg, b->pool, b->pool_used };
+    for (void *p : ptrs)
+        if (p) hipFree(p);
+}
+
+int validate_and_measure(pg_ctx *ctx, const pg_read_batch *reads, uint32_t *max_len, uint32_t *levels)
+{
+    if (!reads || (reads->n_reads && (!reads->seq_off || !reads->anchor_strand || !reads->anchor_pos ||
+                                      !reads->insert_size || !reads->chr_id)))
+        return fail(ctx, PG_E_INVALID, "null array in pg_read_batch");
+    if (ctx->names.empty()) return fail(ctx, PG_E_NO_REFERENCE, "no reference loaded");
+    uint32_t ml = 1;
+    const int n_chr = (int)ctx->names.size();
+    for (uint32_t i = 0; i < reads->n_reads; i++) {
+        if (reads->seq_off[i + 1] < reads->seq_off[i])
+            return fail(ctx, PG_E_INVALID, "seq_off not monotone");
+        uint64_t len = reads->seq_off[i + 1] - reads->seq_off[i];
+        if (len > PG_MAX_READ_LEN) return fail(ctx, PG_E_READ_TOO_LONG, "read longer than 499 bases");
+        ml = std::max<uint32_t>(ml, (uint32_t)len);
+        int c = reads->chr_id[i];
+        if (c < 0 || c >= n_chr) return fail(ctx, PG_E_INVALID, "chr_id out of range");
+        // the close-end windows (pindel.cpp:2272-2274, 2301-2302) must lie inside the padded string
+        long long apos = (long long)reads->anchor_pos[i] + ctx->prm.spacer;
+        long long isz = reads->insert_size[i];
+        long long lo = apos - 2 * std::max<long long>(isz, 0) - 2, hi = apos + 2 * std::max<long long>(isz, 0) + 2;
+        if (lo < 0 || hi > (long long)ctx->comp_size[c])
+            return fail(ctx, PG_E_INVALID, "anchor position/insert size reach outside the padded chromosome");
+    }
+    *max_len = ml;
+    uint32_t lv = ctx->mm[ml] + (uint32_t)ctx->prm.additional_mismatch + 1;
+    for (uint32_t l = 0; l <= ml; l++)
+        lv = std::max<uint32_t>(lv, ctx->mm[l] + (uint32_t)ctx->prm.additional_mismatch + 1);
+    if (lv > PG_MAX_LEVELS) return fail(ctx, PG_E_UNSUPPORTED, "more than 16 mismatch levels");
+    *levels = lv;
+    return PG_OK;
+}
+
+int upload_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_device_batch **out)
+{
+    uint32_t max_len = 0, levels = 0;
+    int rc = validate_and_measure(ctx, reads, &max_len, &levels);
+    if (rc) return rc;
+    pg_device_batch *b = new pg_device_batch();
+    b->n = reads->n_reads;
+    b->max_len = max_len;
+    b->levels = levels;
+    const size_t n = b->n;
+    const uint64_t base0 = n ? reads->seq_off[0] : 0;
+    const uint64_t nseq = n ? reads->seq_off[n] - base0 : 0;
+    std::vector<uint64_t> off(n + 1);
+    for (size_t i = 0; i <= n; i++) off[i] = (n ? reads->seq_off[i] : 0) - base0;
+#define UP(field, src, cnt)                                            \
+    if ((rc = dev_upload(ctx, &b->field, src, cnt)) != PG_OK) {        \
+        free_batch_buffers(b);                                         \
+        delete b;                                                      \
+        return rc;                                                     \
+    }
+#define AL(field, cnt)                                                 \
+    if ((rc = dev_alloc(ctx, &b->field, cnt)) != PG_OK) {              \
+        free_batch_buffers(b);                                         \
+        delete b;                                                      \
+        return rc;                                                     \
+    }
+    UP(seq, reads->seq ? reads->seq + base0 : nullptr, (size_t)nseq);
+    UP(seq_off, off.data(), n + 1);
+    UP(strand, reads->anchor_strand, n);
+    UP(pos, reads->anchor_pos, n);
+    UP(isz, reads->insert_size, n);
+    UP(chr, reads->chr_id, n);
+    AL(rc_flag, n);
+    AL(close_last, n);
+    AL(close_max, n);
+    AL(close_off, n);
+    AL(close_cnt, n);
+    AL(far_off, n);
+    AL(far_cnt, n);
+    AL(alg, n);
+    AL(pool_used, 1);
+    b->pool_cap = (uint32_t)std::min<uint64_t>(3ull * n + 1024ull, 0x7fffffffull);
+    AL(pool, b->pool_cap);
+#undef UP
+#undef AL
+    hipMemset(b->close_cnt, 0, std::max<size_t>(n, 1) * sizeof(uint32_t));
+    hipMemset(b->far_cnt, 0, std::max<size_t>(n, 1) * sizeof(uint32_t));
+    hipMemset(b->close_off, 0, std::max<size_t>(n, 1) * sizeof(uint32_t));
+    hipMemset(b->far_off, 0, std::max<size_t>(n, 1) * sizeof(uint32_t));
+    hipMemset(b->rc_flag, 0, std::max<size_t>(n, 1));
+    hipMemset(b->close_max, 0, std::max<size_t>(n, 1) * sizeof(uint16_t));
+    hipMemset(b->alg, 0, std::max<size_t>(n, 1) * sizeof(uint32_t));
+    *out = b;
+    return PG_OK;
+}
+
+PgDevBatch dev_batch(const pg_device_batch *b)
+{
+    PgDevBatch d;
+    d.n_reads = b->n;
+    d.first_read = 0;
+    d.seq = b->seq;
+    d.seq_off = b->seq_off;
+    d.strand = b->strand;
+    d.pos = b->pos;
+    d.isz = b->isz;
+    d.chr = b->chr;
+    d.rc_flag = b->rc_flag;
+    d.close_last_abs = b->close_last;
+    d.close_max_len = b->close_max;
+    d.bd_off = b->bd_off;
+    d.bd = b->bd;
+    d.close_run_off = b->close_off;
+    d.close_run_cnt = b->close_cnt;
+    d.far_run_off = b->far_off;
+    d.far_run_cnt = b->far_cnt;
+    d.pool = b->pool;
+    d.pool_cap = b->pool_cap;
+    d.pool_used = b->pool_used;
+    d.alg_bytes = b->alg;
+    return d;
+}
+
+// Runs the kernel in `mode`; the run pool is regrown and the launch repeated if it overflowed
+// (still entirely on the GPU).  In FAR mode the close runs already in the pool are kept.
+int run_search(pg_ctx *ctx, pg_device_batch *b, int mode)
+{
+    if (ctx->names.empty()) return fail(ctx, PG_E_NO_REFERENCE, "no reference loaded");
+    PgDevRef ref = dev_ref(ctx);
+    PgDevParams prm = dev_params(ctx);
+    uint32_t keep = 0;   // pool entries that must survive (close runs before a FAR pass)
+    if (mode == PG_MODE_FAR && (b->modes_done & PG_MODE_CLOSE))
+        HIP_TRY(ctx, hipMemcpy(&keep, b->pool_used, sizeof keep, hipMemcpyDeviceToHost));
+    double total_ms = 0.0;
+    for (int attempt = 0; attempt < 8; attempt++) {
+        HIP_TRY(ctx, hipMemcpyAsync(b->pool_used, &keep, sizeof keep, hipMemcpyHostToDevice, ctx->stream));
+        PgDevBatch d = dev_batch(b);
+        HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        int lrc = pg_launch_search(&ref, &prm, &d, mode, b->max_len, b->levels, ctx->stream);
+        if (lrc != 0) return fail(ctx, PG_E_DEVICE, std::string("kernel launch: ") + hipGetErrorString((hipError_t)lrc));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        total_ms = ms;
+        uint32_t used = 0;
+        HIP_TRY(ctx, hipMemcpy(&used, b->pool_used, sizeof used, hipMemcpyDeviceToHost));
+        if (used <= b->pool_cap) {
+            ctx->last_ms = total_ms;
+            ctx->last_runs = used;
+            b->modes_done |= mode;
+            return PG_OK;
+        }
+        // overflow: grow the pool (keeping the close runs) and redo the launch
+        uint32_t ncap = (uint32_t)std::min<uint64_t>((uint64_t)used + used / 4 + 1024, 0x7fffffffull);
+        pg_run *npool = nullptr;
+        int rc = dev_alloc(ctx, &npool, ncap);
+        if (rc) return rc;
+        if (keep) HIP_TRY(ctx, hipMemcpy(npool, b->pool, (size_t)keep * sizeof(pg_run), hipMemcpyDeviceToDevice));
+        hipFree(b->pool);
+        b->pool = npool;
+        b->pool_cap = ncap;
+    }
+    return fail(ctx, PG_E_DEVICE, "run pool kept overflowing");
+}
+
+int download(pg_ctx *ctx, pg_device_batch *b, pg_result *r)
+{
+    const size_t n = b->n;
+    r->n = b->n;
+    std::vector<uint32_t> coff(n), ccnt(n), foff(n), fcnt(n);
+    uint32_t used = 0;
+    HIP_TRY(ctx, hipMemcpy(&used, b->pool_used, sizeof used, hipMemcpyDeviceToHost));
+    std::vector<pg_run> pool(used);
+    if (n) {
+        HIP_TRY(ctx, hipMemcpy(coff.data(), b->close_off, n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(ccnt.data(), b->close_cnt, n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(foff.data(), b->far_off, n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(fcnt.data(), b->far_cnt, n * 4, hipMemcpyDeviceToHost));
+    }
+    if (used) HIP_TRY(ctx, hipMemcpy(pool.data(), b->pool, (size_t)used * sizeof(pg_run), hipMemcpyDeviceToHost));
+    r->rc_flag.resize(n);
+    r->close_last.resize(n);
+    r->close_max.resize(n);
+    if (n) {
+        HIP_TRY(ctx, hipMemcpy(r->rc_flag.data(), b->rc_flag, n, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(r->close_last.data(), b->close_last, n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(r->close_max.data(), b->close_max, n * 2, hipMemcpyDeviceToHost));
+    }
+    const bool has_close = b->modes_done & PG_MODE_CLOSE, has_far = b->modes_done & PG_MODE_FAR;
+    r->close_off.assign(n + 1, 0);
+    r->far_off.assign(n + 1, 0);
+    for (size_t i = 0; i < n; i++) {
+        r->close_off[i + 1] = r->close_off[i] + (has_close ? ccnt[i] : 0);
+        r->far_off[i + 1] = r->far_off[i] + (has_far ? fcnt[i] : 0);
+    }
+    r->close_runs.resize(r->close_off[n]);
+    r->far_runs.resize(r->far_off[n]);
+    for (size_t i = 0; i < n; i++) {
+        if (has_close && ccnt[i])
+            memcpy(&r->close_runs[r->close_off[i]], &pool[coff[i]], (size_t)ccnt[i] * sizeof(pg_run));
+        if (has_far && fcnt[i])
+            memcpy(&r->far_runs[r->far_off[i]], &pool[foff[i]], (size_t)fcnt[i] * sizeof(pg_run));
+    }
+    return PG_OK;
+}
+
+}  // namespace
+
+// ============================================================================== C ABI
+extern "C" {
+
+void pg_default_params(pg_params *p)
+{
+    if (!p) return;
+    memset(p, 0, sizeof *p);
+    p->abi_version = PG_ABI_VERSION;
+    p->device = 0;
+    p->max_range_index = 2;
+    p->additional_mismatch = 1;
+    p->min_perfect_match_around_bp = 3;
+    p->min_close = 8;
+    p->max_allowed_mismatch_rate = 0.02;
+    p->seq_error_rate = 0.01;
+    p->sensitivity = 0.95;
+    p->spacer = 100000;
+}
+
+int pg_create(const pg_params *p, pg_ctx **out)
+{
+    if (!p || !out) return PG_E_INVALID;
+    *out = nullptr;
+    if (p->abi_version != PG_ABI_VERSION) return PG_E_INVALID;
+    pg_ctx *ctx = new pg_ctx();
+    ctx->prm = *p;
+    // pindel.cpp:921-930: -x capped at g_MAX_RANGE_INDEX (9), -a raised to 1
+    if (ctx->prm.max_range_index > 9) ctx->prm.max_range_index = 9;
+    if (ctx->prm.max_range_index < 0) ctx->prm.max_range_index = 0;
+    if (ctx->prm.additional_mismatch < 1) ctx->prm.additional_mismatch = 1;
+    if (ctx->prm.min_close < 1 || ctx->prm.min_close > 64 || ctx->prm.min_perfect_match_around_bp < 0 ||
+        ctx->prm.min_perfect_match_around_bp > 64) {
+        delete ctx;
+        return PG_E_UNSUPPORTED;
+    }
+    make_tables(ctx);
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0 || p->device < 0 || p->device >= n_dev) {
+        // No HIP device: there is deliberately no CPU path behind this ABI.
+        delete ctx;
+        return PG_E_DEVICE;
+    }
+    if (hipSetDevice(p->device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx;
+        return PG_E_DEVICE;
+    }
+    uint8_t mm8[512];
+    for (int i = 0; i < 512; i++) mm8[i] = (uint8_t)std::min<uint32_t>(ctx->mm[i], 255u);
+    if (dev_upload(ctx, &ctx->d_mm, mm8, 512) || dev_upload(ctx, &ctx->d_thr, ctx->thr, 512)) {
+        pg_destroy(ctx);
+        return PG_E_DEVICE;
+    }
+    *out = ctx;
+    return PG_OK;
+}
+
+void pg_destroy(pg_ctx *ctx)
+{
+    if (!ctx) return;
+    free_reference(ctx);
+    if (ctx->d_mm) hipFree(ctx->d_mm);
+    if (ctx->d_thr) hipFree(ctx->d_thr);
+    if (ctx->ev0) hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *pg_last_error(const pg_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int pg_get_max_mismatch(const pg_ctx *ctx, uint32_t *table500)
+{
+    if (!ctx || !table500) return PG_E_INVALID;
+    memcpy(table500, ctx->mm, 500 * sizeof(uint32_t));
+    return PG_OK;
+}
+
+int pg_load_reference(pg_ctx *ctx, int32_t n_chr, const char *const *names,
+                      const uint8_t *const *seq_padded, const uint64_t *len_padded)
+{
+    if (!ctx || n_chr <= 0 || !seq_padded || !len_padded) return fail(ctx, PG_E_INVALID, "bad reference arguments");
+    if (n_chr > 32767) return fail(ctx, PG_E_UNSUPPORTED, "more than 32767 chromosomes");
+    free_reference(ctx);
+    uint64_t total_words = 0;
+    for (int c = 0; c < n_chr; c++) {
+        if (len_padded[c] >= 0xffffffffull) return fail(ctx, PG_E_UNSUPPORTED, "chromosome longer than 2^32 bases");
+        if (len_padded[c] < 2ull * ctx->prm.spacer) return fail(ctx, PG_E_INVALID, "chromosome shorter than its spacers");
+        total_words += PG_GUARD_WORDS;
+        ctx->word_off.push_back(total_words);
+        total_words += (len_padded[c] + 31) / 32 + PG_GUARD_WORDS;
+        ctx->names.push_back(names && names[c] ? names[c] : "");
+        ctx->comp_size.push_back(len_padded[c]);
+    }
+    total_words += 8;
+    try {
+        ctx->h_lo.assign(total_words, 0u);
+        ctx->h_hi.assign(total_words, 0u);
+        ctx->h_nn.assign(total_words, 0xffffffffu);   // guards and tails are N
+    } catch (...) {
+        free_reference(ctx);
+        return fail(ctx, PG_E_NOMEM, "host memory for the packed reference");
+    }
+    uint8_t code[256];
+    memset(code, 4, sizeof code);
+    code['A'] = 0; code['C'] = 1; code['G'] = 2; code['T'] = 3;
+    for (int c = 0; c < n_chr; c++) {
+        const uint8_t *s = seq_padded[c];
+        const uint64_t len = len_padded[c];
+        uint32_t *lo = &ctx->h_lo[ctx->word_off[c]], *hi = &ctx->h_hi[ctx->word_off[c]],
+                 *nn = &ctx->h_nn[ctx->word_off[c]];
+        for (uint64_t w = 0; w * 32 < len; w++) {
+            uint32_t l = 0, h = 0, n = 0xffffffffu;
+            const uint64_t b0 = w * 32, cnt = std::min<uint64_t>(32, len - b0);
+            for (uint64_t k = 0; k < cnt; k++) {
+                uint8_t cd = code[s[b0 + k]];
+                if (cd < 4) {
+                    l |= (uint32_t)(cd & 1u) << k;
+                    h |= (uint32_t)(cd >> 1) << k;
+                    n &= ~(1u << k);
+                }
+            }
+            lo[w] = l; hi[w] = h; nn[w] = n;
+        }
+    }
+    std::vector<uint32_t> sizes(n_chr);
+    for (int c = 0; c < n_chr; c++) sizes[c] = (uint32_t)len_padded[c];
+    int rc;
+    if ((rc = dev_upload(ctx, &ctx->d_lo, ctx->h_lo.data(), ctx->h_lo.size())) ||
+        (rc = dev_upload(ctx, &ctx->d_hi, ctx->h_hi.data(), ctx->h_hi.size())) ||
+        (rc = dev_upload(ctx, &ctx->d_nn, ctx->h_nn.data(), ctx->h_nn.size())) ||
+        (rc = dev_upload(ctx, &ctx->d_word_off, ctx->word_off.data(), ctx->word_off.size())) ||
+        (rc = dev_upload(ctx, &ctx->d_chr_size, sizes.data(), sizes.size()))) {
+        free_reference(ctx);
+        return rc;
+    }
+    return PG_OK;
+}
+
+int pg_load_fasta(pg_ctx *ctx, const char *path)
+{
+    if (!ctx || !path) return fail(ctx, PG_E_INVALID, "bad fasta arguments");
+    std::ifstream in(path, std::ios::binary);
+    if (!in) return fail(ctx, PG_E_INVALID, std::string("cannot open ") + path);
+    std::string data((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    // Genome::loadChromosome (pindel.cpp:272-312): name = first token after '>', every
+    // non-blank character is upper-cased, non-ACGT -> N, spacer N's both sides.  The
+    // reference's extraction loop appends the final base of the LAST record twice.
+    std::vector<std::string> names, seqs;
+    size_t i = 0;
+    const size_t n = data.size();
+    while (i < n && isspace((unsigned char)data[i])) i++;
+    if (i >= n || data[i] != '>') return fail(ctx, PG_E_INVALID, "fasta does not start with '>'");
+    const std::string spacer(ctx->prm.spacer, 'N');
+    while (i < n) {
+        i++;   // '>'
+        while (i < n && (data[i] == ' ' || data[i] == '\t')) i++;
+        size_t j = i;
+        while (j < n && !isspace((unsigned char)data[j])) j++;
+        names.push_back(data.substr(i, j - i));
+        while (j < n && data[j] != '\n') j++;
+        std::string s = spacer;
+        i = j;
+        while (i < n && data[i] != '>') {
+            unsigned char ch = (unsigned char)data[i++];
+            if (isspace(ch)) continue;
+            ch = (unsigned char)toupper(ch);
+            if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T') ch = 'N';
+            s.push_back((char)ch);
+        }
+        if (i >= n && s.size() > spacer.size()) s.push_back(s.back());
+        s += spacer;
+        seqs.push_back(std::move(s));
+    }
+    std::vector<const char *> np;
+    std::vector<const uint8_t *> sp;
+    std::vector<uint64_t> lp;
+    for (size_t c = 0; c < seqs.size(); c++) {
+        np.push_back(names[c].c_str());
+        sp.push_back((const uint8_t *)seqs[c].data());
+        lp.push_back(seqs[c].size());
+    }
+    return pg_load_reference(ctx, (int32_t)seqs.size(), np.data(), sp.data(), lp.data());
+}
+
+int pg_reference_n_chr(const pg_ctx *ctx) { return ctx ? (int)ctx->names.size() : 0; }
+
+const char *pg_reference_name(const pg_ctx *ctx, int32_t c)
+{
+    return (ctx && c >= 0 && c < (int)ctx->names.size()) ? ctx->names[c].c_str() : nullptr;
+}
+
+uint64_t pg_reference_comp_size(const pg_ctx *ctx, int32_t c)
+{
+    return (ctx && c >= 0 && c < (int)ctx->names.size()) ? ctx->comp_size[c] : 0;
+}
+
+int pg_reference_fetch(const pg_ctx *ctx, int32_t c, uint64_t start, uint64_t n, uint8_t *out)
+{
+    if (!ctx || !out || c < 0 || c >= (int)ctx->names.size()) return PG_E_INVALID;
+    if (start + n > ctx->comp_size[c]) return PG_E_INVALID;
+    const uint32_t *lo = &ctx->h_lo[ctx->word_off[c]], *hi = &ctx->h_hi[ctx->word_off[c]],
+                   *nn = &ctx->h_nn[ctx->word_off[c]];
+    for (uint64_t k = 0; k < n; k++) {
+        uint64_t p = start + k;
+        uint32_t w = (uint32_t)(p >> 5), b = (uint32_t)(p & 31);
+        if ((nn[w] >> b) & 1u) out[k] = 'N';
+        else out[k] = "ACGT"[((lo[w] >> b) & 1u) | (((hi[w] >> b) & 1u) << 1)];
+    }
+    return PG_OK;
+}
+
+// ---------------------------------------------------------------- device-resident
+int pg_device_batch_upload(pg_ctx *ctx, const pg_read_batch *reads, pg_device_batch **out)
+{
+    if (!ctx || !out) return PG_E_INVALID;
+    *out = nullptr;
+    return upload_batch(ctx, reads, out);
+}
+
+int pg_device_batch_search(pg_ctx *ctx, pg_device_batch *b)
+{
+    if (!ctx || !b) return PG_E_INVALID;
+    b->modes_done = 0;
+    return run_search(ctx, b, PG_MODE_BOTH);
+}
+
+int pg_device_batch_download(pg_ctx *ctx, pg_device_batch *b, pg_result **out)
+{
+    if (!ctx || !b || !out) return PG_E_INVALID;
+    pg_result *r = new pg_result();
+    int rc = download(ctx, b, r);
+    if (rc) {
+        delete r;
+        return rc;
+    }
+    *out = r;
+    return PG_OK;
+}
+
+void pg_device_batch_free(pg_ctx *ctx, pg_device_batch *b)
+{
+    (void)ctx;
+    if (!b) return;
+    free_batch_buffers(b);
+    delete b;
+}
+
+int pg_last_search_stats(const pg_ctx *ctx, double *kernel_ms, uint64_t *n_runs)
+{
+    if (!ctx) return PG_E_INVALID;
+    if (kernel_ms) *kernel_ms = ctx->last_ms;
+    if (n_runs) *n_runs = ctx->last_runs;
+    return PG_OK;
+}
+
+int pg_device_batch_algorithmic_bytes(pg_ctx *ctx, pg_device_batch *b, double *bytes)
+{
+    if (!ctx || !b || !bytes) return PG_E_INVALID;
+    std::vector<uint32_t> alg(b->n);
+    if (b->n) HIP_TRY(ctx, hipMemcpy(alg.data(), b->alg, (size_t)b->n * 4, hipMemcpyDeviceToHost));
+    double s = 0.0;
+    for (uint32_t v : alg) s += v;
+    *bytes = s;
+    return PG_OK;
+}
+
+// ---------------------------------------------------------------- host in / host out
+static int search_host(pg_ctx *ctx, const pg_read_batch *reads, int mode, pg_result **out)
+{
+    if (!ctx || !out) return PG_E_INVALID;
+    *out = nullptr;
+    pg_device_batch *b = nullptr;
+    int rc = upload_batch(ctx, reads, &b);
+    if (rc) return rc;
+    rc = run_search(ctx, b, mode);
+    pg_result *r = nullptr;
+    if (!rc) {
+        r = new pg_result();
+        rc = download(ctx, b, r);
+    }
+    free_batch_buffers(b);
+    delete b;
+    if (rc) {
+        delete r;
+        return rc;
+    }
+    *out = r;
+    return PG_OK;
+}
+
+int pg_close_end_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_result **out)
+{
+    return search_host(ctx, reads, PG_MODE_CLOSE, out);
+}
+
+int pg_search_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_result **out)
+{
+    return search_host(ctx, reads, PG_MODE_BOTH, out);
+}
+
+int pg_far_end_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_result *close, const pg_windows *bd_hints)
+{
+    if (!ctx || !reads || !close) return PG_E_INVALID;
+    if (close->n != reads->n_reads) return fail(ctx, PG_E_INVALID, "close result does not belong to these reads");
+    pg_device_batch *b = nullptr;
+    int rc = upload_batch(ctx, reads, &b);
+    if (rc) return rc;
+    const size_t n = b->n;
+    auto bail = [&](int code) {
+        free_batch_buffers(b);
+        delete b;
+        return code;
+    };
+    if (n) {
+        if (hipMemcpy(b->rc_flag, close->rc_flag.data(), n, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(b->close_last, close->close_last.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(b->close_max, close->close_max.data(), n * 2, hipMemcpyHostToDevice) != hipSuccess)
+            return bail(fail(ctx, PG_E_DEVICE, "upload of close-end summary failed"));
+    }
+    if (bd_hints && bd_hints->offset && n) {
+        const uint64_t nw = bd_hints->offset[n];
+        for (size_t i = 0; i < n; i++) {
+            if (bd_hints->offset[i + 1] < bd_hints->offset[i] ||
+                bd_hints->offset[i + 1] - bd_hints->offset[i] > PG_MAX_BD_WINDOWS)
+                return bail(fail(ctx, PG_E_UNSUPPORTED, "more than 127 windows in a BreakDancer cluster"));
+        }
+        for (uint64_t k = 0; k < nw; k++) {
+            const pg_window &w = bd_hints->windows[k];
+            if (w.chr_id < 0 || w.chr_id >= (int)ctx->names.size())
+                return bail(fail(ctx, PG_E_INVALID, "BreakDancer window on unknown chromosome"));
+            long long st = w.start < 0 ? (long long)w.end - 1 : w.start;
+            if ((long long)w.end - st >= (1ll << PG_REL_BITS))
+                return bail(fail(ctx, PG_E_UNSUPPORTED, "BreakDancer window larger than 2^26 bases"));
+        }
+        if ((rc = dev_upload(ctx, &b->bd_off, bd_hints->offset, n + 1)) ||
+            (rc = dev_upload(ctx, &b->bd, bd_hints->windows, (size_t)nw)))
+            return bail(rc);
+    }
+    rc = run_search(ctx, b, PG_MODE_FAR);
+    if (rc) return bail(rc);
+    pg_result tmp;
+    rc = download(ctx, b, &tmp);
+    if (rc) return bail(rc);
+    close->far_off.swap(tmp.far_off);
+    close->far_runs.swap(tmp.far_runs);
+    return bail(PG_OK);
+}
+
+int pg_result_view_get(const pg_result *r, pg_result_view *v)
+{
+    if (!r || !v) return PG_E_INVALID;
+    v->n_reads = r->n;
+    v->close_off = r->close_off.data();
+    v->close_runs = r->close_runs.data();
+    v->far_off = r->far_off.data();
+    v->far_runs = r->far_runs.data();
+    v->rc_flag = r->rc_flag.data();
+    return PG_OK;
+}
+
+void pg_result_free(pg_result *r) { delete r; }
+
+uint64_t pg_expand_runs(const pg_run *runs, uint64_t n_runs, pg_point *out)
+{
+    uint64_t k = 0;
+    for (uint64_t i = 0; i < n_runs; i++) {
+        const pg_run &r = runs[i];
+        const bool back = r.flags & PG_RUN_BACKWARD;
+        for (uint32_t L = r.len_first; L <= r.len_last; L++, k++) {
+            if (!out) continue;
+            pg_point &p = out[k];
+            uint32_t d = L - r.len_first;
+            p.abs_loc = back ? r.abs_loc_first - d : r.abs_loc_first + d;
+            p.length = (int16_t)L;
+            p.mismatches = r.mismatches;
+            p.chr_id = r.chr_id;
+            p.direction = back ? '-' : '+';
+            p.strand = (r.flags & PG_RUN_ANTISENSE) ? '-' : '+';
+        }
+    }
+    return k;
+}
+
+}  // extern "C"

@@ -1,0 +1,112 @@
+// pg_device.h -- structures shared by the host API (pg_api.cpp) and the HIP
+// kernels (pg_kernels.hip).  Not part of the public C ABI.
+#ifndef PG_DEVICE_H
+#define PG_DEVICE_H
+
+#include <stdint.h>
+#include "pindel_pg.h"
+
+// Reference in HBM: three 1-bit planes per chromosome ("2-bit planar" + N plane),
+// 32 bases per 32-bit word, indexed by AbsLoc (spacer-padded coordinates).
+//   lo bit = code & 1, hi bit = code >> 1, code: A=0 C=1 G=2 T=3; nn bit = base is N.
+// Every chromosome is preceded and followed by PG_GUARD_WORDS words of N so that a
+// staged window may overhang either end without bounds checks.
+#define PG_GUARD_WORDS 64u
+
+struct PgDevRef {
+    const uint32_t *lo;
+    const uint32_t *hi;
+    const uint32_t *nn;
+    const uint64_t *chr_word_off;  // [n_chr] index of the word holding AbsLoc 0
+    const uint32_t *chr_size;      // [n_chr] getCompSize()
+    int32_t n_chr;
+};
+
+struct PgDevParams {
+    int32_t max_range_index;
+    int32_t add_mm;          // ADDITIONAL_MISMATCH
+    int32_t min_perfect;     // Min_Perfect_Match_Around_BP
+    int32_t min_close;       // g_MinClose
+    uint32_t spacer;
+    const uint8_t *mm_tab;   // [512] g_maxMismatch[L]
+    const uint16_t *thr_tab; // [512] smallest n with (float)n >= (float)(len * u)
+};
+
+enum PgMode { PG_MODE_CLOSE = 1, PG_MODE_FAR = 2, PG_MODE_BOTH = 3 };
+
+struct PgDevBatch {
+    uint32_t n_reads;
+    uint32_t first_read;           // offset into the batch arrays handled by this launch
+    const uint8_t *seq;
+    const uint64_t *seq_off;
+    const uint8_t *strand;
+    const int32_t *pos;
+    const int16_t *isz;
+    const int32_t *chr;
+    // close-end summary: written in CLOSE/BOTH mode, read in FAR mode
+    uint8_t *rc_flag;
+    uint32_t *close_last_abs;      // getLastAbsLocCloseEnd()
+    uint16_t *close_max_len;       // MaxLenCloseEnd(), 0 = no close end
+    // BreakDancer hints (nullable)
+    const uint64_t *bd_off;
+    const pg_window *bd;
+    // outputs: runs go to a bump-allocated pool, (offset, count) per read
+    uint32_t *close_run_off;
+    uint32_t *close_run_cnt;
+    uint32_t *far_run_off;
+    uint32_t *far_run_cnt;
+    pg_run *pool;
+    uint32_t pool_cap;
+    uint32_t *pool_used;           // atomic cursor; > pool_cap means overflow (retry bigger)
+    uint32_t *alg_bytes;           // [n] algorithmic bytes per read, nullable
+};
+
+// Bit layout of the 64-bit histogram word: count in the low 28 bits, candidate id above.
+#define PG_CNT_BITS 28
+#define PG_REL_BITS 26            // position relative to the region origin
+#define PG_MAX_LEVELS 16
+
+// Dynamic LDS layout (bytes), computed identically on host and device.
+struct PgLdsLayout {
+    uint32_t hist_off, carry_off, win_off, runs_off, total;
+    uint32_t lh;        // histogram row length (max read length in the launch)
+    uint32_t levels;    // max TOTAL_SNP_ERROR_CHECKED in the launch
+    uint32_t win_words; // LDS window capacity in 32-base words
+    uint32_t run_cap;   // capacity of each of the three run buffers
+};
+
+#define PG_CHUNK 2048u            // window positions staged per LDS fill
+
+static inline
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+PgLdsLayout pg_lds_layout(uint32_t max_len, uint32_t levels, uint32_t nb)
+{
+    PgLdsLayout l;
+    l.lh = max_len + 1;
+    l.levels = levels;
+    l.hist_off = 0;
+    l.carry_off = l.hist_off + l.levels * l.lh * 8u;
+    l.win_off = (l.carry_off + l.levels * 8u + 15u) & ~15u;
+    // chunk + overhang of nb 64-base blocks on both sides + alignment slack
+    l.win_words = (PG_CHUNK + 2u * (64u * nb)) / 32u + 4u;
+    l.runs_off = l.win_off + l.win_words * 16u;
+    l.run_cap = max_len + 1;
+    l.total = l.runs_off + 3u * l.run_cap * 12u;
+    l.total = (l.total + 15u) & ~15u;
+    return l;
+}
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+// Launches the search kernel for reads [first, first+n) of the batch on `stream`.
+// nb = number of 64-base blocks the longest read needs (2, 4 or 8).
+int pg_launch_search(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch *batch,
+                     int mode, uint32_t max_len, uint32_t levels, void *stream);
+#ifdef __cplusplus
+}
+#endif
+
+#endif

@@ -1,0 +1,35 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_available():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def engine_factory():
+    """Creates pindel_amd Engines; fails loudly (no fallback) when the HIP library cannot run."""
+    from pindel_amd import binding
+    engines = []
+
+    def make(**kw):
+        e = binding.Engine(**kw)
+        engines.append(e)
+        return e
+    yield make
+    for e in engines:
+        e.close()
