@@ -1,0 +1,160 @@
+#!/usr/bin/env python
+"""bench.py -- one-end-anchored reads/s through the split-read search (close end + far end).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path (pg_device_batch_search: close-end + far-end kernel)
+over one batch of synthetic reads already resident in HBM.  Workload at N=1 = BASELINE.json
+configs[2]: 10 M x 100 bp one-end-anchored reads on a chr20-shaped reference, all SV types,
+Pindel defaults (-x 2 ...).  Reads shard across ranks (each rank generates its own 10 M reads,
+reference replicated per GPU, no collective on the data path) -> weak scaling.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CHR20_LEN = 62_435_964       # demo/hs_ref_chr20.fa.fai:1
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(chroms, batch, params_kw, budget_s=15.0):
+    """Time the CPU restatement (oracle, OpenMP over reads) on a bounded sample of the same reads."""
+    from oracle import pyoracle
+    cores = os.cpu_count() or 1
+    p = pyoracle.make_params(**params_kw)
+    seqs = [s for _, s in chroms]
+
+    def run(n):
+        b = batch.slice(0, n)
+        t0 = time.perf_counter()
+        pyoracle.search_batch(p, seqs, b.seq, b.seq_off, b.anchor_strand, b.anchor_pos,
+                              b.insert_size, b.chr_id, n_threads=cores)
+        return time.perf_counter() - t0
+
+    n0 = min(batch.n, 20000)
+    t = run(n0)                          # also warms the pages
+    rate = n0 / max(t, 1e-6)
+    n1 = int(min(batch.n, max(n0, rate * budget_s), 400000))
+    t1 = run(n1)
+    return {"value": n1 / t1, "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": f"first {n1} reads of the rank-0 batch, close+far end, OpenMP {cores} threads, {t1:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
+    ap.add_argument("--read-len", type=int, default=100)
+    ap.add_argument("--chr-len", type=int, default=CHR20_LEN)
+    ap.add_argument("--max-range-index", type=int, default=2, help="Pindel -x")
+    ap.add_argument("--seed", type=int, default=20260927)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from pindel_amd import binding, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    params_kw = dict(max_range_index=args.max_range_index)
+    # ---- synthetic inputs: reference identical on every rank, reads sharded by rank
+    ref = synth.make_reference(args.chr_len, seed=args.seed, device=dev)
+    chroms = [("20", ref)]
+    batch = synth.make_reads(ref, args.reads, read_len=args.read_len, seed=args.seed + 1 + rank,
+                             device=dev)
+    eng = binding.Engine(device=local_rank, **params_kw)
+    eng.load_reference(chroms)
+    dbatch = eng.upload(batch)           # inputs resident in HBM before the timed region
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.search_device(dbatch)
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for _ in range(args.steps):
+        eng.search_device(dbatch)        # synchronous: returns when the kernel finished
+        kernel_ms.append(eng.last_stats()[0])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    alg_bytes = eng.algorithmic_bytes(dbatch)     # per launch (outside the timed region)
+    n_runs = eng.last_stats()[1]
+    res = eng.download(dbatch)
+    n_close = int((res.close_off[1:] > res.close_off[:-1]).sum())
+    n_far = int((res.far_off[1:] > res.far_off[:-1]).sum())
+
+    if rank == 0:
+        avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "one-end-anchored reads/sec through split-read search (close end + far end)",
+            "value": world * args.reads * args.steps / elapsed,
+            "unit": "reads/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {
+                "workload": (f"BASELINE configs[2]: synthetic {args.reads} x {args.read_len} bp "
+                             f"one-end-anchored reads per GPU on a chr20-shaped reference "
+                             f"({args.chr_len} bp), all SV types (D/SI/TD/INV/none), Pindel defaults "
+                             f"-x {args.max_range_index} -a 1 -m 3 -u 0.02 -e 0.01 -E 0.95 -H 8"),
+                "reads_per_gpu": args.reads, "read_len": args.read_len, "insert_size": 500,
+                "parallelism": f"reads sharded over {world} GPU(s), reference replicated, no collective",
+                "reads_with_close_end": n_close, "reads_with_far_end": n_far, "runs_out": int(n_runs),
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "pg_search_kernel", "kernel_ms": avg_ms,
+                "algorithmic_bytes_per_launch": alg_bytes,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(chroms, batch, params_kw)
+        print(json.dumps(out), flush=True)
+    eng.free_device_batch(dbatch)
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

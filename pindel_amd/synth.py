@@ -1,135 +1,144 @@
 """Seeded synthetic inputs: a chr20-shaped reference and
 one-end-anchored reads carrying deletions, short insertions, tandem duplications,
-inversions or nothing, with base errors and N's.  Vectorised numpy; used by the
-tests (small sizes) and by bench.py (BASELINE.json configs).  There is no network,
-so real WGS data cannot be fetched -- everything here is generated.
+inversions or nothing, with base errors and N's.  Written with torch tensor ops so
+the same code generates small test inputs on the CPU and the 10 M-read bench inputs
+on the GPU in seconds (torch is plumbing here: RNG + gathers).  There is no network,
+so real WGS data cannot be fetched -- everything is generated.
 """
 from __future__ import annotations
 
+import math
+
 import numpy as np
+import torch
 
 from .hostio import SPACER, ReadBatch
 
-_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
-_COMP = np.zeros(256, dtype=np.uint8)
+_COMP = torch.zeros(256, dtype=torch.uint8)
 for _a, _b in zip(b"ACGTN", b"TGCAN"):
     _COMP[_a] = _b
+_ACGT = torch.tensor(list(b"ACGT"), dtype=torch.uint8)
+
+
+def _gen(seed, device):
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    return g
 
 
 def make_reference(length: int, seed: int = 20260927, n_gaps: int = 3, gap_len: int = 50000,
                    repeat_len: int = 2000, n_repeat_copies: int = 4, microsat_len: int = 600,
-                   spacer: int = SPACER) -> bytes:
+                   spacer: int = SPACER, device="cpu") -> bytes:
     """i.i.d. ACGT with a few N gaps, one repeat family and an AC microsatellite,
-    returned spacer-padded like Chromosome::getSeq()."""
-    rng = np.random.default_rng(seed)
-    seq = _ACGT[rng.integers(0, 4, size=length, dtype=np.uint8)]
+    returned spacer-padded like Chromosome::getSeq() (src/pindel.cpp:297-309)."""
+    g = _gen(seed, device)
+    code = torch.randint(0, 4, (length,), generator=g, device=device, dtype=torch.uint8)
+    seq = _ACGT.to(device)[code.long()]
     if length > 20 * (gap_len + repeat_len + microsat_len):
-        for g in range(n_gaps):
-            s = int(length * (g + 1) / (n_gaps + 1.5))
+        for k in range(n_gaps):
+            s = int(length * (k + 1) / (n_gaps + 1.5))
             seq[s:s + gap_len] = ord("N")
-        unit = seq[1000:1000 + repeat_len].copy()
+        unit = seq[1000:1000 + repeat_len].clone()
         for k in range(n_repeat_copies):
             s = int(length * (0.07 + 0.11 * k))
             seq[s:s + repeat_len] = unit
         s = int(length * 0.61)
-        seq[s:s + microsat_len] = np.resize(np.frombuffer(b"AC", dtype=np.uint8), microsat_len)
-    pad = np.full(spacer, ord("N"), dtype=np.uint8)
-    return np.concatenate([pad, seq, pad]).tobytes()
+        ac = torch.tensor([ord("A"), ord("C")], dtype=torch.uint8, device=device)
+        seq[s:s + microsat_len] = ac.repeat(microsat_len // 2 + 1)[:microsat_len]
+    pad = torch.full((spacer,), ord("N"), dtype=torch.uint8, device=device)
+    return torch.cat([pad, seq, pad]).cpu().numpy().tobytes()
 
 
-def make_reads(chr_padded: bytes, n_reads: int, read_len: int = 100, seed: int = 20260927,
+def make_reads(chr_padded, n_reads: int, read_len: int = 100, seed: int = 20260927,
                insert_size: int = 500, mix=(0.4, 0.2, 0.1, 0.1, 0.2), error_rate: float = 0.01,
                n_rate: float = 0.001, rc_retry_frac: float = 0.1, chr_id: int = 0,
                max_del: int = 10000, spacer: int = SPACER, read_lens=None,
-               chunk: int = 1 << 20) -> ReadBatch:
-    """mix = fractions of (D, SI, TD, INV, none).  Reads are emitted as Pindel would
-    receive them: sequence in sequencing orientation, anchor strand/position of the
-    mapped mate, so that the close end lies within one insert size of the anchor."""
-    ref = np.frombuffer(chr_padded, dtype=np.uint8)
-    biol = len(ref) - 2 * spacer
-    rng = np.random.default_rng(seed)
-    seqs, strands, poss = [], [], []
-    lens_all = []
+               chunk: int = 1 << 20, device="cpu") -> ReadBatch:
+    """mix = fractions of (D, SI, TD, INV, none).  Reads are emitted the way Pindel receives
+    them: sequence in sequencing orientation plus strand/position of the mapped mate, placed
+    so that the close end lies within one insert size of the anchor."""
+    if isinstance(chr_padded, (bytes, bytearray)):
+        ref = torch.frombuffer(bytearray(chr_padded), dtype=torch.uint8).to(device)
+    else:
+        ref = chr_padded.to(device)
+    biol = ref.numel() - 2 * spacer
+    g = _gen(seed, device)
+    comp_lut = _COMP.to(device)
+    acgt = _ACGT.to(device)
+    mixc = torch.cumsum(torch.tensor(mix, dtype=torch.float64), 0)
+    mixc = (mixc / mixc[-1]).to(device)
+
+    def rand(*shape):
+        return torch.rand(*shape, generator=g, device=device)
+
+    def randint(lo, hi, shape):
+        return torch.randint(lo, hi, shape, generator=g, device=device, dtype=torch.int64)
+
+    seqs, strands, poss, lens_all = [], [], [], []
     done = 0
-    mixc = np.cumsum(np.asarray(mix, dtype=np.float64) / np.sum(mix))
     while done < n_reads:
         n = min(chunk, n_reads - done)
         if read_lens is None:
-            L = np.full(n, read_len, dtype=np.int64)
+            L = torch.full((n,), read_len, dtype=torch.int64, device=device)
         else:
-            L = rng.choice(np.asarray(read_lens, dtype=np.int64), size=n)
+            choices = torch.tensor(list(read_lens), dtype=torch.int64, device=device)
+            L = choices[randint(0, len(read_lens), (n,))]
         Lmax = int(L.max())
-        kind = np.searchsorted(mixc, rng.random(n), side="right").clip(0, 4)
-        sp = (rng.integers(20, 81, size=n) * L // 100).clip(12, None)   # split point
-        sp = np.minimum(sp, L - 12)
+        kind = torch.searchsorted(mixc, rand(n).double(), right=True).clamp(0, 4)
+        sp = (randint(20, 81, (n,)) * L // 100).clamp(min=12)            # split point in the read
+        sp = torch.minimum(sp, L - 12)
         margin = max_del + 4 * insert_size + 2 * Lmax + 64
-        bp = rng.integers(margin, max(biol - margin, margin + 1), size=n) + spacer   # AbsLoc of the break
-        # event geometry: read = left part (sp bases ending at bp) + [insert] + right part
-        dsize = np.exp(rng.random(n) * np.log(max_del)).astype(np.int64).clip(1, max_del)
-        isize = rng.integers(1, 21, size=n)
-        j = np.arange(Lmax)[None, :]
+        bp = randint(margin, max(biol - margin, margin + 1), (n,)) + spacer   # AbsLoc of the break
+        dsize = torch.exp(rand(n) * math.log(max_del)).long().clamp(1, max_del)
+        isize = randint(1, 21, (n,))
+        j = torch.arange(Lmax, device=device)[None, :]
         in_read = j < L[:, None]
         left = j < sp[:, None]
-        idx = np.zeros((n, Lmax), dtype=np.int64)
-        comp = np.zeros((n, Lmax), dtype=bool)
-        junk = np.zeros((n, Lmax), dtype=bool)
-        # left part is always ref[bp-sp .. bp)
-        idx_left = bp[:, None] - sp[:, None] + j
-        # right part by event type
-        r = j - sp[:, None]                                  # offset inside the right part
+        r = j - sp[:, None]                                    # offset inside the right part
         k = kind[:, None]
-        right_D = bp[:, None] + dsize[:, None] + r           # deletion: skip dsize bases
-        ins = (r < isize[:, None])                           # short insertion: isize random bases
-        right_SI = bp[:, None] + (r - isize[:, None])
-        right_TD = bp[:, None] - dsize[:, None].clip(sp[:, None] + 1, None) + r   # jump back: tandem dup
-        q = bp[:, None] + dsize[:, None] + 200               # inversion [bp, q): right part is RC of the far side
-        right_INV = q - 1 - r
-        right_none = bp[:, None] + r                          # plain reference read
-        idx_right = np.where(k == 0, right_D, np.where(k == 1, right_SI, np.where(
-            k == 2, right_TD, np.where(k == 3, right_INV, right_none))))
-        idx = np.where(left, idx_left, idx_right)
+        bpc, dsz = bp[:, None], dsize[:, None]
+        idx_left = bpc - sp[:, None] + j                       # left part: ref[bp-sp .. bp)
+        right_D = bpc + dsz + r                                # deletion of dsize bases
+        right_SI = bpc + (r - isize[:, None])                  # short insertion of isize random bases
+        right_TD = bpc - torch.maximum(dsz, sp[:, None] + 1) + r   # tandem duplication: jump back
+        right_INV = (bpc + dsz + 200) - 1 - r                  # inversion: far side, reverse complement
+        right_none = bpc + r                                   # plain reference read
+        idx_right = torch.where(k == 0, right_D, torch.where(k == 1, right_SI, torch.where(
+            k == 2, right_TD, torch.where(k == 3, right_INV, right_none))))
+        idx = torch.where(left, idx_left, idx_right).clamp(0, ref.numel() - 1)
         comp = (~left) & (k == 3)
-        junk = (~left) & (k == 1) & ins
-        # half of the "none" reads are unmappable junk
-        all_junk = (kind == 4) & (rng.random(n) < 0.5)
-        junk |= all_junk[:, None]
-        idx = idx.clip(0, len(ref) - 1)
+        junk = (~left) & (k == 1) & (r < isize[:, None])
+        all_junk = (kind == 4) & (rand(n) < 0.5)               # half of "none" is unmappable junk
+        junk = junk | all_junk[:, None]
         bases = ref[idx]
-        bases = np.where(comp, _COMP[bases], bases)
-        rnd = _ACGT[rng.integers(0, 4, size=(n, Lmax), dtype=np.uint8)]
-        bases = np.where(junk, rnd, bases)
-        err = rng.random((n, Lmax)) < error_rate
-        bases = np.where(err, rnd, bases)
-        isn = rng.random((n, Lmax)) < n_rate
-        bases = np.where(isn, np.uint8(ord("N")), bases)
-        # anchor: '+' anchors sit upstream (close end = left part, read given as RC of the fragment),
-        # '-' anchors downstream (close end = right part, read given forward)
-        plus = rng.random(n) < 0.5
-        slack = rng.integers(0, max(insert_size - Lmax - 20, 1), size=n)
+        bases = torch.where(comp, comp_lut[bases.long()], bases)
+        rnd = acgt[randint(0, 4, (n, Lmax))]
+        bases = torch.where(junk, rnd, bases)
+        bases = torch.where(rand(n, Lmax) < error_rate, rnd, bases)
+        bases = torch.where(rand(n, Lmax) < n_rate, torch.full_like(bases, ord("N")), bases)
+        # '+' anchors sit upstream of the read (close end = left part), '-' anchors downstream
+        plus = rand(n) < 0.5
+        slack = randint(0, max(insert_size - Lmax - 20, 1), (n,))
         left_start = bp - sp
-        right_end = np.where(kind == 0, bp + dsize, bp) + (L - sp)
-        right_end = np.where(kind == 3, bp + dsize + 200, right_end)
+        right_end = torch.where(kind == 0, bp + dsize, bp) + (L - sp)
         pos_plus = left_start - slack - spacer
         pos_minus = right_end + slack - spacer
-        # for '-' anchors of TD/INV reads the close end is the left part seen from the other side;
-        # keep them simple: anchor after the left part instead
-        pos_minus = np.where((kind == 2) | (kind == 3), bp + slack - spacer, pos_minus)
-        pos = np.where(plus, pos_plus, pos_minus).clip(0, biol)
-        # sequencing orientation: '+' anchor -> mate read is the reverse complement
-        flip = plus ^ (rng.random(n) < rc_retry_frac)
-        rev_idx = (L[:, None] - 1 - j).clip(0, Lmax - 1)
-        rc = _COMP[np.take_along_axis(bases, rev_idx, axis=1)]
-        bases = np.where(flip[:, None], rc, bases)
-        flat = bases[in_read]
-        seqs.append(flat)
-        lens_all.append(L)
-        strands.append(np.where(plus, ord("+"), ord("-")).astype(np.uint8))
-        poss.append(pos.astype(np.int32))
+        pos_minus = torch.where((kind == 2) | (kind == 3), bp + slack - spacer, pos_minus)
+        pos = torch.where(plus, pos_plus, pos_minus).clamp(0, biol)
+        # sequencing orientation: the mate of a '+' anchor is read from the reverse strand
+        flip = plus ^ (rand(n) < rc_retry_frac)
+        rev_idx = (L[:, None] - 1 - j).clamp(0, Lmax - 1)
+        rc = comp_lut[torch.gather(bases, 1, rev_idx).long()]
+        bases = torch.where(flip[:, None], rc, bases)
+        seqs.append(bases[in_read].cpu())
+        lens_all.append(L.cpu())
+        strands.append(torch.where(plus, ord("+"), ord("-")).to(torch.uint8).cpu())
+        poss.append(pos.to(torch.int32).cpu())
         done += n
-    lens = np.concatenate(lens_all)
+    lens = torch.cat(lens_all).numpy()
     off = np.zeros(n_reads + 1, dtype=np.uint64)
     off[1:] = np.cumsum(lens)
-    return ReadBatch(seq=np.concatenate(seqs), seq_off=off,
-                     anchor_strand=np.concatenate(strands), anchor_pos=np.concatenate(poss),
+    return ReadBatch(seq=torch.cat(seqs).numpy(), seq_off=off,
+                     anchor_strand=torch.cat(strands).numpy(), anchor_pos=torch.cat(poss).numpy(),
                      insert_size=np.full(n_reads, insert_size, dtype=np.int16),
                      chr_id=np.full(n_reads, chr_id, dtype=np.int32))
