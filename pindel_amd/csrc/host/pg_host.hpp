@@ -1,0 +1,133 @@
+// pg_host.hpp -- C++ host side around the split-read search: the reference's data
+// model (SPLIT_READ, UniquePoint, Chromosome), its text/FASTA loaders, the SV
+// classifiers and the text reporters that consume UP_Close / UP_Far.
+//
+// This mirrors the reference's interface for the steps either side of the hot path
+//  so that breakpoint calls can be compared byte for
+// byte with the reference's golden files:
+//   loaders      Genome::loadChromosome src/pindel.cpp:272-312, PindelReadReader
+//                src/pindel_read_reader.cpp:53-66, ReadInRead src/reader.cpp:196-361
+//   classifiers  SearchVariant::Search src/search_variant.cpp:48-266 (+ searchdeletions.cpp,
+//                searchshortinsertions.cpp), searchIndels src/search_deletions_nt.cpp:26-140
+//   reporters    SortOutputD / OutputDeletions, SortOutputDI / OutputDI, SortOutputSI /
+//                OutputSIs  src/reporter.cpp
+// The search itself is NOT here: UP_Close / UP_Far come from the GPU through the C ABI
+// (include/pindel_pg.h).  No HIP dependency in this file; plain g++.
+#ifndef PG_HOST_HPP
+#define PG_HOST_HPP
+
+#include <cstdint>
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+namespace pgh {
+
+struct UniquePoint {              // src/pindel.h:137-158
+    int chr = -1;
+    short LengthStr = 0;
+    unsigned AbsLoc = 0;
+    char Direction = 'N';         // '+' FORWARD, '-' BACKWARD
+    char Strand = 'N';            // '+' SENSE, '-' ANTISENSE
+    short Mismatches = 0;
+};
+
+struct SplitRead {                // the SPLIT_READ fields used downstream, src/pindel.h:265-383
+    std::string Name, UnmatchedSeq, FragName, FarFragName, Tag, NT_str;
+    char MatchedD = 0, MatchedFarD = 0;
+    unsigned MatchedRelPos = 0;
+    short MS = 0, InsertSize = 0;
+    short ReadLength = 0, MAX_SNP_ERROR = 0;
+    std::vector<UniquePoint> UP_Close, UP_Far;
+    short BP = 0;
+    int Left = 0, Right = 0;
+    unsigned BPLeft = 0, BPRight = 0, IndelSize = 0;
+    unsigned short NT_size = 0;
+    std::string NT_str_2;         // inversions: second non-template string
+    unsigned short NT_size_2 = 0;
+    bool UniqueRead = false, Used = false;
+    int LeftMostPos = 0;
+    int chr_id = -1;
+    std::map<std::string, unsigned> SampleName2Number;
+    short getReadLength() const { return ReadLength; }
+    short getReadLengthMinus() const { return (short)(ReadLength - 1); }
+};
+
+struct Chromosome {
+    std::string name;
+    std::string seq;              // spacer + sequence + spacer
+};
+
+struct Settings {                 // the flags the downstream steps read (src/fn_parameters.cpp)
+    unsigned spacer = 100000;
+    unsigned NumRead2ReportCutOff = 1;   // -M
+    unsigned BalanceCutoff = 100;        // -B
+    double Seq_Error_Rate = 0.01;        // -e
+    int Min_Num_Matched_Bases = 30;      // -d
+    int MIN_IndelSize_Inversion = 50;    // -v
+    bool Analyze_TD = true, Analyze_INV = true;   // -t, -r
+    double window_mbp = 5.0;             // -w
+    unsigned max_mismatch[500] = {0};    // g_maxMismatch
+};
+
+int load_fasta(const std::string &path, std::vector<Chromosome> &out, unsigned spacer, std::string &err);
+
+// Pindel-text reads (3 lines per read).  Trailing non-alphanumerics of SEQ are stripped
+// (setUnmatchedSeq).  Reads on unknown chromosomes are kept with chr_id = -1.
+int load_pindel_text(const std::string &path, const std::vector<Chromosome> &genome,
+                     std::vector<SplitRead> &out, std::string &err);
+
+std::string reverse_complement(const std::string &s);
+
+// Everything that happens to the reads of ONE chromosome after the close-end stage, with the
+// reference's global counters (SV indices, g_reportLength, g_sampleNames) kept across calls.
+class Caller {
+public:
+    Caller(const Settings &s, const std::vector<Chromosome> *genome, const std::string &out_prefix,
+           bool truncate_outputs);
+    // reads: reads anchored on `chrom` in input order, each with UP_Close/UP_Far filled and
+    // UnmatchedSeq in the orientation GetCloseEnd left it.  Reads without a close end must
+    // already have been dropped (ReadInRead / ReadBuffer::flush do that).
+    void process_window(const Chromosome &chrom, std::vector<SplitRead> &reads, unsigned win_start,
+                        unsigned win_end, unsigned region_start, unsigned region_end);
+    // post-close-end bookkeeping of ReadInRead (reader.cpp:258-291): CloseEndLength, LeftMostPos,
+    // g_reportLength, sample names.  Call once per read that has a close end.
+    void note_close_mapped(SplitRead &r);
+    unsigned long far_end_checksum = 0;
+
+private:
+    Settings S;
+    const std::vector<Chromosome> *genome;
+    std::string prefix;
+    short g_reportLength = 1;
+    std::set<std::string> g_sampleNames;
+    int d_template = 0, d_nontemplate = 0;   // deletionFileData
+    unsigned n_si = 0, n_td = 0, n_inv = 0;
+    unsigned BoxSize = 1;
+    unsigned g_RegionStart = 0, g_RegionEnd = 0;
+
+    struct Ctx;
+    void search_variant(Ctx &c, int kind);
+    void search_indels(Ctx &c);
+    void search_tandem_dup(Ctx &c);
+    void search_tandem_dup_nt(Ctx &c);
+    void search_inversions(Ctx &c);
+    void search_inversions_nt(Ctx &c);
+    void sort_output_d(Ctx &c, std::vector<std::vector<unsigned>> &boxes);
+    void sort_output_di(Ctx &c, std::vector<std::vector<unsigned>> &boxes);
+    void sort_output_si(Ctx &c, std::vector<std::vector<unsigned>> &boxes);
+    void sort_output_td(Ctx &c, std::vector<std::vector<unsigned>> &boxes, bool nt);
+    void sort_output_inv(Ctx &c, std::vector<std::vector<unsigned>> &boxes, bool nt);
+    std::string support_columns(const std::vector<SplitRead> &ev, unsigned s, unsigned e,
+                                unsigned bp_left, unsigned bp_right, unsigned &n_reads);
+    void output_deletion(Ctx &c, std::vector<SplitRead> &g, unsigned s, unsigned e, unsigned rs, unsigned re);
+    void output_di(Ctx &c, std::vector<SplitRead> &g, unsigned s, unsigned e);
+    void output_si(Ctx &c, std::vector<SplitRead> &g, unsigned s, unsigned e, unsigned rs, unsigned re);
+    void output_td(Ctx &c, std::vector<SplitRead> &g, unsigned s, unsigned e, unsigned rs, unsigned re);
+    void output_inv(Ctx &c, std::vector<SplitRead> &g, unsigned s, unsigned e, unsigned rs, unsigned re);
+    void output_short_inv(Ctx &c, std::vector<SplitRead> &g, unsigned s, unsigned e);
+};
+
+}  // namespace pgh
+#endif

@@ -1,0 +1,121 @@
+// pg_host_capi.cpp -- C entry points of the host library (libpindel_host.so): the steps
+// before and after the hot path (loaders, classifiers, reporters), callable from tests and
+// from the pindel_pg command line.  No search code here.
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "pg_host.hpp"
+#include "pindel_pg.h"
+
+using namespace pgh;
+
+static std::string g_err;
+
+extern "C" {
+
+const char *pgh_last_error(void) { return g_err.c_str(); }
+
+struct pgh_settings {
+    uint32_t spacer;
+    uint32_t min_support;        /* -M */
+    uint32_t balance_cutoff;     /* -B */
+    double seq_error_rate;       /* -e */
+    int32_t min_num_matched_bases; /* -d */
+    int32_t min_inversion_size;  /* -v */
+    int32_t analyze_td, analyze_inv;
+    double window_mbp;           /* -w */
+    uint32_t max_mismatch[500];  /* g_maxMismatch (pg_get_max_mismatch) */
+};
+
+/*
+ * Pindel's post-search pipeline for a Pindel-text read file: attaches the given UP_Close /
+ * UP_Far (CSR over ALL reads of the file, in file order; reads without close end have an
+ * empty range) and the rc flags, then walks chromosomes and 5-Mbp bins like main()
+ * (pindel.cpp:1778-1989) and appends <prefix>_D, _SI, _TD, _INV.
+ */
+int pgh_call_from_points(const char *fasta_path, const char *reads_path, const char *out_prefix,
+                         const pgh_settings *st, uint32_t n_reads,
+                         const uint64_t *close_off, const pg_point *close_pts,
+                         const uint64_t *far_off, const pg_point *far_pts, const uint8_t *rc_flag)
+{
+    std::vector<Chromosome> genome;
+    if (load_fasta(fasta_path, genome, st->spacer, g_err)) return -1;
+    std::vector<SplitRead> all;
+    if (load_pindel_text(reads_path, genome, all, g_err)) return -1;
+    if (all.size() != n_reads) {
+        g_err = "read count mismatch between the read file and the point arrays";
+        return -1;
+    }
+    Settings S;
+    S.spacer = st->spacer;
+    S.NumRead2ReportCutOff = st->min_support;
+    S.BalanceCutoff = st->balance_cutoff;
+    S.Seq_Error_Rate = st->seq_error_rate;
+    S.Min_Num_Matched_Bases = st->min_num_matched_bases;
+    S.MIN_IndelSize_Inversion = st->min_inversion_size;
+    S.Analyze_TD = st->analyze_td != 0;
+    S.Analyze_INV = st->analyze_inv != 0;
+    S.window_mbp = st->window_mbp;
+    memcpy(S.max_mismatch, st->max_mismatch, sizeof S.max_mismatch);
+    Caller caller(S, &genome, out_prefix, true);
+    // .fai sizes (init_g_ChrNameAndSizeAndIndex, pindel.cpp:1332-1348) if present
+    std::vector<unsigned> fai(genome.size(), 0);
+    {
+        std::ifstream f((std::string(fasta_path) + ".fai").c_str());
+        std::string name;
+        unsigned size;
+        std::string rest;
+        while (f >> name >> size) {
+            std::getline(f, rest);
+            for (size_t c = 0; c < genome.size(); c++)
+                if (genome[c].name == name) fai[c] = size;
+        }
+    }
+    auto to_up = [](const pg_point &p) {
+        UniquePoint u;
+        u.chr = p.chr_id;
+        u.LengthStr = p.length;
+        u.AbsLoc = p.abs_loc;
+        u.Direction = p.direction;
+        u.Strand = p.strand;
+        u.Mismatches = p.mismatches;
+        return u;
+    };
+    const unsigned WINDOW = (unsigned)(S.window_mbp * 1000000);
+    for (size_t c = 0; c < genome.size(); c++) {
+        const Chromosome &chrom = genome[c];
+        const unsigned biol = (unsigned)(chrom.seq.size() - 2 * S.spacer);
+        const unsigned bed_start = 1, bed_end = fai[c] ? fai[c] : biol;
+        const unsigned global_start = 0;                       // Bed_start < AROUND_REGION_BUFFER
+        const unsigned global_end = std::min(biol, bed_end + 10000u);
+        unsigned g_max_pos = 0;                                // reset per BED region, pindel.cpp:1798
+        unsigned ws = global_start;
+        do {
+            unsigned we = std::min(ws + WINDOW, global_end);
+            std::vector<SplitRead> reads;
+            for (uint32_t i = 0; i < n_reads; i++) {
+                SplitRead &src = all[i];
+                if (src.MatchedRelPos > g_max_pos) g_max_pos = src.MatchedRelPos;   // reader.cpp:224-226
+                if (src.chr_id != (int)c || !(src.MatchedRelPos >= ws && src.MatchedRelPos < we)) continue;
+                if (close_off[i + 1] == close_off[i]) continue;                     // no close end
+                SplitRead r = src;
+                if (r.MatchedRelPos > biol) r.MatchedRelPos = biol;
+                if (rc_flag[i]) r.UnmatchedSeq = reverse_complement(r.UnmatchedSeq);
+                r.MAX_SNP_ERROR = (short)S.max_mismatch[r.ReadLength < 500 ? r.ReadLength : 499];
+                for (uint64_t k = close_off[i]; k < close_off[i + 1]; k++) r.UP_Close.push_back(to_up(close_pts[k]));
+                for (uint64_t k = far_off[i]; k < far_off[i + 1]; k++) r.UP_Far.push_back(to_up(far_pts[k]));
+                caller.note_close_mapped(r);
+                reads.push_back(r);
+            }
+            if (!reads.empty()) caller.process_window(chrom, reads, ws, we, bed_start, bed_end);
+            ws += WINDOW;
+            // LoopingSearchWindow::finished, pindel.cpp:464-471 (Pindel-text input shortcut)
+        } while (!(ws >= g_max_pos || ws > global_end));
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,144 @@
+// pg_host_priv.hpp -- helpers shared by pg_host.cpp and pg_host_sv.cpp (not installed).
+#ifndef PG_HOST_PRIV_HPP
+#define PG_HOST_PRIV_HPP
+
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "pg_host.hpp"
+
+namespace pgh {
+
+struct Caller::Ctx {
+    const Chromosome *chrom;
+    std::vector<SplitRead> *reads;
+    unsigned NumBoxes;
+    unsigned win_end;
+    unsigned region_start, region_end;
+};
+
+namespace detail {
+
+inline char rc4n(char c)   // Convert2RC4N, src/pindel.cpp:966-970 (unset entries are 0)
+{
+    switch (c) {
+    case 'A': return 'T';
+    case 'C': return 'G';
+    case 'G': return 'C';
+    case 'T': return 'A';
+    case 'N': return 'N';
+    default: return 0;
+    }
+}
+
+inline std::string cap2low(const std::string &s)        // Cap2LowArray, src/pindel.cpp:971-976
+{
+    std::string o(s.size(), 0);
+    for (size_t i = 0; i < s.size(); i++) {
+        switch (s[i]) {
+        case 'A': o[i] = 'a'; break;
+        case 'C': o[i] = 'c'; break;
+        case 'G': o[i] = 'g'; break;
+        case 'T': o[i] = 't'; break;
+        case 'N': case '$': o[i] = 'n'; break;
+        default: o[i] = 0; break;
+        }
+    }
+    return o;
+}
+
+// std::string::substr that never throws (the reference only calls it in range)
+inline std::string sub(const std::string &s, long pos, long n)
+{
+    if (pos < 0 || (size_t)pos > s.size() || n <= 0) return std::string();
+    return s.substr((size_t)pos, (size_t)n);
+}
+
+// readTransgressesBinBoundaries, src/pindel.cpp:561-564
+inline bool transgresses(const SplitRead &r, unsigned upper) { return r.BPRight > upper - 2 * r.InsertSize; }
+
+static const char *const HASHES =
+    "####################################################################################################";
+static const char *const DASHES =
+    "----------------------------------------------------------------------------------------------------";
+
+inline std::string read_tail(const SplitRead &r)
+{
+    std::ostringstream o;
+    o << "\t" << r.MatchedD << "\t" << r.MatchedRelPos << "\t" << r.MS << "\t" << r.Tag << "\t" << r.Name;
+    return o.str();
+}
+
+// GetRealStart4Deletion, src/pindel.cpp:2095-2118
+inline void real_start_deletion(const std::string &chr, unsigned spacer, unsigned &rs, unsigned &re)
+{
+    if (chr.size() < rs || chr.size() < re) return;
+    unsigned pos = rs + spacer, start = pos + 1, end = re + spacer - 1;
+    while (chr[pos] == chr[end] && chr[pos] != 'N') {
+        --pos;
+        --end;
+    }
+    rs = pos - spacer;
+    pos = re + spacer;
+    while (chr[pos] == chr[start] && chr[pos] != 'N') {
+        ++pos;
+        ++start;
+    }
+    re = pos - spacer;
+}
+
+// ReportEvent, src/pindel.cpp:2059-2093 (Min_Filter_Ratio = 0.5)
+inline bool report_event(const std::vector<SplitRead> &g, unsigned s, unsigned e)
+{
+    bool lmin = false, lmax = false, rmin = false, rmax = false;
+    for (unsigned i = s; i <= e; i++) {
+        short rl = (short)(g[i].getReadLength() - g[i].NT_size);
+        short mn = (short)((short)((rl * 0.5) + 0.5) - 1);
+        short mx = (short)((short)(rl * (1 - 0.5) - 0.5) - 1);
+        if (g[i].BP <= mn) lmin = true;
+        if (g[i].getReadLength() - g[i].BP - g[i].NT_size <= mn) rmin = true;
+        if (g[i].BP >= mx) lmax = true;
+        if (g[i].getReadLength() - g[i].BP - g[i].NT_size >= mx) rmax = true;
+    }
+    return lmin && lmax && rmin && rmax;
+}
+
+// smaller(), src/reporter.cpp:908-929 (all reads of one window share FragName)
+inline bool smaller(const SplitRead &a, const SplitRead &b)
+{
+    if (a.BPLeft != b.BPLeft) return a.BPLeft < b.BPLeft;
+    if (a.BPRight != b.BPRight) return a.BPRight < b.BPRight;
+    if (a.IndelSize != b.IndelSize) return a.IndelSize < b.IndelSize;
+    if (a.NT_size != b.NT_size) return a.NT_size < b.NT_size;
+    if (a.BP != b.BP) return a.BP < b.BP;
+    return false;
+}
+
+// bubblesortReads, src/reporter.cpp:932-942: an exchange sort that also swaps equal elements.
+// Reproduced as is, because the (unstable) order of equal reads is visible in the report.
+inline void exchange_sort(const std::vector<SplitRead> &reads, std::vector<unsigned> &idx)
+{
+    const size_t n = idx.size();
+    for (size_t a = 0; a + 1 < n; a++)
+        for (size_t b = a + 1; b < n; b++)
+            if (!smaller(reads[idx[a]], reads[idx[b]])) std::swap(idx[a], idx[b]);
+}
+
+// markDuplicates, src/reporter.cpp:946-972
+inline void mark_duplicates(std::vector<SplitRead> &reads, const std::vector<unsigned> &idx)
+{
+    const size_t n = idx.size();
+    for (size_t a = 0; a + 1 < n; a++) {
+        SplitRead &x = reads[idx[a]];
+        if (!x.UniqueRead) continue;
+        for (size_t b = a + 1; b < n; b++) {
+            SplitRead &y = reads[idx[b]];
+            if (x.Left == y.Left && x.Right == y.Right && x.Name == y.Name) y.UniqueRead = false;
+        }
+    }
+}
+
+}  // namespace detail
+}  // namespace pgh
+#endif
