@@ -43,3 +43,135 @@ def test_close_then_far_seams(engine_factory, small_ref):
     assert close.far_off[-1] == 0
     both = eng.far_end_batch(batch, close)
     compare_result(both, orc, batch.n)
+
+
+ALT = dict(max_range_index=5, additional_mismatch=2, max_mismatch_rate=0.05, min_perfect_match=5,
+           min_close=10, seq_error_rate=0.02, sensitivity=0.9)
+
+
+def test_non_default_parameters(engine_factory, small_ref):
+    """-x 5 -a 2 -u 0.05 -m 5 -H 10 -e 0.02 -E 0.9 (the survey's second parameter set)."""
+    eng = engine_factory(**ALT)
+    eng.load_reference(small_ref)
+    batch = synth.make_reads(small_ref[0][1], 1500, seed=8, read_lens=[50, 100, 150], error_rate=0.02)
+    gpu = eng.search_batch(batch)
+    orc = run_oracle(ALT, small_ref, batch)
+    assert (orc["far_cnt"] > 0).sum() > 300
+    compare_result(gpu, orc, batch.n)
+    from oracle import pyoracle
+    np.testing.assert_array_equal(eng.max_mismatch_table(),
+                                  pyoracle.max_mismatch_table(ALT["seq_error_rate"], ALT["sensitivity"]))
+
+
+def test_noisy_reads_and_ns(engine_factory, small_ref):
+    """5 % N's, 3 % errors, first-base N's, IUPAC codes and lower-case bases in reads."""
+    eng = engine_factory()
+    eng.load_reference(small_ref)
+    batch = synth.make_reads(small_ref[0][1], 3000, seed=9, error_rate=0.03, n_rate=0.05)
+    off = batch.seq_off.astype(np.int64)
+    batch.seq[off[:200]] = ord("N")
+    batch.seq[off[200:400] + 17] = ord("R")
+    batch.seq[off[400:600] + 40] = ord("a")
+    batch.seq[off[600:700] + 99] = ord("N")
+    gpu = eng.search_batch(batch)
+    orc = run_oracle({}, small_ref, batch)
+    compare_result(gpu, orc, batch.n)
+
+
+def test_repeats_gaps_and_chromosome_ends(engine_factory):
+    """Reads anchored inside the repeat family, the AC microsatellite, next to N gaps and at both
+    chromosome ends (far-end windows get clipped at the spacers, pindel.cpp:1034-1043)."""
+    ref = [("chrR", synth.make_reference(1_400_000, seed=21))]
+    L = 1_400_000
+    eng = engine_factory(max_range_index=4)
+    eng.load_reference(ref)
+    parts = []
+    hot = [int(L * 0.07), int(L * 0.18), int(L * 0.61), int(L * 1 / 4.5), 300, L - 400]
+    base = synth.make_reads(ref[0][1], 2400, seed=22)
+    rng = np.random.default_rng(5)
+    pos = np.array([hot[i % len(hot)] for i in range(base.n)]) + rng.integers(-600, 600, base.n)
+    base.anchor_pos[:] = np.clip(pos, 0, L).astype(np.int32)
+    # give these reads sequence from where they are anchored so that close ends exist
+    refb = np.frombuffer(ref[0][1], dtype=np.uint8)
+    off = base.seq_off.astype(np.int64)
+    for i in range(0, base.n, 2):
+        p = int(base.anchor_pos[i]) + 100000 + int(rng.integers(0, 300))
+        p = min(max(p, 100000), 100000 + L - 200)
+        frag = refb[p:p + 60].copy()
+        far = refb[p + 5000:p + 5040] if p + 5040 < len(refb) else refb[p - 5000:p - 4960]
+        s = np.concatenate([frag, far])
+        if base.anchor_strand[i] == ord("+"):
+            comp = {65: 84, 67: 71, 71: 67, 84: 65, 78: 78}
+            s = np.array([comp[int(c)] for c in s[::-1]], dtype=np.uint8)
+        base.seq[off[i]:off[i] + 100] = s
+    gpu = eng.search_batch(base)
+    orc = run_oracle(dict(max_range_index=4), ref, base)
+    assert (orc["close_cnt"] > 0).sum() > 200
+    compare_result(gpu, orc, base.n)
+
+
+def test_multi_chromosome_and_breakdancer_hints(engine_factory):
+    """Two chromosomes; per-read BreakDancer clusters (some on the other chromosome, some with
+    start < 0, farend_searcher.cpp:69-71) searched before the ranges (pindel.cpp:1006-1018)."""
+    from pindel_amd.binding import WINDOW_DTYPE
+    chroms = [("a", synth.make_reference(700_000, seed=31)), ("b", synth.make_reference(500_000, seed=32))]
+    eng = engine_factory()
+    eng.load_reference(chroms)
+    b0 = synth.make_reads(chroms[0][1], 1200, seed=33, chr_id=0, max_del=200000)
+    b1 = synth.make_reads(chroms[1][1], 800, seed=34, chr_id=1, max_del=100000)
+    from pindel_amd.hostio import ReadBatch
+    batch = ReadBatch(
+        seq=np.concatenate([b0.seq, b1.seq]),
+        seq_off=np.concatenate([b0.seq_off, b1.seq_off[1:] + b0.seq_off[-1]]),
+        anchor_strand=np.concatenate([b0.anchor_strand, b1.anchor_strand]),
+        anchor_pos=np.concatenate([b0.anchor_pos, b1.anchor_pos]),
+        insert_size=np.concatenate([b0.insert_size, b1.insert_size]),
+        chr_id=np.concatenate([b0.chr_id, b1.chr_id]))
+    close = eng.close_end_batch(batch)
+    orc_close = run_oracle({}, chroms, batch, do_far=False)
+    compare_result(close, orc_close, batch.n, check_far=False)
+    # hints: 0-4 windows per read around plausible far ends
+    rng = np.random.default_rng(7)
+    wins, offs = [], [0]
+    for i in range(batch.n):
+        k = int(rng.integers(0, 5)) if orc_close["close_cnt"][i] else 0
+        for _ in range(k):
+            c = int(batch.chr_id[i]) if rng.random() < 0.8 else 1 - int(batch.chr_id[i])
+            size = len(chroms[c][1])
+            centre = int(orc_close["close_pts"][i][0]["abs_loc"]) + int(rng.integers(-150000, 150000))
+            centre = min(max(centre, 100300), size - 100300)
+            start, end = centre - 200, centre + 200
+            if rng.random() < 0.05:
+                start = -1
+            wins.append((c, start, end))
+        offs.append(len(wins))
+    bd = np.array(wins, dtype=WINDOW_DTYPE)
+    bd_off = np.array(offs, dtype=np.uint64)
+    both = eng.far_end_batch(batch, close, bd=bd, bd_off=bd_off)
+    orc = run_oracle({}, chroms, batch, bd=bd, bd_off=bd_off)
+    assert (orc["far_cnt"] > 0).sum() > 500
+    compare_result(both, orc, batch.n)
+
+
+def test_empty_and_tiny_inputs(engine_factory, small_ref):
+    from pindel_amd import hostio
+    eng = engine_factory()
+    eng.load_reference(small_ref)
+    empty = hostio.batch_from_lists([], [], [], [], [])
+    res = eng.search_batch(empty)
+    assert res.n == 0 and len(res.close_runs) == 0 and len(res.far_runs) == 0
+    tiny = hostio.batch_from_lists([b"ACGTACG", b"A", b"ACGTACGTAC" * 3], [b"+", b"-", b"+"],
+                                   [1000, 2000, 3000], [500, 500, 500], [0, 0, 0])
+    gpu = eng.search_batch(tiny)
+    orc = run_oracle({}, small_ref, tiny)
+    compare_result(gpu, orc, tiny.n)
+
+
+def test_wide_ranges_streaming_windows(engine_factory, small_ref):
+    """-x 7: far-end windows up to 524 288 bases, i.e. many LDS chunks per read."""
+    eng = engine_factory(max_range_index=7)
+    eng.load_reference(small_ref)
+    batch = synth.make_reads(small_ref[0][1], 120, seed=12, max_del=400000, mix=(0.7, 0.0, 0.1, 0.1, 0.1))
+    gpu = eng.search_batch(batch)
+    orc = run_oracle(dict(max_range_index=7), small_ref, batch)
+    compare_result(gpu, orc, batch.n)
