@@ -77,7 +77,7 @@ def build(force: bool = False) -> str:
         os.path.join(_HERE, "..", "include", "pindel_pg.h")]
     if force or not os.path.exists(LIB_PATH) or any(
             os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
-        subprocess.check_call(["make", "-C", src_dir, "-B"], stdout=subprocess.DEVNULL,
+        subprocess.check_call(["make", "-C", src_dir, "-B", "all"], stdout=subprocess.DEVNULL,
                               stderr=subprocess.DEVNULL)
     return LIB_PATH
 

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "pg_host.hpp"
+#include "pg_pipeline.hpp"
 #include "pindel_pg.h"
 
 using namespace pgh;
@@ -60,20 +61,7 @@ int pgh_call_from_points(const char *fasta_path, const char *reads_path, const c
     S.Analyze_INV = st->analyze_inv != 0;
     S.window_mbp = st->window_mbp;
     memcpy(S.max_mismatch, st->max_mismatch, sizeof S.max_mismatch);
-    Caller caller(S, &genome, out_prefix, true);
-    // .fai sizes (init_g_ChrNameAndSizeAndIndex, pindel.cpp:1332-1348) if present
-    std::vector<unsigned> fai(genome.size(), 0);
-    {
-        std::ifstream f((std::string(fasta_path) + ".fai").c_str());
-        std::string name;
-        unsigned size;
-        std::string rest;
-        while (f >> name >> size) {
-            std::getline(f, rest);
-            for (size_t c = 0; c < genome.size(); c++)
-                if (genome[c].name == name) fai[c] = size;
-        }
-    }
+    std::vector<unsigned> fai = read_fai(fasta_path, genome);
     auto to_up = [](const pg_point &p) {
         UniquePoint u;
         u.chr = p.chr_id;
@@ -84,38 +72,17 @@ int pgh_call_from_points(const char *fasta_path, const char *reads_path, const c
         u.Mismatches = p.mismatches;
         return u;
     };
-    const unsigned WINDOW = (unsigned)(S.window_mbp * 1000000);
-    for (size_t c = 0; c < genome.size(); c++) {
-        const Chromosome &chrom = genome[c];
-        const unsigned biol = (unsigned)(chrom.seq.size() - 2 * S.spacer);
-        const unsigned bed_start = 1, bed_end = fai[c] ? fai[c] : biol;
-        const unsigned global_start = 0;                       // Bed_start < AROUND_REGION_BUFFER
-        const unsigned global_end = std::min(biol, bed_end + 10000u);
-        unsigned g_max_pos = 0;                                // reset per BED region, pindel.cpp:1798
-        unsigned ws = global_start;
-        do {
-            unsigned we = std::min(ws + WINDOW, global_end);
-            std::vector<SplitRead> reads;
-            for (uint32_t i = 0; i < n_reads; i++) {
-                SplitRead &src = all[i];
-                if (src.MatchedRelPos > g_max_pos) g_max_pos = src.MatchedRelPos;   // reader.cpp:224-226
-                if (src.chr_id != (int)c || !(src.MatchedRelPos >= ws && src.MatchedRelPos < we)) continue;
-                if (close_off[i + 1] == close_off[i]) continue;                     // no close end
-                SplitRead r = src;
-                if (r.MatchedRelPos > biol) r.MatchedRelPos = biol;
-                if (rc_flag[i]) r.UnmatchedSeq = reverse_complement(r.UnmatchedSeq);
-                r.MAX_SNP_ERROR = (short)S.max_mismatch[r.ReadLength < 500 ? r.ReadLength : 499];
-                for (uint64_t k = close_off[i]; k < close_off[i + 1]; k++) r.UP_Close.push_back(to_up(close_pts[k]));
-                for (uint64_t k = far_off[i]; k < far_off[i + 1]; k++) r.UP_Far.push_back(to_up(far_pts[k]));
-                caller.note_close_mapped(r);
-                reads.push_back(r);
-            }
-            if (!reads.empty()) caller.process_window(chrom, reads, ws, we, bed_start, bed_end);
-            ws += WINDOW;
-            // LoopingSearchWindow::finished, pindel.cpp:464-471 (Pindel-text input shortcut)
-        } while (!(ws >= g_max_pos || ws > global_end));
-    }
-    return 0;
+    auto attach = [&](const Chromosome &, int, std::vector<SplitRead> &reads, const std::vector<uint32_t> &index) {
+        for (size_t k = 0; k < reads.size(); k++) {
+            const uint32_t i = index[k];
+            SplitRead &r = reads[k];
+            if (rc_flag[i]) r.UnmatchedSeq = reverse_complement(r.UnmatchedSeq);
+            for (uint64_t q = close_off[i]; q < close_off[i + 1]; q++) r.UP_Close.push_back(to_up(close_pts[q]));
+            for (uint64_t q = far_off[i]; q < far_off[i + 1]; q++) r.UP_Far.push_back(to_up(far_pts[q]));
+        }
+        return 0;
+    };
+    return run_pipeline(genome, fai, all, S, out_prefix, attach, g_err);
 }
 
 }  // extern "C"

@@ -63,3 +63,18 @@ def test_gpu_path_reproduces_gold_reports(tmp_path, engine_factory):
     prefix = str(tmp_path / "gpu")
     hostlib.call_from_points(fa, reads_txt, prefix, st, co, cp, fo, fp, res.rc_flag)
     gu.assert_reports_match_gold(prefix)
+
+
+@pytest.mark.gpu
+def test_command_line_reproduces_gold_reports(tmp_path):
+    """pindel_pg (C++ host + C ABI): -f/-p/-o like `pindel -f ... -p ... -o ...`."""
+    import os
+    import subprocess
+    from pindel_amd import binding
+    fa, reads_txt = gu.unpack(tmp_path)
+    exe = os.path.join(os.path.dirname(binding.LIB_PATH), "pindel_pg")
+    prefix = str(tmp_path / "cli")
+    out = subprocess.run([exe, "-f", fa, "-p", reads_txt, "-o", prefix, "-T", "1"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "close end 14862, far end 10968" in out.stdout
+    gu.assert_reports_match_gold(prefix)
