@@ -30,7 +30,6 @@ struct pg_ctx {
     pg_params prm{};
     uint32_t mm[512]{};
     uint16_t thr[512]{};
-    uint8_t *d_mm = nullptr;
     uint16_t *d_thr = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -51,6 +50,7 @@ struct pg_ctx {
 struct pg_device_batch {
     uint32_t n = 0;
     uint32_t max_len = 0, levels = 0;
+    int32_t max_isz = 0;
     uint8_t *seq = nullptr;
     uint64_t *seq_off = nullptr;
     uint8_t *strand = nullptr;
@@ -65,8 +65,9 @@ struct pg_device_batch {
     uint32_t *close_off = nullptr, *close_cnt = nullptr, *far_off = nullptr, *far_cnt = nullptr;
     uint32_t *alg = nullptr;
     pg_run *pool = nullptr;
-    uint32_t pool_cap = 0;
-    uint32_t *pool_used = nullptr;
+    uint32_t pool_shard_cap = 0;       // runs per shard (PG_POOL_SHARDS shards)
+    uint32_t *pool_used = nullptr;     // [PG_POOL_SHARDS * 16]
+    uint64_t runs_used = 0;            // total runs of the last search
     int modes_done = 0;
 };
 
@@ -187,7 +188,15 @@ PgDevParams dev_params(const pg_ctx *ctx)
     p.min_perfect = ctx->prm.min_perfect_match_around_bp;
     p.min_close = ctx->prm.min_close;
     p.spacer = ctx->prm.spacer;
-    p.mm_tab = ctx->d_mm;
+    // breakpoints of the (monotone, checked in pg_create) g_maxMismatch table
+    for (int k = 0; k < 16; k++) {
+        p.mm_bp[k] = 0xffffffffu;
+        for (unsigned L = 0; L < 500; L++)
+            if (ctx->mm[L] >= (unsigned)(k + 1)) {
+                p.mm_bp[k] = L;
+                break;
+            }
+    }
     p.thr_tab = ctx->d_thr;
     return p;
 }
@@ -242,6 +251,7 @@ int upload_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_device_batch **out)
     b->n = reads->n_reads;
     b->max_len = max_len;
     b->levels = levels;
+    for (uint32_t i = 0; i < reads->n_reads; i++) b->max_isz = std::max<int32_t>(b->max_isz, reads->insert_size[i]);
     const size_t n = b->n;
     const uint64_t base0 = n ? reads->seq_off[0] : 0;
     const uint64_t nseq = n ? reads->seq_off[n] - base0 : 0;
@@ -273,9 +283,9 @@ int upload_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_device_batch **out)
     AL(far_off, n);
     AL(far_cnt, n);
     AL(alg, n);
-    AL(pool_used, 1);
-    b->pool_cap = (uint32_t)std::min<uint64_t>(3ull * n + 1024ull, 0x7fffffffull);
-    AL(pool, b->pool_cap);
+    AL(pool_used, PG_POOL_SHARDS * 16);
+    b->pool_shard_cap = (uint32_t)std::min<uint64_t>((3ull * n) / PG_POOL_SHARDS + 96ull, 0x7fffffffull / PG_POOL_SHARDS);
+    AL(pool, (size_t)b->pool_shard_cap * PG_POOL_SHARDS);
 #undef UP
 #undef AL
     hipMemset(b->close_cnt, 0, std::max<size_t>(n, 1) * sizeof(uint32_t));
@@ -310,51 +320,56 @@ PgDevBatch dev_batch(const pg_device_batch *b)
     d.far_run_off = b->far_off;
     d.far_run_cnt = b->far_cnt;
     d.pool = b->pool;
-    d.pool_cap = b->pool_cap;
+    d.pool_shard_cap = b->pool_shard_cap;
     d.pool_used = b->pool_used;
     d.alg_bytes = b->alg;
     return d;
 }
 
-// Runs the kernel in `mode`; the run pool is regrown and the launch repeated if it overflowed
-// (still entirely on the GPU).  In FAR mode the close runs already in the pool are kept.
+// Runs the kernel(s) of `mode`; if a pool shard overflowed, the pool is regrown and the launch
+// repeated (still entirely on the GPU).
 int run_search(pg_ctx *ctx, pg_device_batch *b, int mode)
 {
     if (ctx->names.empty()) return fail(ctx, PG_E_NO_REFERENCE, "no reference loaded");
     PgDevRef ref = dev_ref(ctx);
     PgDevParams prm = dev_params(ctx);
-    uint32_t keep = 0;   // pool entries that must survive (close runs before a FAR pass)
-    if (mode == PG_MODE_FAR && (b->modes_done & PG_MODE_CLOSE))
-        HIP_TRY(ctx, hipMemcpy(&keep, b->pool_used, sizeof keep, hipMemcpyDeviceToHost));
-    double total_ms = 0.0;
+    std::vector<uint32_t> cursors(PG_POOL_SHARDS * 16);
     for (int attempt = 0; attempt < 8; attempt++) {
-        HIP_TRY(ctx, hipMemcpyAsync(b->pool_used, &keep, sizeof keep, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(b->pool_used, 0, PG_POOL_SHARDS * 16 * sizeof(uint32_t), ctx->stream));
         PgDevBatch d = dev_batch(b);
         HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-        int lrc = pg_launch_search(&ref, &prm, &d, mode, b->max_len, b->levels, ctx->stream);
+        // 32-bit histogram cells when every window of this launch has <= 32768 positions
+        // (ranges 128*4^x, close windows 3*InsertSize) and there are no BreakDancer regions
+        const bool small = !b->bd_off && ctx->prm.max_range_index <= 4 &&
+                           3ll * b->max_isz <= PG_SMALL_MAX_WINDOW && !getenv("PG_FORCE_WIDE_CELLS");
+        int lrc = pg_launch_search(&ref, &prm, &d, mode, b->max_len, b->levels, small ? 1 : 0, ctx->stream);
         if (lrc != 0) return fail(ctx, PG_E_DEVICE, std::string("kernel launch: ") + hipGetErrorString((hipError_t)lrc));
         HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         float ms = 0.f;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-        total_ms = ms;
-        uint32_t used = 0;
-        HIP_TRY(ctx, hipMemcpy(&used, b->pool_used, sizeof used, hipMemcpyDeviceToHost));
-        if (used <= b->pool_cap) {
-            ctx->last_ms = total_ms;
-            ctx->last_runs = used;
+        HIP_TRY(ctx, hipMemcpy(cursors.data(), b->pool_used, cursors.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        uint32_t worst = 0;
+        uint64_t total = 0;
+        for (uint32_t s = 0; s < PG_POOL_SHARDS; s++) {
+            worst = std::max(worst, cursors[s * 16]);
+            total += cursors[s * 16];
+        }
+        if (worst <= b->pool_shard_cap) {
+            ctx->last_ms = ms;
+            ctx->last_runs = total;
+            b->runs_used = total;
             b->modes_done |= mode;
             return PG_OK;
         }
-        // overflow: grow the pool (keeping the close runs) and redo the launch
-        uint32_t ncap = (uint32_t)std::min<uint64_t>((uint64_t)used + used / 4 + 1024, 0x7fffffffull);
+        // overflow: grow the pool and redo the launch
+        uint32_t ncap = (uint32_t)std::min<uint64_t>((uint64_t)worst + worst / 4 + 64, 0x7fffffffull / PG_POOL_SHARDS);
         pg_run *npool = nullptr;
-        int rc = dev_alloc(ctx, &npool, ncap);
+        int rc = dev_alloc(ctx, &npool, (size_t)ncap * PG_POOL_SHARDS);
         if (rc) return rc;
-        if (keep) HIP_TRY(ctx, hipMemcpy(npool, b->pool, (size_t)keep * sizeof(pg_run), hipMemcpyDeviceToDevice));
-        hipFree(b->pool);
+        (void)hipFree(b->pool);
         b->pool = npool;
-        b->pool_cap = ncap;
+        b->pool_shard_cap = ncap;
     }
     return fail(ctx, PG_E_DEVICE, "run pool kept overflowing");
 }
@@ -364,8 +379,7 @@ int download(pg_ctx *ctx, pg_device_batch *b, pg_result *r)
     const size_t n = b->n;
     r->n = b->n;
     std::vector<uint32_t> coff(n), ccnt(n), foff(n), fcnt(n);
-    uint32_t used = 0;
-    HIP_TRY(ctx, hipMemcpy(&used, b->pool_used, sizeof used, hipMemcpyDeviceToHost));
+    const size_t used = (size_t)b->pool_shard_cap * PG_POOL_SHARDS;   // the pool is sparse: copy all shards
     std::vector<pg_run> pool(used);
     if (n) {
         HIP_TRY(ctx, hipMemcpy(coff.data(), b->close_off, n * 4, hipMemcpyDeviceToHost));
@@ -450,9 +464,13 @@ int pg_create(const pg_params *p, pg_ctx **out)
         delete ctx;
         return PG_E_DEVICE;
     }
-    uint8_t mm8[512];
-    for (int i = 0; i < 512; i++) mm8[i] = (uint8_t)std::min<uint32_t>(ctx->mm[i], 255u);
-    if (dev_upload(ctx, &ctx->d_mm, mm8, 512) || dev_upload(ctx, &ctx->d_thr, ctx->thr, 512)) {
+    // the kernel evaluates g_maxMismatch[L] from breakpoints: the table must be monotone and <= 16
+    for (int i = 1; i < 500; i++)
+        if (ctx->mm[i] < ctx->mm[i - 1] || ctx->mm[i] > 16) {
+            pg_destroy(ctx);
+            return PG_E_UNSUPPORTED;
+        }
+    if (dev_upload(ctx, &ctx->d_thr, ctx->thr, 512)) {
         pg_destroy(ctx);
         return PG_E_DEVICE;
     }
@@ -464,7 +482,6 @@ void pg_destroy(pg_ctx *ctx)
 {
     if (!ctx) return;
     free_reference(ctx);
-    if (ctx->d_mm) hipFree(ctx->d_mm);
     if (ctx->d_thr) hipFree(ctx->d_thr);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
@@ -649,6 +666,14 @@ void pg_device_batch_free(pg_ctx *ctx, pg_device_batch *b)
     if (!b) return;
     free_batch_buffers(b);
     delete b;
+}
+
+// Diagnostics (not in the public header): raw per-read words of the alg-bytes array.
+int pg_debug_read_alg(pg_ctx *ctx, pg_device_batch *b, uint32_t *out, uint32_t n)
+{
+    if (!ctx || !b || !out || n > b->n) return PG_E_INVALID;
+    HIP_TRY(ctx, hipMemcpy(out, b->alg, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return PG_OK;
 }
 
 int pg_last_search_stats(const pg_ctx *ctx, double *kernel_ms, uint64_t *n_runs)

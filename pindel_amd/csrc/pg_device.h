@@ -28,7 +28,8 @@ struct PgDevParams {
     int32_t min_perfect;     // Min_Perfect_Match_Around_BP
     int32_t min_close;       // g_MinClose
     uint32_t spacer;
-    const uint8_t *mm_tab;   // [512] g_maxMismatch[L]
+    // g_maxMismatch as breakpoints (the table is monotone): mm(L) = #{k : L >= mm_bp[k]}
+    uint32_t mm_bp[16];
     const uint16_t *thr_tab; // [512] smallest n with (float)n >= (float)(len * u)
 };
 
@@ -55,24 +56,35 @@ struct PgDevBatch {
     uint32_t *close_run_cnt;
     uint32_t *far_run_off;
     uint32_t *far_run_cnt;
+    // Run pool, split into PG_POOL_SHARDS equal regions with one bump cursor each (a single
+    // device-wide cursor saturates at ~88 M atomics/s, MI355X_MICROARCH.md "dequeue").  Workgroup b
+    // allocates from shard b % PG_POOL_SHARDS; cursors are 64 bytes apart.
     pg_run *pool;
-    uint32_t pool_cap;
-    uint32_t *pool_used;           // atomic cursor; > pool_cap means overflow (retry bigger)
+    uint32_t pool_shard_cap;       // runs per shard
+    uint32_t *pool_used;           // [PG_POOL_SHARDS * 16]; cursor > pool_shard_cap means overflow (retry bigger)
     uint32_t *alg_bytes;           // [n] algorithmic bytes per read, nullable
 };
 
-// Bit layout of the 64-bit histogram word: count in the low 28 bits, candidate id above.
+// Histogram cell = count (low bits) | candidate id (high bits).
+//   64-bit cells: 28-bit count, id = rel(26) | strand(1) | region(7)   -- any window the ABI accepts
+//   32-bit cells: 16-bit count, id = rel(15) | strand(1)               -- every search window of the
+//                 launch has <= 32768 positions and there are no BreakDancer regions
 #define PG_CNT_BITS 28
-#define PG_REL_BITS 26            // position relative to the region origin
+#define PG_REL_BITS 26
+#define PG_CNT_BITS_SMALL 16
+#define PG_REL_BITS_SMALL 15
+#define PG_SMALL_MAX_WINDOW 32768
 #define PG_MAX_LEVELS 16
+#define PG_MM_BREAKS 16
+#define PG_POOL_SHARDS 1024u
+#define PG_RUN_TMP 24            // runs of one search kept in LDS; more -> evaluated again into the pool
 
 // Dynamic LDS layout (bytes), computed identically on host and device.
 struct PgLdsLayout {
-    uint32_t hist_off, carry_off, win_off, runs_off, total;
-    uint32_t lh;        // histogram row length (max read length in the launch)
+    uint32_t hist_off, carry_off, pref_off, queue_off, win_off, runs_off, total;
+    uint32_t lh;        // histogram row length (max read length in the launch + 1)
     uint32_t levels;    // max TOTAL_SNP_ERROR_CHECKED in the launch
     uint32_t win_words; // LDS window capacity in 32-base words
-    uint32_t run_cap;   // capacity of each of the three run buffers
 };
 
 #define PG_CHUNK 2048u            // window positions staged per LDS fill
@@ -81,30 +93,30 @@ static inline
 #ifdef __HIPCC__
 __host__ __device__
 #endif
-PgLdsLayout pg_lds_layout(uint32_t max_len, uint32_t levels, uint32_t nb)
+PgLdsLayout pg_lds_layout(uint32_t max_len, uint32_t levels, uint32_t nb, uint32_t cell)
 {
     PgLdsLayout l;
     l.lh = max_len + 1;
     l.levels = levels;
     l.hist_off = 0;
-    l.carry_off = l.hist_off + l.levels * l.lh * 8u;
-    l.win_off = (l.carry_off + l.levels * 8u + 15u) & ~15u;
+    l.carry_off = (l.hist_off + l.levels * l.lh * cell + 15u) & ~15u;        // ginit[16] + carry[16]
+    l.pref_off = l.carry_off + 2u * PG_MAX_LEVELS * cell;           // pref[levels][64]
+    l.queue_off = l.pref_off + l.levels * 64u * cell;                // queue[128]
+    l.win_off = (l.queue_off + 128u * 4u + 15u) & ~15u;              // window (stays valid during evaluate)
     // chunk + overhang of nb 64-base blocks on both sides + alignment slack
-    l.win_words = (PG_CHUNK + 2u * (64u * nb)) / 32u + 4u;
-    l.runs_off = l.win_off + l.win_words * 16u;
-    l.run_cap = max_len + 1;
-    l.total = l.runs_off + 3u * l.run_cap * 12u;
-    l.total = (l.total + 15u) & ~15u;
+    l.win_words = (PG_CHUNK + 2u * (64u * nb)) / 32u + 6u;
+    l.runs_off = (l.win_off + l.win_words * 16u + 15u) & ~15u;
+    l.total = (l.runs_off + PG_RUN_TMP * 12u + 15u) & ~15u;
     return l;
 }
 
 #ifdef __cplusplus
 extern "C" {
 #endif
-// Launches the search kernel for reads [first, first+n) of the batch on `stream`.
-// nb = number of 64-base blocks the longest read needs (2, 4 or 8).
+// Launches the search kernel for the reads of the batch on `stream`.  small_cells selects the
+// 32-bit histogram cells (see above for when that is valid).
 int pg_launch_search(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch *batch,
-                     int mode, uint32_t max_len, uint32_t levels, void *stream);
+                     int mode, uint32_t max_len, uint32_t levels, int small_cells, void *stream);
 #ifdef __cplusplus
 }
 #endif

@@ -12,25 +12,36 @@
 //
 //   * The chromosome lives in HBM as three bit planes (2-bit code planar + N plane).
 //     A window chunk is staged into LDS with coalesced dword loads.
-//   * Each lane owns one window position p.  The mismatch pattern of the read placed
-//     at p is obtained 64 bases at a time with funnel shifts + XOR on the planes
-//     (no per-base loop); the read's planes are wave-uniform (built with ballots).
-//   * A candidate's life is a short list of events "at length L it moves from
-//     mismatch level k to k+1".  Lanes add these events (count and candidate id
-//     packed in one 64-bit word) into an LDS difference histogram hist[level][L]
-//     with ds_add_u64.  Candidates are order independent in the reference (a point
-//     is only emitted when a level holds exactly one position), so per-level COUNTS
-//     plus the identity of a singleton are all that is needed.
-//   * Lanes then own lengths L: a wave prefix scan over L turns the differences
-//     into cnt[level][L]; the reference's emission / abort rules are evaluated for
-//     64 lengths at once, CheckMismatches is redone with the same plane arithmetic,
-//     and consecutive points are emitted as run-length-encoded runs.
+//   * PREFILTER: each lane owns one window position p.  One 32-base funnel extract +
+//     XOR against the read's (wave-uniform, ballot-built) planes decides whether p
+//     seeds a candidate and whether that candidate is still alive (fewer than
+//     TOTAL_SNP_ERROR_CHECKED mismatches) at the first reportable length.  Survivors
+//     (~10 % of positions) are compacted into an LDS queue with ballots.
+//   * DENSE PASS: 64 queued candidates at a time, one per lane.  The mismatch pattern
+//     of the read placed at p comes 64 bases per step (funnel shifts + XOR, no
+//     per-base loop).  A candidate's life is the short list "at length L it leaves
+//     mismatch level k".  Each such event is ONE LDS atomic add of -(1 | id<<CB) into
+//     the cumulative difference histogram G[k][L] (G[k](L) = number of candidates
+//     with level <= k at length L; count in the low CB bits, candidate id above).
+//     Candidates are order independent in the reference (a point is only emitted
+//     when a level holds exactly one position), so per-level COUNTS plus the identity
+//     of a singleton are all that is needed.
+//   * EVALUATE: a chunked prefix sum over L turns the differences into G[k](L); lanes
+//     then own lengths L and apply the reference's abort / emission rules to 64
+//     lengths at once, CheckMismatches is redone with the same plane arithmetic, and
+//     consecutive points are emitted as run-length-encoded runs.
 //   * Nested far-end ranges (128, 512, 2048 ... bases) only scan the new flanks:
 //     the histogram is additive over disjoint position sets.
+//
+// The kernel is latency bound, so LDS per workgroup is kept small
+// to run 8 waves per SIMD: histogram cells are 32-bit (16-bit count + 16-bit id) whenever
+// every search window of the launch has at most 32 768 positions (Pindel defaults), and
+// 64-bit otherwise (large -x, BreakDancer clusters).
 //
 // No MFMA: this is bit/byte comparison work, not a contraction.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "pg_device.h"
 
@@ -38,8 +49,21 @@ typedef unsigned long long u64;
 typedef unsigned int u32;
 
 #define WAVE 64
+// Optional per-phase cycle accounting (compile with -DPG_PHASE_TIMING; diagnostics only).
+#ifdef PG_PHASE_TIMING
+#define PT_DECL long long pt_t0 = clock64(); long long pt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PT_MARK(k) { long long t_ = clock64(); pt_acc[k] += t_ - pt_t0; pt_t0 = t_; }
+#else
+#define PT_DECL
+#define PT_MARK(k)
+#endif
+#ifndef PG_WAVES_PER_EU
+#define PG_WAVES_PER_EU 4   // register budget the kernel is compiled for (waves per SIMD)
+#endif
 
 __device__ __forceinline__ u64 ballot64(bool p) { return __ballot(p); }
+// tells the compiler a value is wave-uniform (keeps it in SGPRs)
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ u64 low_bits(int n)            // n in [0,64]
 {
     return n >= 64 ? ~0ull : ((1ull << n) - 1ull);
@@ -57,14 +81,20 @@ __device__ __forceinline__ u64 funnel64(u32 w0, u32 w1, u32 w2, u32 s)
     return (u64)a | ((u64)b << 32);
 }
 
-__device__ __forceinline__ u64 wave_incl_scan(u64 v, int lane)
+// Histogram cell formats.
+template <typename Cell> struct CellFmt;
+template <> struct CellFmt<u32> {
+    static constexpr int CB = PG_CNT_BITS_SMALL, RB = PG_REL_BITS_SMALL;
+};
+template <> struct CellFmt<u64> {
+    static constexpr int CB = PG_CNT_BITS, RB = PG_REL_BITS;
+};
+template <typename Cell>
+__device__ __forceinline__ Cell cell_pack(u64 rel, bool isB, u32 region)
 {
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        u64 t = __shfl_up(v, d, WAVE);
-        if (lane >= d) v += t;
-    }
-    return v;
+    typedef CellFmt<Cell> F;
+    u64 id = rel | ((u64)isB << F::RB) | ((u64)region << (F::RB + 1));
+    return (Cell)(1ull | (id << F::CB));
 }
 
 // Wave-uniform description of the read for one orientation: bit planes in
@@ -74,42 +104,65 @@ struct Planes {
     u64 lo[NB], hi[NB], nn[NB], oo[NB];   // code bit0, code bit1, is 'N', is other (never matches)
 };
 
-// Everything a search needs to know about the query.
+// Everything a search needs to know about the query.  The read's planes exist twice (original
+// orientation: forward and reversed consumption order); a query selects one of them.
 template <int NB>
 struct Query {
-    Planes<NB> q;        // base planes (before complement)
+    const Planes<NB> *fw, *rv;
+    bool use_rv;         // base planes (before complement) = use_rv ? *rv : *fw
     bool allowF, allowB; // candidate kinds searched
     bool cF, cB;         // complement flag per kind
     bool antisenseF, antisenseB;  // Strand reported for a point of that kind
     bool first_ok;       // first consumed base is one of ACGT
 };
 
+template <typename Cell>
 struct Search {
     int len, T, M, add_mm, bps, min_perfect, thr;
     int lh;
-    u64 *hist;
-    u64 *carry;
-    uint4 *win;
+    Cell *hist;    // G difference histogram [T][lh]
+    Cell *ginit;   // [PG_MAX_LEVELS] candidates entering at level k (at L = bps)
+    Cell *carry;   // [PG_MAX_LEVELS] running prefix per level during evaluate
+    Cell *pref;    // [T][64] absolute G of the current 64-length round (aliases win/queue)
+    u32 *queue;    // [128] compacted survivors of the prefilter
+    uint4 *win;    // staged window
+    // what the LDS window currently holds: bases [win_lo, win_hi) of the chromosome whose AbsLoc 0 is
+    // at word index win_wo; the first staged base is wbase (a multiple of 32)
+    long long win_wo;
+    int win_lo, win_hi, wbase;
 };
+
+// g_maxMismatch[L] from its breakpoints (the table is monotone): #{k : L >= mm_bp[k]}
+__device__ __forceinline__ int max_mismatch_at(const PgDevParams &prm, int L)
+{
+    int m = 0;
+#pragma unroll
+    for (int k = 0; k < PG_MM_BREAKS; k++) m += (u32)L >= prm.mm_bp[k] ? 1 : 0;
+    return m;
+}
 
 // ---------------------------------------------------------------------------------
 // mismatch / strict-inequality words of one 64-base block
 template <int NB>
-__device__ __forceinline__ void block_masks(const Planes<NB> &q, int b, bool comp,
+__device__ __forceinline__ void block_masks(const Query<NB> &Q, int b, bool comp,
                                             u64 rlo, u64 rhi, u64 rnn, u64 &mis, u64 &sne)
 {
+    const u64 qlo = Q.use_rv ? Q.rv->lo[b] : Q.fw->lo[b];
+    const u64 qhi = Q.use_rv ? Q.rv->hi[b] : Q.fw->hi[b];
+    const u64 qnn = Q.use_rv ? Q.rv->nn[b] : Q.fw->nn[b];
+    const u64 qoo = Q.use_rv ? Q.rv->oo[b] : Q.fw->oo[b];
     u64 cm = comp ? ~0ull : 0ull;
-    u64 x = rlo ^ q.lo[b] ^ cm;
-    u64 y = rhi ^ q.hi[b] ^ cm;
+    u64 x = rlo ^ qlo ^ cm;
+    u64 y = rhi ^ qhi ^ cm;
     u64 d = x | y;
     // Matches(): read N matches any ACGT; reference N matches nothing (searcher.cpp:36-44)
-    mis = (d & ~q.nn[b]) | rnn | q.oo[b];
+    mis = (d & ~qnn) | rnn | qoo;
     // exact character inequality (BP_On_Read != BP_On_Ref, searcher.cpp:349-364)
-    sne = (d & ~(rnn | q.nn[b])) | (rnn ^ q.nn[b]) | q.oo[b];
+    sne = (d & ~(rnn | qnn)) | (rnn ^ qnn) | qoo;
 }
 
 // 64 reference bits of each plane starting at AbsLoc q, from the LDS window.
-__device__ __forceinline__ void fetch_lds(const uint4 *win, long long wbase, long long q, bool rev,
+__device__ __forceinline__ void fetch_lds(const uint4 *win, int wbase, int q, bool rev,
                                           u64 &rlo, u64 &rhi, u64 &rnn)
 {
     u32 rel = (u32)(q - wbase);
@@ -121,11 +174,11 @@ __device__ __forceinline__ void fetch_lds(const uint4 *win, long long wbase, lon
     if (rev) { rlo = __brevll(rlo); rhi = __brevll(rhi); rnn = __brevll(rnn); }
 }
 
-// Same from HBM/L2 (used when re-checking a single candidate).
-__device__ __forceinline__ void fetch_global(const PgDevRef &ref, int chr, long long q, bool rev,
+// Same from HBM/L2 (used when re-checking a single candidate).  wo = word index of AbsLoc 0.
+__device__ __forceinline__ void fetch_global(const PgDevRef &ref, long long wo, int q, bool rev,
                                              u64 &rlo, u64 &rhi, u64 &rnn)
 {
-    long long w = (long long)ref.chr_word_off[chr] + (q >> 5);   // arithmetic shift = floor
+    long long w = wo + (long long)(q >> 5);   // arithmetic shift = floor
     u32 s = (u32)(q & 31);
     rlo = funnel64(ref.lo[w], ref.lo[w + 1], ref.lo[w + 2], s);
     rhi = funnel64(ref.hi[w], ref.hi[w + 1], ref.hi[w + 2], s);
@@ -134,160 +187,266 @@ __device__ __forceinline__ void fetch_global(const PgDevRef &ref, int chr, long 
 }
 
 // ---------------------------------------------------------------------------------
-// Scan window positions [s, e) of chromosome chr: every lane takes one position,
-// decides whether it seeds a candidate, and adds the candidate's level events to
-// the histogram.  Returns the number of seeds (NumberOfHits, farend_searcher.cpp:83).
-template <int NB>
-__device__ u32 scan_range(const PgDevRef &ref, const Search &S, const Query<NB> &Q, int chr,
-                          long long s, long long e, long long origin, u32 region, int lane)
+// Dense pass over n (<= 64) queued candidates, one per lane: full mismatch pattern, level at
+// L = bps, then one histogram update per later mismatch until the candidate dies.
+template <int NB, typename Cell>
+__device__ __forceinline__ void dense_pass(const Search<Cell> &S, const Query<NB> &Q, int wbase,
+                                           int origin, u32 region, int n, int lane)
 {
-    u32 hits = 0;
-    if (!Q.first_ok) return 0;
-    const u32 q0lo = (u32)(Q.q.lo[0] & 1ull), q0hi = (u32)(Q.q.hi[0] & 1ull);
-    for (long long cs = s; cs < e; cs += PG_CHUNK) {
-        long long ce = cs + PG_CHUNK < e ? cs + PG_CHUNK : e;
-        // ---- stage [cs - 64NB, ce + 64NB) into LDS, 32 bases per uint4 {lo,hi,nn,-}
-        long long qlo = cs - 64 * NB, qhi = ce + 64 * NB;
-        long long w0 = qlo >> 5;
-        long long wbase = w0 << 5;
-        int nwords = (int)(((qhi + 31) >> 5) - w0) + 2;
-        __syncthreads();
-        {
-            long long g0 = (long long)ref.chr_word_off[chr] + w0;
-            for (int i = lane; i < nwords; i += WAVE)
-                S.win[i] = make_uint4(ref.lo[g0 + i], ref.hi[g0 + i], ref.nn[g0 + i], 0u);
-        }
-        __syncthreads();
-        for (long long base = cs; base < ce; base += WAVE) {
-            long long p = base + lane;
-            bool act = p < ce;
-            bool seedF = false, seedB = false;
-            if (act) {
-                u32 rel = (u32)(p - wbase);
-                uint4 w = S.win[rel >> 5];
-                u32 bit = rel & 31u;
-                u32 bl = (w.x >> bit) & 1u, bh = (w.y >> bit) & 1u, bn = (w.z >> bit) & 1u;
-                u32 xl = bl ^ q0lo, xh = bh ^ q0hi;
-                seedF = Q.allowF && !bn && xl == (u32)Q.cF && xh == (u32)Q.cF;
-                seedB = Q.allowB && !bn && xl == (u32)Q.cB && xh == (u32)Q.cB;
-            }
-            bool alive = seedF || seedB;
-            hits += (u32)__popcll(ballot64(alive));
-            if (!__any(alive)) continue;
-            const bool isB = seedB;
-            const bool comp = isB ? Q.cB : Q.cF;
-            const u64 val = 1ull | (((u64)(p - origin) | ((u64)isB << PG_REL_BITS) |
-                                     ((u64)region << (PG_REL_BITS + 1))) << PG_CNT_BITS);
-            int level = 0;
+    bool alive = lane < n;
+    int p = 0;
+    bool isB = false;
+    if (alive) {
+        u32 e = S.queue[lane];
+        isB = e & 1u;
+        p = wbase + (int)(e >> 1);
+    }
+    const bool comp = isB ? Q.cB : Q.cF;
+    const Cell val = cell_pack<Cell>((u64)(u32)(p - origin), isB, region);
+    const Cell neg = (Cell)0 - val;
+    int cell = 0;            // level * lh
+    const int cell_end = S.T * S.lh;
 #pragma unroll
-            for (int b = 0; b < NB; b++) {
-                if (64 * b >= S.len - 1) break;                 // uniform
-                if (!__any(alive)) break;                        // uniform
-                u64 bits = 0;
-                if (alive) {
-                    u64 rlo, rhi, rnn, mis, sne;
-                    long long q = isB ? p - 64 * b - 63 : p + 64 * b;
-                    fetch_lds(S.win, wbase, q, isB, rlo, rhi, rnn);
-                    block_masks<NB>(Q.q, b, comp, rlo, rhi, rnn, mis, sne);
-                    if (b == 0) {
-                        // mismatches among the first bps bases decide the level at L = bps
-                        level = __popcll(mis & low_bits(S.bps));
-                        if (level >= S.T) alive = false;
-                        else atomicAdd(&S.hist[level * S.lh + S.bps], val);
-                    }
-                    // events at consumed index j in [bps, len-2] -> L = j+1 in [bps+1, len-1]
-                    bits = mis & bit_range(S.bps - 64 * b, S.len - 1 - 64 * b);
+    for (int b = 0; b < NB; b++) {
+        if (64 * b >= S.len - 1) break;                 // uniform
+        if (!__any(alive)) break;                        // uniform
+        u32 blo = 0, bhi = 0;
+        if (alive) {
+            u64 rlo, rhi, rnn, mis, sne;
+            int q = isB ? p - 64 * b - 63 : p + 64 * b;
+            fetch_lds(S.win, wbase, q, isB, rlo, rhi, rnn);
+            block_masks<NB>(Q, b, comp, rlo, rhi, rnn, mis, sne);
+            if (b == 0) {
+                // mismatches among the first bps bases decide the level at L = bps
+                int level = __popcll(mis & low_bits(S.bps));
+                if (level >= S.T) alive = false;
+                else {
+                    atomicAdd(&S.ginit[level], val);
+                    cell = level * S.lh;
                 }
-                while (__any(alive && bits != 0)) {
-                    if (alive && bits != 0) {
-                        int j = __ffsll((long long)bits) - 1;
-                        bits &= bits - 1;
-                        int L = 64 * b + j + 1;
-                        atomicAdd(&S.hist[level * S.lh + L], 0ull - val);
-                        level++;
-                        if (level >= S.T) alive = false;
-                        else atomicAdd(&S.hist[level * S.lh + L], val);
-                    }
-                }
+            }
+            // events at consumed index j in [bps, len-2] -> L = j+1 in [bps+1, len-1]
+            u64 bits = mis & bit_range(S.bps - 64 * b, S.len - 1 - 64 * b);
+            blo = (u32)bits;
+            bhi = (u32)(bits >> 32);
+        }
+        while (__any(alive && (blo | bhi) != 0u)) {
+            if (alive && (blo | bhi) != 0u) {
+                int j;
+                if (blo) { j = __ffs((int)blo) - 1; blo &= blo - 1u; }
+                else { j = 32 + __ffs((int)bhi) - 1; bhi &= bhi - 1u; }
+                atomicAdd(&S.hist[cell + 64 * b + j + 1], neg);   // leaves its level at L = j+1
+                cell += S.lh;
+                if (cell >= cell_end) alive = false;
             }
         }
     }
+}
+
+// Stages bases [lo, hi) (hi - lo <= PG_CHUNK + 128 NB) of a chromosome into the LDS window.
+template <int NB, typename Cell>
+__device__ __forceinline__ void stage_window(const PgDevRef &ref, Search<Cell> &S, long long wo, int lo, int hi,
+                                             int lane)
+{
+    const int w0 = lo >> 5;
+    const int nwords = ((hi + 31) >> 5) - w0 + 2;
+    __syncthreads();
+    {
+        const long long g0 = wo + (long long)w0;
+        const u32 *glo = ref.lo + g0, *ghi = ref.hi + g0, *gnn = ref.nn + g0;
+        for (int i = lane; i < nwords; i += WAVE) S.win[i] = make_uint4(glo[i], ghi[i], gnn[i], 0u);
+    }
+    __syncthreads();
+    S.win_wo = wo;
+    S.wbase = w0 << 5;
+    S.win_lo = lo;
+    S.win_hi = hi;
+}
+
+// Scan window positions [s, e) of a chromosome (wo = word index of its AbsLoc 0).
+// Returns the number of seeds (NumberOfHits, farend_searcher.cpp:83).
+template <int NB, typename Cell>
+__device__ __forceinline__ u32 scan_range(const PgDevRef &ref, Search<Cell> &S, const Query<NB> &Q,
+                                          long long wo, int s, int e, int origin, u32 region, int lane)
+{
+    u32 hits = 0;
+    if (!Q.first_ok) return 0;
+    const Planes<NB> &qp = Q.use_rv ? *Q.rv : *Q.fw;
+    const u32 q0lo = (u32)qp.lo[0], q0hi = (u32)qp.hi[0], q0nn = (u32)qp.nn[0], q0oo = (u32)qp.oo[0];
+    const u32 pre_mask = S.bps >= 32 ? 0xffffffffu : ((1u << S.bps) - 1u);
+    for (int cs = s; cs < e; cs += (int)PG_CHUNK) {
+        const int ce = cs + (int)PG_CHUNK < e ? cs + (int)PG_CHUNK : e;
+        // the chunk plus 64 NB bases of overhang on both sides must be in LDS
+        if (!(wo == S.win_wo && cs - 64 * NB >= S.win_lo && ce + 64 * NB <= S.win_hi))
+            stage_window<NB, Cell>(ref, S, wo, cs - 64 * NB, ce + 64 * NB, lane);
+        const int wbase = S.wbase;
+        int qn = 0;     // queued survivors (uniform)
+        for (int base = cs; base < ce; base += WAVE) {
+            const int p = base + lane;
+            bool surv = false, isB = false, seed = false;
+            const u32 rel = (u32)(p - wbase);
+            if (p < ce) {
+                // ---- prefilter: first 32 consumed bases of the candidate at p
+                u32 wi = rel >> 5, sh = rel & 31u;
+                uint4 wm = S.win[wi - 1], wc = S.win[wi], wp = S.win[wi + 1];
+                u32 bl = (wc.x >> sh) & 1u, bh = (wc.y >> sh) & 1u, bn = (wc.z >> sh) & 1u;
+                u32 xl = bl ^ (q0lo & 1u), xh = bh ^ (q0hi & 1u);
+                bool seedF = Q.allowF && !bn && xl == (u32)Q.cF && xh == (u32)Q.cF;
+                bool seedB = Q.allowB && !bn && xl == (u32)Q.cB && xh == (u32)Q.cB;
+                seed = seedF || seedB;
+                isB = seedB;
+                // forward: bits [p, p+32); backward: bits [p-31, p] reversed
+                u32 s2 = sh + (isB ? 1u : 0u);
+                u32 rlo = (u32)((((u64)(isB ? wc.x : wp.x) << 32) | (isB ? wm.x : wc.x)) >> s2);
+                u32 rhi = (u32)((((u64)(isB ? wc.y : wp.y) << 32) | (isB ? wm.y : wc.y)) >> s2);
+                u32 rnn = (u32)((((u64)(isB ? wc.z : wp.z) << 32) | (isB ? wm.z : wc.z)) >> s2);
+                if (isB) { rlo = __brev(rlo); rhi = __brev(rhi); rnn = __brev(rnn); }
+                u32 cm = (isB ? Q.cB : Q.cF) ? 0xffffffffu : 0u;
+                u32 d = (rlo ^ q0lo ^ cm) | (rhi ^ q0hi ^ cm);
+                u32 mis = (d & ~q0nn) | rnn | q0oo;
+                surv = seed && (S.bps > 32 || __popc(mis & pre_mask) < S.T);
+            }
+            hits += (u32)__popcll(ballot64(seed));
+            const u64 sm = ballot64(surv);
+            if (sm) {
+                if (surv) S.queue[qn + __popcll(sm & low_bits(lane))] = (rel << 1) | (isB ? 1u : 0u);
+                qn += __popcll(sm);
+                if (qn >= WAVE) {
+                    __syncthreads();
+                    dense_pass<NB, Cell>(S, Q, wbase, origin, region, WAVE, lane);
+                    __syncthreads();
+                    u32 moved = (lane < qn - WAVE) ? S.queue[WAVE + lane] : 0u;
+                    __syncthreads();
+                    if (lane < qn - WAVE) S.queue[lane] = moved;
+                    qn -= WAVE;
+                }
+            }
+        }
+        if (qn > 0) {
+            __syncthreads();
+            dense_pass<NB, Cell>(S, Q, wbase, origin, region, qn, lane);
+        }
+    }
+    __syncthreads();
     return hits;
 }
 
 // ---------------------------------------------------------------------------------
-// Decoded candidate of a histogram id.
+// Where the candidates of a search live.
 struct RegionInfo {
-    // for range / close searches: one region on `chr` with `origin`
-    // for BD searches: regions come from the per-read window list
-    int chr;
-    long long origin;
-    const pg_window *bd;     // non-null: BD cluster search
-    const PgDevRef *ref;
+    int chr;                 // range / close searches: one region on `chr` ...
+    long long wo;            // ... whose AbsLoc 0 is at word index wo, positions relative to `origin`
+    int origin;
+    const pg_window *bd;     // non-null: BreakDancer cluster search, regions from the window list
 };
 
-// Evaluate the reference's emission rules for every L (lanes own L) and write the
-// resulting runs to `out`.  Returns the number of runs; max_len = LengthStr of the last
-// emitted point (0 if none).
-template <int NB>
-__device__ int evaluate(const PgDevRef &ref, const PgDevParams &prm, const Search &S,
-                        const Query<NB> &Q, const RegionInfo &R, pg_run *out, int &max_len,
-                        int lane)
+// Evaluate the reference's emission rules for every L (lanes own L).  The runs with index in
+// [skip, skip+cap) are written to out[0..cap); the total number of runs is returned, so a caller
+// whose buffer is too small can come back for the next chunk.  max_len = LengthStr of the last
+// emitted point (0 if none).  The histogram is not modified.
+template <int NB, typename Cell>
+__device__ __forceinline__ int evaluate(const PgDevRef &ref, const PgDevParams &prm, const Search<Cell> &S,
+                                        const Query<NB> &Q, const RegionInfo &R, pg_run *out, int skip,
+                                        int cap, int &max_len, int lane)
 {
+    typedef CellFmt<Cell> F;
     int n_runs = 0;
     max_len = 0;
-    if (lane < S.T) S.carry[lane] = 0;
+    // G[k](bps) = sum over l <= k of the candidates that entered at level l
     __syncthreads();
+    {
+        Cell g = lane < S.T ? S.ginit[lane] : (Cell)0;
+#pragma unroll
+        for (int d = 1; d < PG_MAX_LEVELS; d <<= 1) {
+            Cell t = __shfl_up(g, d, WAVE);
+            if (lane >= d) g += t;
+        }
+        if (lane < S.T) S.carry[lane] = g;
+    }
+    __syncthreads();
+    // lanes as (level, chunk) for the prefix over L
+    const int CPL = WAVE / S.T;                  // chunks per level
+    const int CS = (WAVE + CPL - 1) / CPL;       // cells per chunk
+    const int pk = lane / CPL, pc = lane - pk * CPL;
+    const bool pact = pk < S.T;
     bool aborted = false;
     for (int r0 = S.bps; r0 <= S.len - 1 && !aborted; r0 += WAVE) {
+        // ---- phase 1: absolute G[k](L) for L in [r0, r0+64) into pref[k][L-r0]
+        {
+            const int j0 = pc * CS, j1 = (j0 + CS < WAVE) ? j0 + CS : WAVE;
+            const Cell *row = S.hist + pk * S.lh + r0;
+            Cell tot = 0;
+            if (pact)
+                for (int j = j0; j < j1; j++)
+                    if (r0 + j <= S.len - 1) tot += row[j];
+            Cell inc = tot;
+            for (int d = 1; d < CPL; d <<= 1) {
+                Cell t = __shfl_up(inc, d, WAVE);
+                if (pc >= d) inc += t;
+            }
+            Cell acc = pact ? (Cell)(S.carry[pk] + inc - tot) : (Cell)0;
+            if (pact)
+                for (int j = j0; j < j1; j++) {
+                    if (r0 + j <= S.len - 1) acc += row[j];
+                    S.pref[pk * WAVE + j] = acc;
+                }
+            __syncthreads();
+            if (pact && pc == CPL - 1) S.carry[pk] = acc;
+            __syncthreads();
+        }
+        // ---- phase 2: lanes own L
         const int L = r0 + lane;
         const bool valid = L <= S.len - 1;
         int lo = -1;
         u32 cnt_lo = 0, sumw = 0;
         u64 id_lo = 0;
         for (int i = 0; i < S.T; i++) {
-            u64 d = valid ? S.hist[i * S.lh + L] : 0ull;
-            u64 c = wave_incl_scan(d, lane) + S.carry[i];
-            __syncthreads();
-            if (lane == WAVE - 1) S.carry[i] = c;
-            u32 cnt = (u32)(c & ((1ull << PG_CNT_BITS) - 1ull));
-            if (lo < 0 && i <= S.M && cnt > 0) { lo = i; cnt_lo = cnt; id_lo = c >> PG_CNT_BITS; }
-            if (lo >= 0 && i <= lo + S.add_mm) sumw += cnt;
+            Cell c = valid ? S.pref[i * WAVE + lane] : (Cell)0;
+            u32 cnt = (u32)(c & (Cell)((1ull << F::CB) - 1ull));
+            if (lo < 0 && i <= S.M && cnt > 0) { lo = i; cnt_lo = cnt; }
+            if (lo >= 0 && i == lo + S.add_mm) { sumw = cnt; id_lo = (u64)(c >> F::CB); }
         }
-        __syncthreads();
-        const int mmL = valid ? (int)prm.mm_tab[L] : 0;
+        const int mmL = valid ? max_mismatch_at(prm, L) : 0;
         // "if (minimumNumberOfMismatches(...) > g_maxMismatch[L]) return;"
         const bool abortL = valid && ((lo < 0 ? S.M + 1 : lo) > mmL);
         const u64 ab = ballot64(abortL);
         const int first_abort = ab ? __ffsll((long long)ab) - 1 : WAVE;
+        // cumulative counts: G[lo] == 1 and G[lo+ADD] == 1 <=> the level-lo position is the only one
+        // within ADDITIONAL_MISMATCH extra mismatches; its id is the id field of G[lo+ADD]
         bool cand = valid && lane < first_abort && lo >= 0 && cnt_lo == 1 && L >= S.bps + lo &&
                     sumw == 1;
         // ---- CheckMismatches (searcher.cpp:331-388) on the singleton
         bool isB = false;
-        long long p = 0;
+        int p = 0;
         int chr = R.chr;
         if (cand) {
-            u64 rel = id_lo & ((1ull << PG_REL_BITS) - 1ull);
-            isB = (id_lo >> PG_REL_BITS) & 1ull;
-            u32 region = (u32)(id_lo >> (PG_REL_BITS + 1));
-            long long origin = R.origin;
+            u32 rel = (u32)(id_lo & ((1ull << F::RB) - 1ull));
+            isB = (id_lo >> F::RB) & 1ull;
+            u32 region = (u32)(id_lo >> (F::RB + 1));
+            int origin = R.origin;
+            long long wo = R.wo;
             if (R.bd) {
                 pg_window w = R.bd[region];
                 chr = w.chr_id;
+                wo = (long long)ref.chr_word_off[chr];
                 int st = w.start < 0 ? w.end - 1 : w.start;
                 origin = st;
             }
-            p = origin + (long long)rel;
+            p = origin + (int)rel;
             const bool comp = isB ? Q.cB : Q.cF;
+            // the whole read placed at the candidate lies inside the staged window?
+            const bool in_lds = wo == S.win_wo && (isB ? (p - 64 * NB + 1 >= S.win_lo && p < S.win_hi)
+                                                       : (p >= S.win_lo && p + 64 * NB <= S.win_hi));
             int ham = 0;
             bool bad = false;
 #pragma unroll
             for (int b = 0; b < NB; b++) {
                 if (64 * b < S.len) {
                     u64 rlo, rhi, rnn, mis, sne;
-                    long long q = isB ? p - 64 * b - 63 : p + 64 * b;
-                    fetch_global(ref, chr, q, isB, rlo, rhi, rnn);
-                    block_masks<NB>(Q.q, b, comp, rlo, rhi, rnn, mis, sne);
+                    int q = isB ? p - 64 * b - 63 : p + 64 * b;
+                    if (in_lds) fetch_lds(S.win, S.wbase, q, isB, rlo, rhi, rnn);
+                    else fetch_global(ref, wo, q, isB, rlo, rhi, rnn);
+                    block_masks<NB>(Q, b, comp, rlo, rhi, rnn, mis, sne);
                     ham += __popcll(mis & low_bits(S.len - 64 * b));
                     bad |= (sne & bit_range(L - S.min_perfect - 64 * b, L - 64 * b)) != 0;
                 }
@@ -305,16 +464,18 @@ __device__ int evaluate(const PgDevRef &ref, const PgDevParams &prm, const Searc
         if (start) {
             u64 higher = lane == 63 ? 0ull : (brk & ~low_bits(lane + 1));
             int end_lane = higher ? __ffsll((long long)higher) - 2 : WAVE - 1;
-            int idx = n_runs + __popcll(starts & low_bits(lane));
-            pg_run run;
-            run.abs_loc_first = isB ? (u32)(p - L + 1) : (u32)(p + L - 1);
-            run.len_first = (uint16_t)L;
-            run.len_last = (uint16_t)(r0 + end_lane);
-            run.mismatches = (uint8_t)lo;
-            bool anti = isB ? Q.antisenseB : Q.antisenseF;
-            run.flags = (uint8_t)((isB ? PG_RUN_BACKWARD : 0u) | (anti ? PG_RUN_ANTISENSE : 0u));
-            run.chr_id = (int16_t)chr;
-            out[idx] = run;
+            int idx = n_runs + __popcll(starts & low_bits(lane)) - skip;
+            if (idx >= 0 && idx < cap) {
+                pg_run run;
+                run.abs_loc_first = isB ? (u32)(p - L + 1) : (u32)(p + L - 1);
+                run.len_first = (uint16_t)L;
+                run.len_last = (uint16_t)(r0 + end_lane);
+                run.mismatches = (uint8_t)lo;
+                bool anti = isB ? Q.antisenseB : Q.antisenseF;
+                run.flags = (uint8_t)((isB ? PG_RUN_BACKWARD : 0u) | (anti ? PG_RUN_ANTISENSE : 0u));
+                run.chr_id = (int16_t)chr;
+                out[idx] = run;
+            }
         }
         n_runs += __popcll(starts);
         const u64 em = ballot64(cand);
@@ -325,11 +486,15 @@ __device__ int evaluate(const PgDevRef &ref, const PgDevParams &prm, const Searc
     return n_runs;
 }
 
-__device__ __forceinline__ void zero_hist(const Search &S, int lane)
+template <typename Cell>
+__device__ __forceinline__ void zero_hist(const Search<Cell> &S, int lane)
 {
     __syncthreads();
-    int n = S.T * S.lh;
-    for (int i = lane; i < n; i += WAVE) S.hist[i] = 0ull;
+    // hist is 16-byte aligned; its padded tail belongs to it (pg_lds_layout)
+    const int n16 = (int)(((size_t)S.T * S.lh * sizeof(Cell) + 15) / 16);
+    uint4 *h = (uint4 *)S.hist;
+    for (int i = lane; i < n16; i += WAVE) h[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (lane < PG_MAX_LEVELS) S.ginit[lane] = (Cell)0;
     __syncthreads();
 }
 
@@ -357,276 +522,400 @@ __device__ void load_planes(const uint8_t *seq, int len, int lane, Planes<NB> &f
     }
 }
 
-template <int NB>
-__device__ __forceinline__ bool first_base_ok(const Planes<NB> &p)
+// Bump-allocates n runs in this workgroup's pool shard (one atomic per wave); returns the pool
+// offset.  fits = the allocation lies inside the shard (otherwise the host repeats the launch with a
+// larger pool).
+__device__ __forceinline__ u32 pool_alloc(const PgDevBatch &B, int n, int lane, bool &fits)
 {
-    return ((p.nn[0] | p.oo[0]) & 1ull) == 0ull;
+    const u32 shard = blockIdx.x & (PG_POOL_SHARDS - 1u);
+    u32 off = 0;
+    if (n > 0 && lane == 0) off = atomicAdd(B.pool_used + shard * 16u, (u32)n);
+    off = __shfl(off, 0, WAVE);
+    fits = (u64)off + (u64)n <= (u64)B.pool_shard_cap;
+    return shard * B.pool_shard_cap + off;
 }
 
-__device__ __forceinline__ void copy_runs(pg_run *dst, const pg_run *src, int n, int lane)
+template <int NB>
+__device__ __forceinline__ bool first_base_ok(const Query<NB> &Q)
 {
-    for (int i = lane; i < n; i += WAVE) dst[i] = src[i];
+    const u64 x = Q.use_rv ? (Q.rv->nn[0] | Q.rv->oo[0]) : (Q.fw->nn[0] | Q.fw->oo[0]);
+    return (x & 1ull) == 0ull;
 }
 
-// One read per 64-thread workgroup.
-template <int NB>
-__global__ __launch_bounds__(WAVE) void pg_search_kernel(PgDevRef ref, PgDevParams prm,
-                                                         PgDevBatch B, int mode, uint32_t max_len,
-                                                         uint32_t levels)
+// One read per 64-thread workgroup.  The read goes through a sequence of search STEPS that share
+// one scan site and one evaluate site:
+//   steps 0..3  close-end attempts (R0,seq) (R0,RC) (R1,RC) (R1,seq)   pindel.cpp:2537-2575
+//   step  4     far end, BreakDancer cluster                            pindel.cpp:1006-1018
+//   steps 5..   far end, ranges r = 1 .. MaxRangeIndex+1                pindel.cpp:1025-1070
+template <int NB, typename Cell, int mode>
+__global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevRef ref, PgDevParams prm,
+                                                         PgDevBatch B, uint32_t max_len, uint32_t levels)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
     const uint32_t rid = B.first_read + blockIdx.x;
     if (blockIdx.x >= B.n_reads) return;
 
-    const PgLdsLayout lay = pg_lds_layout(max_len, levels, NB);
-    Search S;
-    S.hist = (u64 *)(smem + lay.hist_off);
-    S.carry = (u64 *)(smem + lay.carry_off);
+    const PgLdsLayout lay = pg_lds_layout(max_len, levels, NB, (uint32_t)sizeof(Cell));
+    Search<Cell> S;
+    S.hist = (Cell *)(smem + lay.hist_off);
+    S.ginit = (Cell *)(smem + lay.carry_off);
+    S.carry = S.ginit + PG_MAX_LEVELS;
+    S.pref = (Cell *)(smem + lay.pref_off);
+    S.queue = (u32 *)(smem + lay.queue_off);
     S.win = (uint4 *)(smem + lay.win_off);
     pg_run *runs_tmp = (pg_run *)(smem + lay.runs_off);
-    pg_run *runs_far = runs_tmp + lay.run_cap;
-    pg_run *runs_close = runs_far + lay.run_cap;
     S.lh = (int)lay.lh;
+    S.win_wo = -1;
+    S.win_lo = S.win_hi = S.wbase = 0;
 
     const u64 off = B.seq_off[rid];
     const int len = (int)(B.seq_off[rid + 1] - off);
     const uint8_t *seq = B.seq + off;
     const int chr = B.chr[rid];
+    const long long chr_wo = (long long)ref.chr_word_off[chr];
+    const int chr_size = (int)ref.chr_size[chr];
     S.len = len;
-    S.M = prm.mm_tab[len];
+    S.M = max_mismatch_at(prm, len);
     S.add_mm = prm.add_mm;
     S.T = S.M + prm.add_mm + 1;
     S.min_perfect = prm.min_perfect;
     S.thr = prm.thr_tab[len];
 
+    PT_DECL
     Planes<NB> A, Ar;   // original orientation: forward and reversed consumption order
     load_planes<NB>(seq, len, lane, A, Ar);
+    PT_MARK(0)
 
-    float alg = (float)len;
-    int flipped = 0;
-    int n_close = 0, close_max = 0;
-    u32 close_last = 0;
+    float alg = (mode & PG_MODE_CLOSE) ? (float)len : 0.f;   // the read itself is counted once
+    int flipped = 0, close_max = 0, n_close = 0, n_far = 0, far_max = 0;
+    u32 close_last = 0, close_base = 0, far_base = 0;
 
-    // ============================ close end ======================================
-    if (mode & PG_MODE_CLOSE) {
-        const char strand = (char)B.strand[rid];
-        const long long apos = (long long)B.pos[rid] + prm.spacer;
-        const long long isz = B.isz[rid];
-        S.bps = prm.min_close;
-        long long wsize = 0;
-        if (len - 1 >= S.bps && (strand == '+' || strand == '-')) {
-            // attempts: (R0, seq) (R0, RC) (R1, RC) (R1, seq), pindel.cpp:2537-2575
-            for (int att = 0; att < 4 && n_close == 0; att++) {
-                const int Rg = att >> 1;
-                flipped = (att == 1 || att == 2) ? 1 : 0;
-                Query<NB> Q;
-                long long s, e;
-                if (strand == '+') {
-                    // CurrentReadSeq = RC(cur), grown left to right (pindel.cpp:2271-2291)
-                    Q.q = flipped ? A : Ar;
-                    Q.cF = !flipped; Q.cB = false;
-                    Q.allowF = true; Q.allowB = false;
-                    s = apos - Rg * isz;
-                    e = s + (2 * Rg + 1) * isz;
-                } else {
-                    // CurrentReadSeq = cur, grown right to left (pindel.cpp:2298-2319)
-                    Q.q = flipped ? A : Ar;
-                    Q.cB = flipped; Q.cF = false;
-                    Q.allowF = false; Q.allowB = true;
-                    e = apos + Rg * isz;
-                    s = e - (2 * Rg + 1) * isz;
-                }
-                Q.antisenseF = true;    // CheckLeft_Close: FORWARD, ANTISENSE
-                Q.antisenseB = false;   // CheckRight_Close: BACKWARD, SENSE
-                Q.first_ok = first_base_ok<NB>(Q.q);
-                wsize = e > s ? e - s : 0;
-                zero_hist(S, lane);
-                scan_range<NB>(ref, S, Q, chr, s, e, s, 0u, lane);
-                __syncthreads();
-                RegionInfo R = { chr, s, nullptr, &ref };
-                n_close = evaluate<NB>(ref, prm, S, Q, R, runs_tmp, close_max, lane);
-            }
-            if (n_close == 0) flipped = 0;   // two flips: back to the original orientation
-        }
-        alg += 0.375f * (float)(wsize + 2 * len);
-        // CleanUniquePoints (pindel.cpp:2904-2941): keep the points whose implied read
-        // terminal equals the last point's, i.e. the runs of the last run's candidate.
-        int kept = 0;
-        if (n_close > 0) {
-            pg_run last = runs_tmp[n_close - 1];
-            u32 term_last = (last.flags & PG_RUN_BACKWARD) ? last.abs_loc_first + last.len_first
-                                                           : last.abs_loc_first - last.len_first;
-            for (int i0 = 0; i0 < n_close; i0 += WAVE) {
-                int i = i0 + lane;
-                bool keep = false;
-                pg_run r;
-                if (i < n_close) {
-                    r = runs_tmp[i];
-                    u32 term = (r.flags & PG_RUN_BACKWARD) ? r.abs_loc_first + r.len_first
-                                                           : r.abs_loc_first - r.len_first;
-                    keep = term == term_last && r.flags == last.flags && r.chr_id == last.chr_id;
-                }
-                u64 km = ballot64(keep);
-                if (keep) runs_close[kept + __popcll(km & low_bits(lane))] = r;
-                kept += __popcll(km);
-            }
-            __syncthreads();
-            u32 span = (u32)(last.len_last - last.len_first);
-            close_last = (last.flags & PG_RUN_BACKWARD) ? last.abs_loc_first - span
-                                                        : last.abs_loc_first + span;
-        }
-        n_close = kept;
-        if (lane == 0) {
-            B.rc_flag[rid] = (uint8_t)flipped;
-            B.close_last_abs[rid] = close_last;
-            B.close_max_len[rid] = (uint16_t)close_max;
-        }
-        // publish UP_Close
-        u32 base = 0;
-        if (n_close > 0) {
-            if (lane == 0) base = atomicAdd(B.pool_used, (u32)n_close);
-            base = __shfl(base, 0, WAVE);
-            if (base + (u32)n_close <= B.pool_cap)
-                copy_runs(B.pool + base, runs_close, n_close, lane);
-        }
-        if (lane == 0) { B.close_run_off[rid] = base; B.close_run_cnt[rid] = (u32)n_close; }
-        alg += 12.0f * (float)n_close;
-    } else {
+    const bool do_close = (mode & PG_MODE_CLOSE) != 0, do_far = (mode & PG_MODE_FAR) != 0;
+    const char strand = do_close ? (char)B.strand[rid] : '+';
+    const int apos = do_close ? (int)(B.pos[rid] + (int)prm.spacer) : 0;
+    const int isz = do_close ? (int)B.isz[rid] : 0;
+    if (!do_close) {
         flipped = B.rc_flag[rid];
         close_last = B.close_last_abs[rid];
         close_max = B.close_max_len[rid];
     }
-
-    // ============================ far end ========================================
-    if (mode & PG_MODE_FAR) {
-        int n_far = 0, far_max = 0;
-        S.bps = 10;                        // farend_searcher.cpp:90
-        Query<NB> Q;
-        // cur = flipped ? RC(orig) : orig.  Plus strand consumes cur left to right,
-        // Minus strand consumes complement(cur) walking the reference right to left.
-        Q.q = flipped ? Ar : A;
-        Q.cF = flipped; Q.cB = !flipped;
-        Q.allowF = Q.allowB = true;
-        Q.antisenseF = false;              // FORWARD, SENSE
-        Q.antisenseB = true;               // BACKWARD, ANTISENSE
-        // "if (CurrentBase == 'N' || MaxLenCloseEnd() == 0) return;" -- any other
-        // non-ACGT first base simply finds no seed.
-        Q.first_ok = first_base_ok<NB>(Q.q);
-        const bool searchable = close_max > 0 && Q.first_ok && len - 1 >= S.bps;
-        float far_bases = 0.f;
-        if (searchable) {
-            const long long size = ref.chr_size[chr];
-            bool done = false;
-            // ---- BreakDancer cluster first (pindel.cpp:1006-1018)
-            if (B.bd_off) {
-                const u64 b0 = B.bd_off[rid], b1 = B.bd_off[rid + 1];
-                const int nw = (int)(b1 - b0);
-                if (nw > 0) {
-                    const pg_window *bd = B.bd + b0;
-                    zero_hist(S, lane);
-                    u32 hits = 0;
-                    for (int r = 0; r < nw; r++) {
-                        pg_window w = bd[r];
-                        long long st = w.start < 0 ? w.end - 1 : w.start;
-                        long long en = w.end;
-                        long long csz = ref.chr_size[w.chr_id];
-                        long long s2 = st < 0 ? 0 : st, e2 = en > csz ? csz : en;
-                        hits += scan_range<NB>(ref, S, Q, w.chr_id, s2, e2, st, (u32)r, lane);
-                        far_bases += (float)(e2 > s2 ? e2 - s2 : 0) + 2.f * len;
-                    }
-                    __syncthreads();
-                    if (hits > 0) {
-                        RegionInfo R = { chr, 0, bd, &ref };
-                        int mx;
-                        int n = evaluate<NB>(ref, prm, S, Q, R, runs_tmp, mx, lane);
-                        if (mx >= far_max) {           // NewUPFarIsBetter
-                            copy_runs(runs_far, runs_tmp, n, lane);
-                            n_far = n; far_max = mx;
-                            __syncthreads();
-                        }
-                    }
-                    done = far_max + close_max >= len; // goodFarEndFound
-                }
-            }
-            // ---- ranges 64*4^(r-1) around the close end (pindel.cpp:1025-1070)
-            if (!done) {
-                const long long center = close_last;
-                long long span = 64;
-                long long maxspan = 64;
-                for (int i = 0; i < prm.max_range_index; i++) maxspan *= 4;
-                const long long origin = center - maxspan;
-                long long ps = 0, pe = 0;          // previous (nested) window, empty if ps >= pe
-                u32 hits = 0;
-                long long reach = 0;
-                zero_hist(S, lane);
-                for (int r = 1; r <= prm.max_range_index + 1 && !done; r++, span *= 4) {
-                    long long s, e;
-                    if (center > span + prm.spacer) s = center - span; else s = prm.spacer;
-                    if (center + span + prm.spacer < size) e = center + span; else e = size - prm.spacer;
-                    if (s < e) {
-                        if (ps < pe) {
-                            // only the new flanks; the histogram is additive
-                            long long le = e < ps ? e : ps;
-                            if (s < le) hits += scan_range<NB>(ref, S, Q, chr, s, le, origin, 0u, lane);
-                            long long rs = s > pe ? s : pe;
-                            if (rs < e) hits += scan_range<NB>(ref, S, Q, chr, rs, e, origin, 0u, lane);
-                            ps = s < ps ? s : ps;
-                            pe = e > pe ? e : pe;
-                        } else {
-                            hits += scan_range<NB>(ref, S, Q, chr, s, e, origin, 0u, lane);
-                            ps = s; pe = e;
-                        }
-                        reach = pe - ps;
-                    }
-                    __syncthreads();
-                    if (hits > 0) {
-                        RegionInfo R = { chr, origin, nullptr, &ref };
-                        int mx;
-                        int n = evaluate<NB>(ref, prm, S, Q, R, runs_tmp, mx, lane);
-                        if (mx >= far_max) {
-                            copy_runs(runs_far, runs_tmp, n, lane);
-                            n_far = n; far_max = mx;
-                            __syncthreads();
-                        }
-                    }
-                    done = far_max + close_max >= len;
-                }
-                far_bases += (float)reach + 2.f * len;
-            }
-        }
-        alg += 0.375f * far_bases;
-        u32 base = 0;
-        if (n_far > 0) {
-            if (lane == 0) base = atomicAdd(B.pool_used, (u32)n_far);
-            base = __shfl(base, 0, WAVE);
-            if (base + (u32)n_far <= B.pool_cap) copy_runs(B.pool + base, runs_far, n_far, lane);
-        }
-        if (lane == 0) { B.far_run_off[rid] = base; B.far_run_cnt[rid] = (u32)n_far; }
-        alg += 12.0f * (float)n_far;
+    int nbd = 0;
+    const pg_window *bd = nullptr;
+    if (do_far && B.bd_off) {
+        const u64 b0 = B.bd_off[rid];
+        nbd = (int)(B.bd_off[rid + 1] - b0);
+        bd = B.bd + b0;
     }
-    if (B.alg_bytes && lane == 0) B.alg_bytes[rid] = (u32)(alg + 0.5f);
+    int maxspan = 64;
+    for (int i = 0; i < prm.max_range_index; i++) maxspan *= 4;
+    const int last_step = 5 + prm.max_range_index;
+
+    // far-range bookkeeping (nested windows)
+    int ps = 0, pe = 0, span = 64, reach = 0;
+    u32 hits = 0;
+    float close_bases = 0.f, far_bases = 0.f;
+
+    int step = do_close ? 0 : 4;
+    if (do_close && !(len - 1 >= prm.min_close && (strand == '+' || strand == '-')))
+        step = 4;                                    // no close end possible
+    bool far_ready = false;                          // far-end query configured
+    while (step <= last_step) {
+        const bool is_close = step < 4;
+        if (!is_close && !do_far) break;
+        if (!is_close && !far_ready) {
+            // entering the far end: "if (CurrentBase == 'N' || MaxLenCloseEnd() == 0) return;"
+            if (!(close_max > 0 && len - 1 >= 10)) break;
+            far_ready = true;
+        }
+        // ---------------- configure the step
+        Query<NB> Q;
+        Q.fw = &A;
+        Q.rv = &Ar;
+        int nwin = 0;                 // windows to scan this step (<= 2, or nbd)
+        int s1 = 0, e1 = 0, s2 = 0, e2 = 0;
+        int origin = 0;
+        bool zero = false;
+        if (is_close) {
+            const int Rg = step >> 1;
+            flipped = (step == 1 || step == 2) ? 1 : 0;
+            S.bps = prm.min_close;
+            // '+' anchor: CurrentReadSeq = RC(cur), grown left to right (pindel.cpp:2271-2291)
+            // '-' anchor: CurrentReadSeq = cur, grown right to left     (pindel.cpp:2298-2319)
+            Q.use_rv = !flipped;
+            if (strand == '+') {
+                Q.cF = !flipped; Q.cB = false; Q.allowF = true; Q.allowB = false;
+                s1 = apos - Rg * isz;
+                e1 = s1 + (2 * Rg + 1) * isz;
+            } else {
+                Q.cB = flipped; Q.cF = false; Q.allowF = false; Q.allowB = true;
+                e1 = apos + Rg * isz;
+                s1 = e1 - (2 * Rg + 1) * isz;
+            }
+            Q.antisenseF = true;      // CheckLeft_Close: FORWARD, ANTISENSE
+            Q.antisenseB = false;     // CheckRight_Close: BACKWARD, SENSE
+            origin = s1;
+            nwin = 1;
+            zero = true;
+            hits = 0;
+            close_bases = (float)(e1 > s1 ? e1 - s1 : 0);
+        } else {
+            S.bps = 10;               // farend_searcher.cpp:90
+            // cur = flipped ? RC(orig) : orig.  Plus strand consumes cur left to right, Minus strand
+            // consumes complement(cur) walking the reference right to left.
+            Q.use_rv = flipped;
+            Q.cF = flipped; Q.cB = !flipped;
+            Q.allowF = Q.allowB = true;
+            Q.antisenseF = false;     // FORWARD, SENSE
+            Q.antisenseB = true;      // BACKWARD, ANTISENSE
+            if (step == 4) {
+                if (nbd == 0) { step++; continue; }
+                nwin = nbd;
+                zero = true;
+                hits = 0;
+            } else {
+                const int center = (int)close_last;
+                origin = center - maxspan;
+                if (step == 5) {
+                    zero = true; hits = 0; ps = pe = 0; span = 64;
+                    // one LDS fill serves the nested ranges up to 2048 bases (all of them at -x <= 2)
+                    const int half = maxspan < (int)PG_CHUNK / 2 ? maxspan : (int)PG_CHUNK / 2;
+                    stage_window<NB, Cell>(ref, S, chr_wo, center - half - 64 * NB, center + half + 64 * NB, lane);
+                }
+                // window of this range, clipped to the non-spacer part (pindel.cpp:1034-1043)
+                int s, e;
+                if ((u32)center > (u32)span + prm.spacer) s = center - span; else s = (int)prm.spacer;
+                if ((u32)center + (u32)span + prm.spacer < (u32)chr_size) e = center + span;
+                else e = chr_size - (int)prm.spacer;
+                if (s < e) {
+                    if (ps < pe) {
+                        // only the new flanks; the histogram is additive
+                        const int le = e < ps ? e : ps;
+                        const int rs = s > pe ? s : pe;
+                        if (s < le) { s1 = s; e1 = le; nwin = 1; }
+                        if (rs < e) {
+                            if (nwin == 0) { s1 = rs; e1 = e; } else { s2 = rs; e2 = e; }
+                            nwin++;
+                        }
+                        ps = s < ps ? s : ps;
+                        pe = e > pe ? e : pe;
+                    } else {
+                        s1 = s; e1 = e; nwin = 1;
+                        ps = s; pe = e;
+                    }
+                    reach = pe - ps;
+                }
+                span *= 4;
+            }
+        }
+        Q.first_ok = first_base_ok<NB>(Q);
+        if (!is_close && !Q.first_ok) break;         // far end: first base N (or not ACGT): nothing to find
+        PT_MARK(5)
+        if (zero) zero_hist(S, lane);
+        PT_MARK(4)
+        // ---------------- scan
+        for (int w = 0; w < nwin; w++) {
+            long long wo = chr_wo;
+            int s, e, org = origin;
+            u32 region = 0;
+            if (step == 4) {
+                const pg_window bw = bd[w];
+                const int st = bw.start < 0 ? bw.end - 1 : bw.start;
+                const int csz = (int)ref.chr_size[bw.chr_id];
+                wo = (long long)ref.chr_word_off[bw.chr_id];
+                s = st < 0 ? 0 : st;
+                e = bw.end > csz ? csz : bw.end;
+                org = st;
+                region = (u32)w;
+                far_bases += (float)(e > s ? e - s : 0) + 2.f * len;
+            } else {
+                s = w == 0 ? s1 : s2;
+                e = w == 0 ? e1 : e2;
+            }
+            hits += scan_range<NB, Cell>(ref, S, Q, wo, s, e, org, region, lane);
+        }
+        PT_MARK(1)
+        // ---------------- evaluate (NumberOfHits == 0 leaves UP_Far untouched, farend_searcher.cpp:87)
+        // One evaluate site inside a small pass machine.  Normally a search yields <= PG_RUN_TMP runs
+        // and every pass works on the LDS copy; with more runs the later passes re-evaluate chunk by
+        // chunk (skip = first run of the chunk).
+        //   pass 0  evaluate; decide whether the result is kept (close: any point; far: NewUPFarIsBetter)
+        //   pass 1  close end with > PG_RUN_TMP runs: fetch the last run
+        //   pass 2  close end: count the runs CleanUniquePoints keeps (pindel.cpp:2904-2941: points whose
+        //           implied read terminal equals the last point's = runs of the last run's candidate)
+        //   pass 3  write the (kept) runs to the pool
+        if (is_close || hits > 0) {
+            const RegionInfo R = { chr, chr_wo, origin, step == 4 ? bd : nullptr };
+            const u32 *tmp32 = (const u32 *)runs_tmp;
+            int n = 0, mx = 0, kept = 0, wr = 0, pass = 0, skip = 0;
+            u32 base = 0, last0 = 0, last1 = 0, last2 = 0;
+            bool fits = true;
+            for (;;) {
+                if (pass == 0 || n > PG_RUN_TMP) {
+                    int mm;
+                    int nn = evaluate<NB, Cell>(ref, prm, S, Q, R, runs_tmp, skip, PG_RUN_TMP, mm, lane);
+                    if (pass == 0) { n = uni(nn); mx = uni(mm); }
+                    PT_MARK(2)
+                }
+                if (pass == 0) {
+                    if (is_close) {
+                        close_max = mx;
+                        if (n == 0) break;
+                        if (n > PG_RUN_TMP) { pass = 1; skip = ((n - 1) / PG_RUN_TMP) * PG_RUN_TMP; }
+                        else pass = 2;
+                    } else {
+                        if (mx < far_max) break;              // the earlier UP_Far stays
+                        far_max = mx;
+                        n_far = n;
+                        far_base = 0;
+                        if (n == 0) break;
+                        base = (u32)uni((int)pool_alloc(B, n, lane, fits));
+                        far_base = base;
+                        pass = 3;
+                    }
+                    continue;
+                }
+                if (pass == 1 || (pass == 2 && skip == 0 && n <= PG_RUN_TMP)) {
+                    const int li = (n - 1) - (pass == 1 ? skip : 0);
+                    last0 = tmp32[3 * li];
+                    last1 = tmp32[3 * li + 1];
+                    last2 = tmp32[3 * li + 2];
+                    if (pass == 1) { pass = 2; skip = 0; continue; }
+                }
+                // one chunk of runs, one run per lane
+                const int cn = n - skip < PG_RUN_TMP ? n - skip : PG_RUN_TMP;
+                u32 r0 = 0, r1 = 0, r2 = 0;
+                bool keep = lane < cn;
+                if (keep) {
+                    r0 = tmp32[3 * lane];
+                    r1 = tmp32[3 * lane + 1];
+                    r2 = tmp32[3 * lane + 2];
+                    if (is_close) {
+                        const bool back = (r2 >> 8) & PG_RUN_BACKWARD, lback = (last2 >> 8) & PG_RUN_BACKWARD;
+                        const u32 term = back ? r0 + (r1 & 0xffffu) : r0 - (r1 & 0xffffu);
+                        const u32 lterm = lback ? last0 + (last1 & 0xffffu) : last0 - (last1 & 0xffffu);
+                        keep = term == lterm && (r2 >> 8) == (last2 >> 8);   // same flags and chromosome
+                    }
+                }
+                const u64 km = ballot64(keep);
+                if (pass == 2) {
+                    kept += __popcll(km);
+                    skip += PG_RUN_TMP;
+                    if (skip >= n) {
+                        base = (u32)uni((int)pool_alloc(B, kept, lane, fits));
+                        pass = 3;
+                        skip = 0;
+                    }
+                    continue;
+                }
+                // pass 3
+                if (keep && fits) {
+                    u32 *dst = (u32 *)(B.pool + base + wr + __popcll(km & low_bits(lane)));
+                    dst[0] = r0; dst[1] = r1; dst[2] = r2;
+                }
+                wr += __popcll(km);
+                skip += PG_RUN_TMP;
+                if (skip >= n) break;
+            }
+            PT_MARK(3)
+            if (is_close && n > 0) {
+                n_close = kept;
+                close_base = base;
+                const u32 sp = (last1 >> 16) - (last1 & 0xffffu);
+                close_last = ((last2 >> 8) & PG_RUN_BACKWARD) ? last0 - sp : last0 + sp;
+            }
+        }
+        // ---------------- next step
+        if (is_close) {
+            if (n_close > 0 || step == 3) step = 4;          // found, or all four attempts failed
+            else step++;
+        } else {
+            if (far_max + close_max >= len) break;           // goodFarEndFound (pindel.cpp:480-483)
+            step++;
+        }
+    }
+    if (do_close && n_close == 0) { flipped = 0; close_max = 0; }   // back to the original orientation
+
+    if (do_close) {
+        alg += 0.375f * (close_bases + 2.f * len) + 12.0f * (float)n_close;
+        if (lane == 0) {
+            B.rc_flag[rid] = (uint8_t)flipped;
+            B.close_last_abs[rid] = close_last;
+            B.close_max_len[rid] = (uint16_t)close_max;
+            B.close_run_off[rid] = close_base;
+            B.close_run_cnt[rid] = (u32)n_close;
+        }
+    }
+    if (do_far) {
+        if (far_ready) far_bases += (float)reach + 2.f * len;
+        alg += 0.375f * far_bases + 12.0f * (float)n_far;
+        if (lane == 0) { B.far_run_off[rid] = far_base; B.far_run_cnt[rid] = (u32)n_far; }
+    }
+#ifdef PG_PHASE_TIMING
+    PT_MARK(6)
+    if (B.alg_bytes && lane == 0 && rid < 65536) {      // overwrites the alg-bytes of the first reads
+        u32 *d = B.alg_bytes + (size_t)B.n_reads - 65536 * 16 + (size_t)rid * 16 + (do_close ? 0 : 8);
+        for (int k = 0; k < 8; k++) d[k] = (u32)pt_acc[k];
+    }
+    return;
+#endif
+    if (B.alg_bytes && lane == 0) {
+        if (do_close) B.alg_bytes[rid] = (u32)(alg + 0.5f);
+        else B.alg_bytes[rid] += (u32)(alg + 0.5f);        // the far-end launch adds to the close-end launch
+    }
 }
 
 // ---------------------------------------------------------------------------------
+template <int NB, typename Cell>
+static void launch(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch *batch, int mode,
+                   uint32_t max_len, uint32_t levels, hipStream_t st, unsigned lds_pad)
+{
+    PgLdsLayout lay = pg_lds_layout(max_len, levels, NB, (uint32_t)sizeof(Cell));
+    dim3 grid(batch->n_reads), block(WAVE);
+    // close end and far end are separate launches (the reference's two seams); each kernel only
+    // carries the state of its own phase, which keeps the register count down
+    if (mode & PG_MODE_CLOSE)
+        hipLaunchKernelGGL((pg_search_kernel<NB, Cell, PG_MODE_CLOSE>), grid, block, lay.total + lds_pad, st,
+                           *ref, *prm, *batch, max_len, levels);
+    if (mode & PG_MODE_FAR)
+        hipLaunchKernelGGL((pg_search_kernel<NB, Cell, PG_MODE_FAR>), grid, block, lay.total + lds_pad, st,
+                           *ref, *prm, *batch, max_len, levels);
+}
+
+// Debug/diagnostics: resident workgroups per CU the runtime predicts for the close/far kernels.
+extern "C" int pg_debug_occupancy(uint32_t max_len, uint32_t levels, int small_cells, int *close_blocks,
+                                  int *far_blocks, unsigned *lds_bytes)
+{
+    const int nb = max_len <= 128 ? 2 : (max_len <= 256 ? 4 : 8);
+    PgLdsLayout lay = pg_lds_layout(max_len, levels, nb, small_cells ? 4u : 8u);
+    *lds_bytes = lay.total;
+    hipError_t e1, e2;
+    if (small_cells && nb == 2) {
+        e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(close_blocks, pg_search_kernel<2, u32, PG_MODE_CLOSE>, WAVE, lay.total);
+        e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(far_blocks, pg_search_kernel<2, u32, PG_MODE_FAR>, WAVE, lay.total);
+    } else {
+        e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(close_blocks, pg_search_kernel<2, u64, PG_MODE_CLOSE>, WAVE, lay.total);
+        e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(far_blocks, pg_search_kernel<2, u64, PG_MODE_FAR>, WAVE, lay.total);
+    }
+    return (int)e1 | (int)e2;
+}
+
 extern "C" int pg_launch_search(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch *batch,
-                                int mode, uint32_t max_len, uint32_t levels, void *stream)
+                                int mode, uint32_t max_len, uint32_t levels, int small_cells, void *stream)
 {
     if (batch->n_reads == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(batch->n_reads), block(WAVE);
-    if (max_len <= 128) {
-        PgLdsLayout lay = pg_lds_layout(max_len, levels, 2);
-        hipLaunchKernelGGL(pg_search_kernel<2>, grid, block, lay.total, st, *ref, *prm, *batch, mode,
-                           max_len, levels);
-    } else if (max_len <= 256) {
-        PgLdsLayout lay = pg_lds_layout(max_len, levels, 4);
-        hipLaunchKernelGGL(pg_search_kernel<4>, grid, block, lay.total, st, *ref, *prm, *batch, mode,
-                           max_len, levels);
+    // experiment knob: extra dynamic LDS per workgroup (lowers occupancy), bytes
+    static const unsigned lds_pad = getenv("PG_LDS_PAD") ? (unsigned)atoi(getenv("PG_LDS_PAD")) : 0u;
+    const int nb = max_len <= 128 ? 2 : (max_len <= 256 ? 4 : 8);
+    if (small_cells) {
+        if (nb == 2) launch<2, u32>(ref, prm, batch, mode, max_len, levels, st, lds_pad);
+        else if (nb == 4) launch<4, u32>(ref, prm, batch, mode, max_len, levels, st, lds_pad);
+        else launch<8, u32>(ref, prm, batch, mode, max_len, levels, st, lds_pad);
     } else {
-        PgLdsLayout lay = pg_lds_layout(max_len, levels, 8);
-        hipLaunchKernelGGL(pg_search_kernel<8>, grid, block, lay.total, st, *ref, *prm, *batch, mode,
-                           max_len, levels);
+        if (nb == 2) launch<2, u64>(ref, prm, batch, mode, max_len, levels, st, lds_pad);
+        else if (nb == 4) launch<4, u64>(ref, prm, batch, mode, max_len, levels, st, lds_pad);
+        else launch<8, u64>(ref, prm, batch, mode, max_len, levels, st, lds_pad);
     }
     return (int)hipGetLastError();
 }
