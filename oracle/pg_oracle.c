@@ -583,6 +583,9 @@ int orc_search_batch(const orc_params *P, int n_chr, const char *const *chr_seq,
         memset(&ra, 0, sizeof ra);
         memset(&rb, 0, sizeof rb);
         orc_point *tmp = (orc_point *)malloc((size_t)stride * sizeof(orc_point));
+        /* close_pts / far_pts may be NULL (timing runs): points then go to per-thread scratch */
+        orc_point *scratch_c = (orc_point *)malloc((size_t)stride * sizeof(orc_point));
+        orc_point *scratch_f = (orc_point *)malloc((size_t)stride * sizeof(orc_point));
         #pragma omp for schedule(dynamic, 64)
         for (int64_t i = 0; i < (int64_t)n_reads; i++) {
             int len = (int)(seq_off[i + 1] - seq_off[i]);
@@ -593,7 +596,7 @@ int orc_search_batch(const orc_params *P, int n_chr, const char *const *chr_seq,
             char *s = seq + seq_off[i];
             int cid = chr_id[i];
             int flip = 0;
-            orc_point *cp = close_pts + (size_t)i * stride;
+            orc_point *cp = close_pts ? close_pts + (size_t)i * stride : scratch_c;
             int nc = close_end_ws(P, chr_seq[cid], cid, s, len, anchor_strand[i], anchor_pos[i],
                                   insert_size[i], 1, &a, &b, cp, (int)stride, &flip);
             close_cnt[i] = (uint32_t)nc;
@@ -605,11 +608,13 @@ int orc_search_batch(const orc_params *P, int n_chr, const char *const *chr_seq,
                 if (bd && bd_off) { w = bd + bd_off[i]; nw = (int)(bd_off[i + 1] - bd_off[i]); }
                 int nf = far_end_ws(P, n_chr, chr_seq, chr_len, cid, s, len,
                                     cp[nc - 1].abs_loc, cp[nc - 1].length, w, nw, &ra, &rb,
-                                    far_pts + (size_t)i * stride, tmp, (int)stride);
+                                    far_pts ? far_pts + (size_t)i * stride : scratch_f, tmp, (int)stride);
                 far_cnt[i] = (uint32_t)nf;
             }
         }
         free(tmp);
+        free(scratch_c);
+        free(scratch_f);
         levels_free(&a);
         levels_free(&b);
         region_set_free(&ra);

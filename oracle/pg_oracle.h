@@ -95,7 +95,7 @@ int orc_far_end(const orc_params *p,
  * Reads are given as a flat SoA.  seq is modified in place for reads that end
  * up reverse-complemented.  Results are strided: read i's UP_Close points are
  * close_pts[i*stride .. i*stride+close_cnt[i]) (likewise far); stride must be
- * >= the longest read.  bd/bd_off (per-read BD-hint clusters, CSR, n+1
+ * >= the longest read.  close_pts / far_pts may be NULL (counts only; used when timing).  bd/bd_off (per-read BD-hint clusters, CSR, n+1
  * offsets) may be NULL.  Returns 0 or a negative error.
  */
 int orc_search_batch(const orc_params *p,

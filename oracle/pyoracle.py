@@ -88,7 +88,7 @@ def max_mismatch_table(seq_error_rate=0.01, sensitivity=0.95) -> np.ndarray:
 
 def search_batch(params: OrcParams, chr_seqs, seq: np.ndarray, seq_off: np.ndarray,
                  anchor_strand: np.ndarray, anchor_pos: np.ndarray, insert_size: np.ndarray,
-                 chr_id: np.ndarray, bd=None, bd_off=None, do_far=True, n_threads=0):
+                 chr_id: np.ndarray, bd=None, bd_off=None, do_far=True, n_threads=0, keep_points=True):
     """Run close end (+ far end) for a batch.
 
     chr_seqs: list of spacer-padded chromosome strings (bytes).
@@ -111,8 +111,8 @@ def search_batch(params: OrcParams, chr_seqs, seq: np.ndarray, seq_off: np.ndarr
     chr_len = (C.c_uint64 * n_chr)(*[len(s) for s in chr_seqs])
     close_cnt = np.zeros(n, dtype=np.uint32)
     far_cnt = np.zeros(n, dtype=np.uint32)
-    close_pts = np.zeros(n * stride, dtype=POINT_DTYPE)
-    far_pts = np.zeros(n * stride, dtype=POINT_DTYPE)
+    close_pts = np.zeros(n * stride if keep_points else 0, dtype=POINT_DTYPE)
+    far_pts = np.zeros(n * stride if keep_points else 0, dtype=POINT_DTYPE)
     rc_flag = np.zeros(n, dtype=np.uint8)
     bd_p = bd_off_p = None
     if bd is not None:
@@ -123,10 +123,12 @@ def search_batch(params: OrcParams, chr_seqs, seq: np.ndarray, seq_off: np.ndarr
         C.byref(params), n_chr, chr_arr, chr_len, n, seq.ctypes.data, seq_off.ctypes.data,
         anchor_strand.ctypes.data, anchor_pos.ctypes.data, insert_size.ctypes.data,
         chr_id.ctypes.data, bd_p, bd_off_p, 1 if do_far else 0, stride,
-        close_cnt.ctypes.data, close_pts.ctypes.data, far_cnt.ctypes.data, far_pts.ctypes.data,
-        rc_flag.ctypes.data, n_threads)
+        close_cnt.ctypes.data, close_pts.ctypes.data if keep_points else None, far_cnt.ctypes.data,
+        far_pts.ctypes.data if keep_points else None, rc_flag.ctypes.data, n_threads)
     if rc != 0:
         raise RuntimeError(f"orc_search_batch failed: {rc}")
+    if not keep_points:
+        return dict(seq=seq, rc_flag=rc_flag, close_cnt=close_cnt, far_cnt=far_cnt, stride=stride)
     return dict(seq=seq, rc_flag=rc_flag, close_cnt=close_cnt,
                 close_pts=close_pts.reshape(n, stride) if n else close_pts,
                 far_cnt=far_cnt, far_pts=far_pts.reshape(n, stride) if n else far_pts,

@@ -101,8 +101,8 @@ PgLdsLayout pg_lds_layout(uint32_t max_len, uint32_t levels, uint32_t nb, uint32
     l.hist_off = 0;
     l.carry_off = (l.hist_off + l.levels * l.lh * cell + 15u) & ~15u;        // ginit[16] + carry[16]
     l.pref_off = l.carry_off + 2u * PG_MAX_LEVELS * cell;           // pref[levels][64]
-    l.queue_off = l.pref_off + l.levels * 64u * cell;                // queue[128]
-    l.win_off = (l.queue_off + 128u * 4u + 15u) & ~15u;              // window (stays valid during evaluate)
+    l.queue_off = l.pref_off + l.levels * 64u * cell;                // queue[192]
+    l.win_off = (l.queue_off + 192u * 4u + 15u) & ~15u;              // window (stays valid during evaluate)
     // chunk + overhang of nb 64-base blocks on both sides + alignment slack
     l.win_words = (PG_CHUNK + 2u * (64u * nb)) / 32u + 6u;
     l.runs_off = (l.win_off + l.win_words * 16u + 15u) & ~15u;

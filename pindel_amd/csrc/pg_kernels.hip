@@ -57,11 +57,53 @@ typedef unsigned int u32;
 #define PT_DECL
 #define PT_MARK(k)
 #endif
+#ifndef PG_PF
+#define PG_PF 1      // prefilter rounds (64 positions each) per loop iteration
+#endif
 #ifndef PG_WAVES_PER_EU
 #define PG_WAVES_PER_EU 4   // register budget the kernel is compiled for (waves per SIMD)
 #endif
 
 __device__ __forceinline__ u64 ballot64(bool p) { return __ballot(p); }
+// DPP lane shifts (no LDS round trip).  row_shr:n moves lane i-n -> i inside each 16-lane row and
+// yields 0 where i-n leaves the row; wave_shr:1 moves lane i-1 -> i across the whole wave.
+template <int N>
+__device__ __forceinline__ u32 row_shr(u32 v)
+{
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + N, 0xf, 0xf, true);
+}
+__device__ __forceinline__ u32 wave_shr1(u32 v)
+{
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);
+}
+template <int N>
+__device__ __forceinline__ u64 row_shr(u64 v)
+{
+    return (u64)row_shr<N>((u32)v) | ((u64)row_shr<N>((u32)(v >> 32)) << 32);
+}
+__device__ __forceinline__ u64 wave_shr1(u64 v)
+{
+    return (u64)wave_shr1((u32)v) | ((u64)wave_shr1((u32)(v >> 32)) << 32);
+}
+// inclusive prefix sum inside aligned groups of G lanes (G = 4, 8 or 16); c = lane % G
+template <typename C>
+__device__ __forceinline__ C group_scan(C v, int c, int G)
+{
+    C t = row_shr<1>(v);
+    if (c >= 1) v += t;
+    t = row_shr<2>(v);
+    if (c >= 2) v += t;
+    if (G > 4) {
+        t = row_shr<4>(v);
+        if (c >= 4) v += t;
+    }
+    if (G > 8) {
+        t = row_shr<8>(v);
+        if (c >= 8) v += t;
+    }
+    return v;
+}
+
 // tells the compiler a value is wave-uniform (keeps it in SGPRs)
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ u64 low_bits(int n)            // n in [0,64]
@@ -124,7 +166,7 @@ struct Search {
     Cell *ginit;   // [PG_MAX_LEVELS] candidates entering at level k (at L = bps)
     Cell *carry;   // [PG_MAX_LEVELS] running prefix per level during evaluate
     Cell *pref;    // [T][64] absolute G of the current 64-length round (aliases win/queue)
-    u32 *queue;    // [128] compacted survivors of the prefilter
+    u32 *queue;    // [192] compacted survivors of the prefilter
     uint4 *win;    // staged window
     // what the LDS window currently holds: bases [win_lo, win_hi) of the chromosome whose AbsLoc 0 is
     // at word index win_wo; the first staged base is wbase (a multiple of 32)
@@ -281,44 +323,61 @@ __device__ __forceinline__ u32 scan_range(const PgDevRef &ref, Search<Cell> &S, 
             stage_window<NB, Cell>(ref, S, wo, cs - 64 * NB, ce + 64 * NB, lane);
         const int wbase = S.wbase;
         int qn = 0;     // queued survivors (uniform)
-        for (int base = cs; base < ce; base += WAVE) {
-            const int p = base + lane;
-            bool surv = false, isB = false, seed = false;
-            const u32 rel = (u32)(p - wbase);
-            if (p < ce) {
-                // ---- prefilter: first 32 consumed bases of the candidate at p
-                u32 wi = rel >> 5, sh = rel & 31u;
-                uint4 wm = S.win[wi - 1], wc = S.win[wi], wp = S.win[wi + 1];
-                u32 bl = (wc.x >> sh) & 1u, bh = (wc.y >> sh) & 1u, bn = (wc.z >> sh) & 1u;
-                u32 xl = bl ^ (q0lo & 1u), xh = bh ^ (q0hi & 1u);
-                bool seedF = Q.allowF && !bn && xl == (u32)Q.cF && xh == (u32)Q.cF;
-                bool seedB = Q.allowB && !bn && xl == (u32)Q.cB && xh == (u32)Q.cB;
-                seed = seedF || seedB;
-                isB = seedB;
+        for (int base = cs; base < ce; base += PG_PF * WAVE) {
+            // ---- prefilter, two 64-position rounds per iteration, no branches: the first 32 consumed
+            // bases of the candidate at p decide "seed" and "still alive at the first reportable length"
+            bool surv[2] = {false, false}, seedv[2] = {false, false}, isBv[2] = {false, false};
+            u32 relv[2] = {0u, 0u};
+#pragma unroll
+            for (int h = 0; h < PG_PF; h++) {
+                const int pp = base + 64 * h + lane;
+                const bool act = pp < ce;
+                const int p = act ? pp : ce - 1;
+                const u32 rel = (u32)(p - wbase);
+                const u32 wi = rel >> 5, sh = rel & 31u;
+                const uint4 wm = S.win[wi - 1], wc = S.win[wi], wp = S.win[wi + 1];
+                const u32 bl = (wc.x >> sh) & 1u, bh = (wc.y >> sh) & 1u, bn = (wc.z >> sh) & 1u;
+                const u32 xl = bl ^ (q0lo & 1u), xh = bh ^ (q0hi & 1u);
+                const bool seedF = Q.allowF && !bn && xl == (u32)Q.cF && xh == (u32)Q.cF;
+                const bool seedB = Q.allowB && !bn && xl == (u32)Q.cB && xh == (u32)Q.cB;
+                const bool isB = seedB;
                 // forward: bits [p, p+32); backward: bits [p-31, p] reversed
-                u32 s2 = sh + (isB ? 1u : 0u);
+                const u32 s2 = sh + (isB ? 1u : 0u);
                 u32 rlo = (u32)((((u64)(isB ? wc.x : wp.x) << 32) | (isB ? wm.x : wc.x)) >> s2);
                 u32 rhi = (u32)((((u64)(isB ? wc.y : wp.y) << 32) | (isB ? wm.y : wc.y)) >> s2);
                 u32 rnn = (u32)((((u64)(isB ? wc.z : wp.z) << 32) | (isB ? wm.z : wc.z)) >> s2);
-                if (isB) { rlo = __brev(rlo); rhi = __brev(rhi); rnn = __brev(rnn); }
-                u32 cm = (isB ? Q.cB : Q.cF) ? 0xffffffffu : 0u;
-                u32 d = (rlo ^ q0lo ^ cm) | (rhi ^ q0hi ^ cm);
-                u32 mis = (d & ~q0nn) | rnn | q0oo;
-                surv = seed && (S.bps > 32 || __popc(mis & pre_mask) < S.T);
+                const u32 blo = __brev(rlo), bhi2 = __brev(rhi), bnn = __brev(rnn);
+                rlo = isB ? blo : rlo;
+                rhi = isB ? bhi2 : rhi;
+                rnn = isB ? bnn : rnn;
+                const u32 cm = (isB ? Q.cB : Q.cF) ? 0xffffffffu : 0u;
+                const u32 d = (rlo ^ q0lo ^ cm) | (rhi ^ q0hi ^ cm);
+                const u32 mis = (d & ~q0nn) | rnn | q0oo;
+                seedv[h] = act && (seedF || seedB);
+                surv[h] = seedv[h] && (S.bps > 32 || __popc(mis & pre_mask) < S.T);
+                isBv[h] = isB;
+                relv[h] = rel;
             }
-            hits += (u32)__popcll(ballot64(seed));
-            const u64 sm = ballot64(surv);
-            if (sm) {
-                if (surv) S.queue[qn + __popcll(sm & low_bits(lane))] = (rel << 1) | (isB ? 1u : 0u);
-                qn += __popcll(sm);
-                if (qn >= WAVE) {
+            const u64 sd0 = ballot64(seedv[0]), sd1 = ballot64(seedv[1]);
+            hits += (u32)(__popcll(sd0) + __popcll(sd1));
+            const u64 sm0 = ballot64(surv[0]), sm1 = ballot64(surv[1]);
+            if (sm0 | sm1) {
+                const int n0 = __popcll(sm0);
+                if (surv[0]) S.queue[qn + __popcll(sm0 & low_bits(lane))] = (relv[0] << 1) | (isBv[0] ? 1u : 0u);
+                if (surv[1]) S.queue[qn + n0 + __popcll(sm1 & low_bits(lane))] = (relv[1] << 1) | (isBv[1] ? 1u : 0u);
+                qn += n0 + __popcll(sm1);
+                while (qn >= WAVE) {
                     __syncthreads();
                     dense_pass<NB, Cell>(S, Q, wbase, origin, region, WAVE, lane);
                     __syncthreads();
-                    u32 moved = (lane < qn - WAVE) ? S.queue[WAVE + lane] : 0u;
+                    // move the remainder (< 128 entries) to the front
+                    const int rem = qn - WAVE;
+                    u32 m0 = (lane < rem) ? S.queue[WAVE + lane] : 0u;
+                    u32 m1 = (WAVE + lane < rem) ? S.queue[2 * WAVE + lane] : 0u;
                     __syncthreads();
-                    if (lane < qn - WAVE) S.queue[lane] = moved;
-                    qn -= WAVE;
+                    if (lane < rem) S.queue[lane] = m0;
+                    if (WAVE + lane < rem) S.queue[WAVE + lane] = m1;
+                    qn = rem;
                 }
             }
         }
@@ -356,18 +415,15 @@ __device__ __forceinline__ int evaluate(const PgDevRef &ref, const PgDevParams &
     __syncthreads();
     {
         Cell g = lane < S.T ? S.ginit[lane] : (Cell)0;
-#pragma unroll
-        for (int d = 1; d < PG_MAX_LEVELS; d <<= 1) {
-            Cell t = __shfl_up(g, d, WAVE);
-            if (lane >= d) g += t;
-        }
+        g = group_scan<Cell>(g, lane & 15, 16);
         if (lane < S.T) S.carry[lane] = g;
     }
     __syncthreads();
-    // lanes as (level, chunk) for the prefix over L
-    const int CPL = WAVE / S.T;                  // chunks per level
-    const int CS = (WAVE + CPL - 1) / CPL;       // cells per chunk
-    const int pk = lane / CPL, pc = lane - pk * CPL;
+    // lanes as (level, chunk) for the prefix over L: 8 chunks of 8 cells per level (T <= 8), else
+    // 4 chunks of 16 cells; a level's lanes sit inside one 16-lane row so the scan is pure DPP
+    const int CPL = S.T <= 8 ? 8 : 4;            // chunks per level
+    const int CS = WAVE / CPL;                   // cells per chunk
+    const int pk = lane / CPL, pc = lane & (CPL - 1);
     const bool pact = pk < S.T;
     bool aborted = false;
     for (int r0 = S.bps; r0 <= S.len - 1 && !aborted; r0 += WAVE) {
@@ -379,11 +435,7 @@ __device__ __forceinline__ int evaluate(const PgDevRef &ref, const PgDevParams &
             if (pact)
                 for (int j = j0; j < j1; j++)
                     if (r0 + j <= S.len - 1) tot += row[j];
-            Cell inc = tot;
-            for (int d = 1; d < CPL; d <<= 1) {
-                Cell t = __shfl_up(inc, d, WAVE);
-                if (pc >= d) inc += t;
-            }
+            const Cell inc = group_scan<Cell>(tot, pc, CPL);
             Cell acc = pact ? (Cell)(S.carry[pk] + inc - tot) : (Cell)0;
             if (pact)
                 for (int j = j0; j < j1; j++) {
@@ -456,8 +508,7 @@ __device__ __forceinline__ int evaluate(const PgDevRef &ref, const PgDevParams &
         }
         // ---- run-length encode consecutive points of the same candidate / level
         const u64 key = cand ? ((id_lo << 8) | (u64)(lo + 1)) : 0ull;
-        u64 prev_key = __shfl_up(key, 1, WAVE);
-        if (lane == 0) prev_key = 0ull;        // runs never span two 64-length rounds
+        const u64 prev_key = wave_shr1(key);   // lane 0 gets 0: runs never span two 64-length rounds
         const bool start = cand && key != prev_key;
         const u64 starts = ballot64(start);
         const u64 brk = ballot64(start || !cand);
@@ -872,14 +923,35 @@ static void launch(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch
 {
     PgLdsLayout lay = pg_lds_layout(max_len, levels, NB, (uint32_t)sizeof(Cell));
     dim3 grid(batch->n_reads), block(WAVE);
-    // close end and far end are separate launches (the reference's two seams); each kernel only
-    // carries the state of its own phase, which keeps the register count down
+    // close end + far end in one launch; PG_SPLIT_LAUNCH=1 runs the two seams as separate launches
+    static const bool fused = getenv("PG_SPLIT_LAUNCH") == nullptr;
+    if (mode == PG_MODE_BOTH && fused) {
+        hipLaunchKernelGGL((pg_search_kernel<NB, Cell, PG_MODE_BOTH>), grid, block, lay.total + lds_pad, st,
+                           *ref, *prm, *batch, max_len, levels);
+        return;
+    }
     if (mode & PG_MODE_CLOSE)
         hipLaunchKernelGGL((pg_search_kernel<NB, Cell, PG_MODE_CLOSE>), grid, block, lay.total + lds_pad, st,
                            *ref, *prm, *batch, max_len, levels);
     if (mode & PG_MODE_FAR)
         hipLaunchKernelGGL((pg_search_kernel<NB, Cell, PG_MODE_FAR>), grid, block, lay.total + lds_pad, st,
                            *ref, *prm, *batch, max_len, levels);
+}
+
+// Diagnostics: streams n dwords with the staging access pattern (one dword per lane, coalesced) so the
+// FETCH_SIZE counter can be calibrated against a known byte count (MI355X_MICROARCH.md, HBM section).
+__global__ void pg_calib_stream(const u32 *src, size_t n, u32 *sink)
+{
+    u32 acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        acc ^= src[i];
+    if (acc == 0x12345678u) *sink = acc;
+}
+
+extern "C" int pg_debug_calib_stream(const void *src, size_t n_dwords, void *sink)
+{
+    hipLaunchKernelGGL(pg_calib_stream, dim3(4096), dim3(256), 0, 0, (const u32 *)src, n_dwords, (u32 *)sink);
+    return (int)hipDeviceSynchronize();
 }
 
 // Debug/diagnostics: resident workgroups per CU the runtime predicts for the close/far kernels.
