@@ -48,6 +48,20 @@ def cpu_baseline(chroms, batch, params_kw, budget_s=12.0):
             "sample": f"first {n1} reads of the rank-0 batch, close+far end, OpenMP {cores} threads, {t1:.1f} s"}
 
 
+def measured_traffic(args):
+    """HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE with the gfx950
+    x2 correction + WRITE_SIZE, MI355X_MICROARCH.md).  PMC counters cannot be read from inside this
+    process, so the per-read figure measured with rocprofv3 on this same workload is scaled by the reads
+    of one launch; null for any other workload."""
+    path = os.path.join(ROOT, "profiles", "r01", "v3_hbm_traffic.json")
+    if args.read_len != 100 or args.max_range_index != 2 or not os.path.exists(path):
+        return None, None
+    with open(path) as fh:
+        t = json.load(fh)
+    per_read = t["fetch_bytes_per_read"] + t["write_bytes_per_read_uncalibrated"]
+    return per_read * args.reads, "profiles/r01/v3_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per read x reads per launch)"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,6 +131,7 @@ def main():
     if rank == 0:
         avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic, traffic_src = measured_traffic(args)
         out = {
             "metric": "one-end-anchored reads/sec through split-read search (close end + far end)",
             "value": world * args.reads * args.steps / elapsed,
@@ -141,7 +156,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "pg_search_kernel", "kernel_ms": avg_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
             },
