@@ -85,6 +85,13 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def use_library(path):
+    """Tests: bind a differently configured build of the library (call before the first use)."""
+    global _lib, LIB_PATH
+    _lib = None
+    LIB_PATH = path
+
+
 def lib():
     """Load the shared library (building it first if the sources are newer)."""
     global _lib

@@ -285,6 +285,7 @@ int upload_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_device_batch **out)
     AL(alg, n);
     AL(pool_used, PG_POOL_SHARDS * 16);
     b->pool_shard_cap = (uint32_t)std::min<uint64_t>((3ull * n) / PG_POOL_SHARDS + 96ull, 0x7fffffffull / PG_POOL_SHARDS);
+    if (getenv("PG_TEST_TINY_POOL")) b->pool_shard_cap = 1;      // tests: force the overflow/regrow path
     AL(pool, (size_t)b->pool_shard_cap * PG_POOL_SHARDS);
 #undef UP
 #undef AL

@@ -77,7 +77,9 @@ struct PgDevBatch {
 #define PG_MAX_LEVELS 16
 #define PG_MM_BREAKS 16
 #define PG_POOL_SHARDS 1024u
-#define PG_RUN_TMP 24            // runs of one search kept in LDS; more -> evaluated again into the pool
+#ifndef PG_RUN_TMP
+#define PG_RUN_TMP 24            // runs of one search kept in LDS; more -> evaluated again, chunk by chunk
+#endif
 
 // Dynamic LDS layout (bytes), computed identically on host and device.
 struct PgLdsLayout {

@@ -368,7 +368,9 @@ __device__ __forceinline__ u32 scan_range(const PgDevRef &ref, Search<Cell> &S, 
                 qn += n0 + __popcll(sm1);
                 while (qn >= WAVE) {
                     __syncthreads();
+#ifndef PG_ABL_NODENSE
                     dense_pass<NB, Cell>(S, Q, wbase, origin, region, WAVE, lane);
+#endif
                     __syncthreads();
                     // move the remainder (< 128 entries) to the front
                     const int rem = qn - WAVE;
@@ -383,7 +385,9 @@ __device__ __forceinline__ u32 scan_range(const PgDevRef &ref, Search<Cell> &S, 
         }
         if (qn > 0) {
             __syncthreads();
+#ifndef PG_ABL_NODENSE
             dense_pass<NB, Cell>(S, Q, wbase, origin, region, qn, lane);
+#endif
         }
     }
     __syncthreads();
@@ -765,6 +769,9 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
         if (zero) zero_hist(S, lane);
         PT_MARK(4)
         // ---------------- scan
+#ifdef PG_ABL_NOSCAN
+        nwin = 0;
+#endif
         for (int w = 0; w < nwin; w++) {
             long long wo = chr_wo;
             int s, e, org = origin;
@@ -804,7 +811,11 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
             for (;;) {
                 if (pass == 0 || n > PG_RUN_TMP) {
                     int mm;
+#ifdef PG_ABL_NOEVAL
+                    int nn = 0; mm = 0;
+#else
                     int nn = evaluate<NB, Cell>(ref, prm, S, Q, R, runs_tmp, skip, PG_RUN_TMP, mm, lane);
+#endif
                     if (pass == 0) { n = uni(nn); mx = uni(mm); }
                     PT_MARK(2)
                 }
@@ -924,7 +935,7 @@ static void launch(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch
     PgLdsLayout lay = pg_lds_layout(max_len, levels, NB, (uint32_t)sizeof(Cell));
     dim3 grid(batch->n_reads), block(WAVE);
     // close end + far end in one launch; PG_SPLIT_LAUNCH=1 runs the two seams as separate launches
-    static const bool fused = getenv("PG_SPLIT_LAUNCH") == nullptr;
+    const bool fused = getenv("PG_SPLIT_LAUNCH") == nullptr;
     if (mode == PG_MODE_BOTH && fused) {
         hipLaunchKernelGGL((pg_search_kernel<NB, Cell, PG_MODE_BOTH>), grid, block, lay.total + lds_pad, st,
                            *ref, *prm, *batch, max_len, levels);

@@ -175,3 +175,76 @@ def test_wide_ranges_streaming_windows(engine_factory, small_ref):
     gpu = eng.search_batch(batch)
     orc = run_oracle(dict(max_range_index=7), small_ref, batch)
     compare_result(gpu, orc, batch.n)
+
+
+def test_long_reads_and_wide_close_windows(engine_factory, small_ref):
+    """300-450 bp reads (8 blocks of 64 bases per read) and insert size 1200: the R=1 close-end
+    window (3 x InsertSize = 3600 bases) spans two LDS fills."""
+    eng = engine_factory()
+    eng.load_reference(small_ref)
+    batch = synth.make_reads(small_ref[0][1], 600, seed=13, read_lens=[300, 450], insert_size=1200)
+    gpu = eng.search_batch(batch)
+    orc = run_oracle({}, small_ref, batch)
+    assert (orc["far_cnt"] > 0).sum() > 100
+    compare_result(gpu, orc, batch.n)
+
+
+def test_pool_overflow_is_retried_on_the_gpu(engine_factory, small_ref, monkeypatch):
+    """A pool that is far too small makes the launch repeat with a regrown pool; results unchanged."""
+    eng = engine_factory()
+    eng.load_reference(small_ref)
+    batch = synth.make_reads(small_ref[0][1], 5000, seed=14)
+    orc = run_oracle({}, small_ref, batch)
+    monkeypatch.setenv("PG_TEST_TINY_POOL", "1")
+    gpu = eng.search_batch(batch)
+    compare_result(gpu, orc, batch.n)
+
+
+def test_wide_cells_and_split_launches(engine_factory, small_ref, monkeypatch):
+    """The 64-bit histogram cells and the two-launch form (close kernel, then far kernel) on a default
+    workload give the same result as the default (32-bit cells, one fused launch)."""
+    eng = engine_factory()
+    eng.load_reference(small_ref)
+    batch = synth.make_reads(small_ref[0][1], 3000, seed=15)
+    orc = run_oracle({}, small_ref, batch)
+    monkeypatch.setenv("PG_FORCE_WIDE_CELLS", "1")
+    compare_result(eng.search_batch(batch), orc, batch.n)
+    monkeypatch.delenv("PG_FORCE_WIDE_CELLS")
+    monkeypatch.setenv("PG_SPLIT_LAUNCH", "1")
+    compare_result(eng.search_batch(batch), orc, batch.n)
+
+
+def test_more_runs_than_the_lds_buffer(tmp_path, small_ref):
+    """Builds the library with a 2-run LDS buffer (PG_RUN_TMP=2) so that the chunked re-evaluation
+    path (close-end CleanUniquePoints over several chunks, far-end publish) is exercised."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "pindel_amd", "csrc")
+    out = str(tmp_path / "libpindel_pg_runtmp2.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950",
+                           "-I" + os.path.join(root, "include"), "-I" + src, "-DPG_RUN_TMP=2", "-shared",
+                           "-x", "hip", os.path.join(src, "pg_api.cpp"), os.path.join(src, "pg_kernels.hip"),
+                           "-o", out], stderr=subprocess.DEVNULL)
+    # a separate interpreter so that the differently configured library does not mix with the default one
+    code = f"""
+import sys
+sys.path.insert(0, {root!r})
+from pindel_amd import binding, synth
+binding.use_library({out!r})
+from tests.parity import compare_result, run_oracle
+ref = [("chrS", synth.make_reference(1_500_000, seed=11))]
+eng = binding.Engine()
+eng.load_reference(ref)
+batch = synth.make_reads(ref[0][1], 3000, seed=16, error_rate=0.03)
+gpu = eng.search_batch(batch)
+orc = run_oracle({{}}, ref, batch)
+import numpy as np
+multi = int(((gpu.close_off[1:] - gpu.close_off[:-1]) > 2).sum() + ((gpu.far_off[1:] - gpu.far_off[:-1]) > 2).sum())
+assert multi > 50, multi
+compare_result(gpu, orc, batch.n)
+print("ok", multi)
+"""
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert res.returncode == 0 and "ok" in res.stdout, res.stdout + res.stderr
