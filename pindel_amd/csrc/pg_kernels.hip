@@ -231,16 +231,18 @@ __device__ __forceinline__ void fetch_global(const PgDevRef &ref, long long wo, 
 // ---------------------------------------------------------------------------------
 // Dense pass over n (<= 64) queued candidates, one per lane: full mismatch pattern, level at
 // L = bps, then one histogram update per later mismatch until the candidate dies.
-template <int NB, typename Cell>
+// MIXED = both candidate kinds in one search (far end); otherwise the kind is wave-uniform (close end)
+// and the per-lane selects / bit reversals disappear.
+template <int NB, typename Cell, bool MIXED>
 __device__ __forceinline__ void dense_pass(const Search<Cell> &S, const Query<NB> &Q, int wbase,
                                            int origin, u32 region, int n, int lane)
 {
     bool alive = lane < n;
     int p = 0;
-    bool isB = false;
+    bool isB = MIXED ? false : Q.allowB;
     if (alive) {
         u32 e = S.queue[lane];
-        isB = e & 1u;
+        if (MIXED) isB = e & 1u;
         p = wbase + (int)(e >> 1);
     }
     const bool comp = isB ? Q.cB : Q.cF;
@@ -272,14 +274,18 @@ __device__ __forceinline__ void dense_pass(const Search<Cell> &S, const Query<NB
             blo = (u32)bits;
             bhi = (u32)(bits >> 32);
         }
-        while (__any(alive && (blo | bhi) != 0u)) {
-            if (alive && (blo | bhi) != 0u) {
-                int j;
-                if (blo) { j = __ffs((int)blo) - 1; blo &= blo - 1u; }
-                else { j = 32 + __ffs((int)bhi) - 1; bhi &= bhi - 1u; }
-                atomicAdd(&S.hist[cell + 64 * b + j + 1], neg);   // leaves its level at L = j+1
-                cell += S.lh;
-                if (cell >= cell_end) alive = false;
+        // one histogram update per mismatch, low word first; selects instead of branches
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            u32 w = half ? bhi : blo;
+            const int lbase = 64 * b + 32 * half + 1;
+            while (__any(alive && w != 0u)) {
+                const bool act = alive && w != 0u;
+                const int j = __ffs((int)w) - 1;
+                w &= w - 1u;
+                if (act) atomicAdd(&S.hist[cell + lbase + j], neg);   // leaves its level at L = 64b+j+1
+                cell += act ? S.lh : 0;
+                alive = alive && cell < cell_end;
             }
         }
     }
@@ -307,9 +313,9 @@ __device__ __forceinline__ void stage_window(const PgDevRef &ref, Search<Cell> &
 
 // Scan window positions [s, e) of a chromosome (wo = word index of its AbsLoc 0).
 // Returns the number of seeds (NumberOfHits, farend_searcher.cpp:83).
-template <int NB, typename Cell>
-__device__ __forceinline__ u32 scan_range(const PgDevRef &ref, Search<Cell> &S, const Query<NB> &Q,
-                                          long long wo, int s, int e, int origin, u32 region, int lane)
+template <int NB, typename Cell, bool MIXED>
+__device__ __forceinline__ u32 scan_impl(const PgDevRef &ref, Search<Cell> &S, const Query<NB> &Q,
+                                         long long wo, int s, int e, int origin, u32 region, int lane)
 {
     u32 hits = 0;
     if (!Q.first_ok) return 0;
@@ -340,16 +346,27 @@ __device__ __forceinline__ u32 scan_range(const PgDevRef &ref, Search<Cell> &S, 
                 const u32 xl = bl ^ (q0lo & 1u), xh = bh ^ (q0hi & 1u);
                 const bool seedF = Q.allowF && !bn && xl == (u32)Q.cF && xh == (u32)Q.cF;
                 const bool seedB = Q.allowB && !bn && xl == (u32)Q.cB && xh == (u32)Q.cB;
-                const bool isB = seedB;
+                const bool isB = MIXED ? seedB : Q.allowB;
                 // forward: bits [p, p+32); backward: bits [p-31, p] reversed
-                const u32 s2 = sh + (isB ? 1u : 0u);
-                u32 rlo = (u32)((((u64)(isB ? wc.x : wp.x) << 32) | (isB ? wm.x : wc.x)) >> s2);
-                u32 rhi = (u32)((((u64)(isB ? wc.y : wp.y) << 32) | (isB ? wm.y : wc.y)) >> s2);
-                u32 rnn = (u32)((((u64)(isB ? wc.z : wp.z) << 32) | (isB ? wm.z : wc.z)) >> s2);
-                const u32 blo = __brev(rlo), bhi2 = __brev(rhi), bnn = __brev(rnn);
-                rlo = isB ? blo : rlo;
-                rhi = isB ? bhi2 : rhi;
-                rnn = isB ? bnn : rnn;
+                u32 rlo, rhi, rnn;
+                if (MIXED) {
+                    const u32 s2 = sh + (isB ? 1u : 0u);
+                    rlo = (u32)((((u64)(isB ? wc.x : wp.x) << 32) | (isB ? wm.x : wc.x)) >> s2);
+                    rhi = (u32)((((u64)(isB ? wc.y : wp.y) << 32) | (isB ? wm.y : wc.y)) >> s2);
+                    rnn = (u32)((((u64)(isB ? wc.z : wp.z) << 32) | (isB ? wm.z : wc.z)) >> s2);
+                    const u32 blo = __brev(rlo), bhi2 = __brev(rhi), bnn = __brev(rnn);
+                    rlo = isB ? blo : rlo;
+                    rhi = isB ? bhi2 : rhi;
+                    rnn = isB ? bnn : rnn;
+                } else if (Q.allowB) {          // wave-uniform kind: no selects
+                    rlo = __brev((u32)((((u64)wc.x << 32) | wm.x) >> (sh + 1u)));
+                    rhi = __brev((u32)((((u64)wc.y << 32) | wm.y) >> (sh + 1u)));
+                    rnn = __brev((u32)((((u64)wc.z << 32) | wm.z) >> (sh + 1u)));
+                } else {
+                    rlo = __builtin_amdgcn_alignbit(wp.x, wc.x, sh);
+                    rhi = __builtin_amdgcn_alignbit(wp.y, wc.y, sh);
+                    rnn = __builtin_amdgcn_alignbit(wp.z, wc.z, sh);
+                }
                 const u32 cm = (isB ? Q.cB : Q.cF) ? 0xffffffffu : 0u;
                 const u32 d = (rlo ^ q0lo ^ cm) | (rhi ^ q0hi ^ cm);
                 const u32 mis = (d & ~q0nn) | rnn | q0oo;
@@ -369,7 +386,7 @@ __device__ __forceinline__ u32 scan_range(const PgDevRef &ref, Search<Cell> &S, 
                 while (qn >= WAVE) {
                     __syncthreads();
 #ifndef PG_ABL_NODENSE
-                    dense_pass<NB, Cell>(S, Q, wbase, origin, region, WAVE, lane);
+                    dense_pass<NB, Cell, MIXED>(S, Q, wbase, origin, region, WAVE, lane);
 #endif
                     __syncthreads();
                     // move the remainder (< 128 entries) to the front
@@ -386,12 +403,20 @@ __device__ __forceinline__ u32 scan_range(const PgDevRef &ref, Search<Cell> &S, 
         if (qn > 0) {
             __syncthreads();
 #ifndef PG_ABL_NODENSE
-            dense_pass<NB, Cell>(S, Q, wbase, origin, region, qn, lane);
+            dense_pass<NB, Cell, MIXED>(S, Q, wbase, origin, region, qn, lane);
 #endif
         }
     }
     __syncthreads();
     return hits;
+}
+
+template <int NB, typename Cell>
+__device__ __forceinline__ u32 scan_range(const PgDevRef &ref, Search<Cell> &S, const Query<NB> &Q,
+                                          long long wo, int s, int e, int origin, u32 region, int lane)
+{
+    if (Q.allowF && Q.allowB) return scan_impl<NB, Cell, true>(ref, S, Q, wo, s, e, origin, region, lane);
+    return scan_impl<NB, Cell, false>(ref, S, Q, wo, s, e, origin, region, lane);
 }
 
 // ---------------------------------------------------------------------------------
@@ -641,6 +666,10 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
     Planes<NB> A, Ar;   // original orientation: forward and reversed consumption order
     load_planes<NB>(seq, len, lane, A, Ar);
     PT_MARK(0)
+#if defined(PG_STOP_AFTER) && PG_STOP_AFTER == 0
+    if (lane == 0) B.rc_flag[rid] = (uint8_t)(A.lo[0] ^ Ar.hi[0]);
+    return;
+#endif
 
     float alg = (mode & PG_MODE_CLOSE) ? (float)len : 0.f;   // the read itself is counted once
     int flipped = 0, close_max = 0, n_close = 0, n_far = 0, far_max = 0;
@@ -793,6 +822,10 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
             hits += scan_range<NB, Cell>(ref, S, Q, wo, s, e, org, region, lane);
         }
         PT_MARK(1)
+#if defined(PG_STOP_AFTER) && PG_STOP_AFTER == 1
+        if (lane == 0) B.rc_flag[rid] = (uint8_t)hits;
+        return;
+#endif
         // ---------------- evaluate (NumberOfHits == 0 leaves UP_Far untouched, farend_searcher.cpp:87)
         // One evaluate site inside a small pass machine.  Normally a search yields <= PG_RUN_TMP runs
         // and every pass works on the LDS copy; with more runs the later passes re-evaluate chunk by
@@ -818,6 +851,10 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
 #endif
                     if (pass == 0) { n = uni(nn); mx = uni(mm); }
                     PT_MARK(2)
+#if defined(PG_STOP_AFTER) && PG_STOP_AFTER == 2
+                    if (lane == 0) B.rc_flag[rid] = (uint8_t)(n + mx);
+                    return;
+#endif
                 }
                 if (pass == 0) {
                     if (is_close) {
