@@ -313,15 +313,30 @@ __device__ __forceinline__ void stage_window(const PgDevRef &ref, Search<Cell> &
 
 // Scan window positions [s, e) of a chromosome (wo = word index of its AbsLoc 0).
 // Returns the number of seeds (NumberOfHits, farend_searcher.cpp:83).
+// Scan of one window.  PREFILTER: lane = window position p; the first 32 consumed bases of the candidate
+// at p (one funnel extract per plane) decide "seed" and "can still matter at the first reportable
+// length"; survivors are compacted into the LDS queue and go through dense_pass 64 at a time.
 template <int NB, typename Cell, bool MIXED>
-__device__ __forceinline__ u32 scan_impl(const PgDevRef &ref, Search<Cell> &S, const Query<NB> &Q,
-                                         long long wo, int s, int e, int origin, u32 region, int lane)
+__device__ __forceinline__ u32 scan_impl32(const PgDevRef &ref, const PgDevParams &prm, Search<Cell> &S,
+                                           const Query<NB> &Q, long long wo, int s, int e, int origin, u32 region,
+                                           int lane)
 {
     u32 hits = 0;
     if (!Q.first_ok) return 0;
     const Planes<NB> &qp = Q.use_rv ? *Q.rv : *Q.fw;
     const u32 q0lo = (u32)qp.lo[0], q0hi = (u32)qp.hi[0], q0nn = (u32)qp.nn[0], q0oo = (u32)qp.oo[0];
     const u32 pre_mask = S.bps >= 32 ? 0xffffffffu : ((1u << S.bps) - 1u);
+    // Which seeds matter (exact, DESIGN.md "relevance"): a candidate at level k at length L can only
+    // influence the result if k <= g_maxMismatch[L] + ADD -- otherwise either a lower level exists (and
+    // lo + ADD < k), or it is itself the lowest level and the search aborts at L with or without it.
+    // So a seed is kept iff level(bps) <= g_maxMismatch[bps] + ADD, or it is still alive (< T mismatches)
+    // after the 32 (or len-1) bases the prefilter sees and may become relevant further on.
+    const int Wv = S.len - 1 < 32 ? S.len - 1 : 32;
+    const u32 w_mask = Wv >= 32 ? 0xffffffffu : ((1u << Wv) - 1u);
+    int cap0 = max_mismatch_at(prm, S.bps) + S.add_mm;
+    for (int k = 0; k < PG_MM_BREAKS; k++)
+        if ((int)prm.mm_bp[k] > S.bps && (int)prm.mm_bp[k] <= Wv) cap0 = S.T - 1;   // breakpoint inside the window
+    if (cap0 > S.T - 1) cap0 = S.T - 1;
     for (int cs = s; cs < e; cs += (int)PG_CHUNK) {
         const int ce = cs + (int)PG_CHUNK < e ? cs + (int)PG_CHUNK : e;
         // the chunk plus 64 NB bases of overhang on both sides must be in LDS
@@ -371,7 +386,7 @@ __device__ __forceinline__ u32 scan_impl(const PgDevRef &ref, Search<Cell> &S, c
                 const u32 d = (rlo ^ q0lo ^ cm) | (rhi ^ q0hi ^ cm);
                 const u32 mis = (d & ~q0nn) | rnn | q0oo;
                 seedv[h] = act && (seedF || seedB);
-                surv[h] = seedv[h] && (S.bps > 32 || __popc(mis & pre_mask) < S.T);
+                surv[h] = seedv[h] && (S.bps > 32 || __popc(mis & pre_mask) <= cap0 || __popc(mis & w_mask) < S.T);
                 isBv[h] = isB;
                 relv[h] = rel;
             }
@@ -412,11 +427,12 @@ __device__ __forceinline__ u32 scan_impl(const PgDevRef &ref, Search<Cell> &S, c
 }
 
 template <int NB, typename Cell>
-__device__ __forceinline__ u32 scan_range(const PgDevRef &ref, Search<Cell> &S, const Query<NB> &Q,
-                                          long long wo, int s, int e, int origin, u32 region, int lane)
+__device__ __forceinline__ u32 scan_range(const PgDevRef &ref, const PgDevParams &prm, Search<Cell> &S,
+                                          const Query<NB> &Q, long long wo, int s, int e, int origin, u32 region,
+                                          int lane)
 {
-    if (Q.allowF && Q.allowB) return scan_impl<NB, Cell, true>(ref, S, Q, wo, s, e, origin, region, lane);
-    return scan_impl<NB, Cell, false>(ref, S, Q, wo, s, e, origin, region, lane);
+    if (Q.allowF && Q.allowB) return scan_impl32<NB, Cell, true>(ref, prm, S, Q, wo, s, e, origin, region, lane);
+    return scan_impl32<NB, Cell, false>(ref, prm, S, Q, wo, s, e, origin, region, lane);
 }
 
 // ---------------------------------------------------------------------------------
@@ -451,13 +467,14 @@ __device__ __forceinline__ int evaluate(const PgDevRef &ref, const PgDevParams &
     // lanes as (level, chunk) for the prefix over L: 8 chunks of 8 cells per level (T <= 8), else
     // 4 chunks of 16 cells; a level's lanes sit inside one 16-lane row so the scan is pure DPP
     const int CPL = S.T <= 8 ? 8 : 4;            // chunks per level
-    const int CS = WAVE / CPL;                   // cells per chunk
     const int pk = lane / CPL, pc = lane & (CPL - 1);
     const bool pact = pk < S.T;
     bool aborted = false;
     for (int r0 = S.bps; r0 <= S.len - 1 && !aborted; r0 += WAVE) {
         // ---- phase 1: absolute G[k](L) for L in [r0, r0+64) into pref[k][L-r0]
         {
+            const int nvalid = S.len - r0 < WAVE ? S.len - r0 : WAVE;   // lengths r0 .. len-1
+            const int CS = (nvalid + CPL - 1) / CPL;                     // cells per chunk
             const int j0 = pc * CS, j1 = (j0 + CS < WAVE) ? j0 + CS : WAVE;
             const Cell *row = S.hist + pk * S.lh + r0;
             Cell tot = 0;
@@ -819,7 +836,7 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
                 s = w == 0 ? s1 : s2;
                 e = w == 0 ? e1 : e2;
             }
-            hits += scan_range<NB, Cell>(ref, S, Q, wo, s, e, org, region, lane);
+            hits += scan_range<NB, Cell>(ref, prm, S, Q, wo, s, e, org, region, lane);
         }
         PT_MARK(1)
 #if defined(PG_STOP_AFTER) && PG_STOP_AFTER == 1
