@@ -172,6 +172,7 @@ struct Search {
     // at word index win_wo; the first staged base is wbase (a multiple of 32)
     long long win_wo;
     int win_lo, win_hi, wbase;
+    int nsurv;     // candidates added to the histogram since it was zeroed
 };
 
 // g_maxMismatch[L] from its breakpoints (the table is monotone): #{k : L >= mm_bp[k]}
@@ -398,6 +399,7 @@ __device__ __forceinline__ u32 scan_impl32(const PgDevRef &ref, const PgDevParam
                 if (surv[0]) S.queue[qn + __popcll(sm0 & low_bits(lane))] = (relv[0] << 1) | (isBv[0] ? 1u : 0u);
                 if (surv[1]) S.queue[qn + n0 + __popcll(sm1 & low_bits(lane))] = (relv[1] << 1) | (isBv[1] ? 1u : 0u);
                 qn += n0 + __popcll(sm1);
+                S.nsurv += n0 + __popcll(sm1);
                 while (qn >= WAVE) {
                     __syncthreads();
 #ifndef PG_ABL_NODENSE
@@ -595,6 +597,7 @@ __device__ __forceinline__ void zero_hist(const Search<Cell> &S, int lane)
     __syncthreads();
 }
 
+
 // ---------------------------------------------------------------------------------
 template <int NB>
 __device__ void load_planes(const uint8_t *seq, int len, int lane, Planes<NB> &fw, Planes<NB> &rv)
@@ -665,6 +668,7 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
     S.lh = (int)lay.lh;
     S.win_wo = -1;
     S.win_lo = S.win_hi = S.wbase = 0;
+    S.nsurv = 0;
 
     const u64 off = B.seq_off[rid];
     const int len = (int)(B.seq_off[rid + 1] - off);
@@ -721,6 +725,7 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
     if (do_close && !(len - 1 >= prm.min_close && (strand == '+' || strand == '-')))
         step = 4;                                    // no close end possible
     bool far_ready = false;                          // far-end query configured
+    int nsurv_eval = -1;                             // S.nsurv when the histogram was last evaluated
     while (step <= last_step) {
         const bool is_close = step < 4;
         if (!is_close && !do_far) break;
@@ -812,7 +817,7 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
         Q.first_ok = first_base_ok<NB>(Q);
         if (!is_close && !Q.first_ok) break;         // far end: first base N (or not ACGT): nothing to find
         PT_MARK(5)
-        if (zero) zero_hist(S, lane);
+        if (zero) { zero_hist(S, lane); S.nsurv = 0; nsurv_eval = -1; }
         PT_MARK(4)
         // ---------------- scan
 #ifdef PG_ABL_NOSCAN
@@ -852,7 +857,12 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
         //   pass 2  close end: count the runs CleanUniquePoints keeps (pindel.cpp:2904-2941: points whose
         //           implied read terminal equals the last point's = runs of the last run's candidate)
         //   pass 3  write the (kept) runs to the pool
-        if (is_close || hits > 0) {
+        // An evaluation can only differ from the previous one of the same histogram if candidates were
+        // added since; an empty histogram yields no point (and "replaces" an empty UP_Far by itself).
+        const bool fresh = S.nsurv != nsurv_eval && S.nsurv > 0;
+        if (!fresh && is_close) close_max = 0;
+        nsurv_eval = S.nsurv;
+        if ((is_close || hits > 0) && fresh) {
             const RegionInfo R = { chr, chr_wo, origin, step == 4 ? bd : nullptr };
             const u32 *tmp32 = (const u32 *)runs_tmp;
             int n = 0, mx = 0, kept = 0, wr = 0, pass = 0, skip = 0;
