@@ -83,13 +83,17 @@ struct PgDevBatch {
 
 // Dynamic LDS layout (bytes), computed identically on host and device.
 struct PgLdsLayout {
-    uint32_t hist_off, carry_off, pref_off, queue_off, win_off, runs_off, total;
+    uint32_t hist_off, carry_off, pref_off, queue_off, win_off, eq_off, runs_off, total;
     uint32_t lh;        // histogram row length (max read length in the launch + 1)
     uint32_t levels;    // max TOTAL_SNP_ERROR_CHECKED in the launch
     uint32_t win_words; // LDS window capacity in 32-base words
 };
 
-#define PG_CHUNK 2048u            // window positions staged per LDS fill
+#define PG_CHUNK 2048u            // window positions staged per LDS fill (= 64 lanes x 32-base words)
+#define PG_CHUNK_SHIFT 11
+#define PG_EQ_ROWS 5u
+// LDS window capacity in 32-base words: chunk + overhang of nb 64-base blocks on both sides + slack
+#define PG_WIN_WORDS(nb) ((PG_CHUNK + 2u * (64u * (nb))) / 32u + 6u)
 
 static inline
 #ifdef __HIPCC__
@@ -106,8 +110,10 @@ PgLdsLayout pg_lds_layout(uint32_t max_len, uint32_t levels, uint32_t nb, uint32
     l.queue_off = l.pref_off + l.levels * 64u * cell;                // queue[192]
     l.win_off = (l.queue_off + 192u * 4u + 15u) & ~15u;              // window (stays valid during evaluate)
     // chunk + overhang of nb 64-base blocks on both sides + alignment slack
-    l.win_words = (PG_CHUNK + 2u * (64u * nb)) / 32u + 6u;
-    l.runs_off = (l.win_off + l.win_words * 16u + 15u) & ~15u;
+    l.win_words = PG_WIN_WORDS(nb);
+    // one-hot planes of the same window (rows A, C, G, T, not-N; win_words words each)
+    l.eq_off = (l.win_off + l.win_words * 16u + 15u) & ~15u;
+    l.runs_off = (l.eq_off + PG_EQ_ROWS * l.win_words * 4u + 15u) & ~15u;
     l.total = (l.runs_off + PG_RUN_TMP * 12u + 15u) & ~15u;
     return l;
 }

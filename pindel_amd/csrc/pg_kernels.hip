@@ -104,8 +104,29 @@ __device__ __forceinline__ C group_scan(C v, int c, int G)
     return v;
 }
 
+// inclusive prefix sum over the 64 lanes of the wave, all DPP: Hillis-Steele inside the 16-lane rows
+// (row_shr shifts zeros in), then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3
+__device__ __forceinline__ u32 wave_scan(u32 v)
+{
+    v += row_shr<1>(v);
+    v += row_shr<2>(v);
+    v += row_shr<4>(v);
+    v += row_shr<8>(v);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
 // tells the compiler a value is wave-uniform (keeps it in SGPRs)
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// An opaque copy of a per-lane value: expressions built on it cannot be hoisted out of the enclosing
+// loop, so lane-derived addresses and masks are recomputed per phase instead of each pinning a VGPR for
+// the whole kernel (occupancy matters more than the few VALU instructions).
+__device__ __forceinline__ int opaque(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
 __device__ __forceinline__ u64 low_bits(int n)            // n in [0,64]
 {
     return n >= 64 ? ~0ull : ((1ull << n) - 1ull);
@@ -158,6 +179,22 @@ struct Query {
     bool first_ok;       // first consumed base is one of ACGT
 };
 
+// Plane word b of the query's base orientation.  Both loads are unconditional and the select is on
+// values: a branchy "use_rv ? rv->x : fw->x" lets the optimizer merge the two loads into one load
+// through a selected pointer, which keeps the planes (and the Query) in scratch memory instead of SGPRs.
+#define PG_QPLANE(name)                                                                       \
+    template <int NB>                                                                         \
+    __device__ __forceinline__ u64 q_##name(const Query<NB> &Q, int b)                        \
+    {                                                                                         \
+        const u64 f = Q.fw->name[b], r = Q.rv->name[b];                                       \
+        return Q.use_rv ? r : f;                                                              \
+    }
+PG_QPLANE(lo)
+PG_QPLANE(hi)
+PG_QPLANE(nn)
+PG_QPLANE(oo)
+#undef PG_QPLANE
+
 template <typename Cell>
 struct Search {
     int len, T, M, add_mm, bps, min_perfect, thr;
@@ -167,9 +204,11 @@ struct Search {
     Cell *carry;   // [PG_MAX_LEVELS] running prefix per level during evaluate
     Cell *pref;    // [T][64] absolute G of the current 64-length round (aliases win/queue)
     u32 *queue;    // [192] compacted survivors of the prefilter
-    uint4 *win;    // staged window
+    uint4 *win;    // staged window: code planes (lo, hi, N)
+    u32 *eq;       // staged window: one-hot planes [5][eq_stride]
+    int eq_stride;
     // what the LDS window currently holds: bases [win_lo, win_hi) of the chromosome whose AbsLoc 0 is
-    // at word index win_wo; the first staged base is wbase (a multiple of 32)
+    // at word index win_wo; the first staged base is wbase = win_lo (any alignment)
     long long win_wo;
     int win_lo, win_hi, wbase;
     int nsurv;     // candidates added to the histogram since it was zeroed
@@ -190,10 +229,7 @@ template <int NB>
 __device__ __forceinline__ void block_masks(const Query<NB> &Q, int b, bool comp,
                                             u64 rlo, u64 rhi, u64 rnn, u64 &mis, u64 &sne)
 {
-    const u64 qlo = Q.use_rv ? Q.rv->lo[b] : Q.fw->lo[b];
-    const u64 qhi = Q.use_rv ? Q.rv->hi[b] : Q.fw->hi[b];
-    const u64 qnn = Q.use_rv ? Q.rv->nn[b] : Q.fw->nn[b];
-    const u64 qoo = Q.use_rv ? Q.rv->oo[b] : Q.fw->oo[b];
+    const u64 qlo = q_lo<NB>(Q, b), qhi = q_hi<NB>(Q, b), qnn = q_nn<NB>(Q, b), qoo = q_oo<NB>(Q, b);
     u64 cm = comp ? ~0ull : 0ull;
     u64 x = rlo ^ qlo ^ cm;
     u64 y = rhi ^ qhi ^ cm;
@@ -292,149 +328,223 @@ __device__ __forceinline__ void dense_pass(const Search<Cell> &S, const Query<NB
     }
 }
 
-// Stages bases [lo, hi) (hi - lo <= PG_CHUNK + 128 NB) of a chromosome into the LDS window.
+// Stages bases [lo, hi) (hi - lo <= PG_CHUNK + 128 NB) of a chromosome into LDS: word i of the window
+// holds bases [lo + 32 i, lo + 32 i + 32) whatever the alignment of lo (funnel shift of two HBM words),
+// once as the code planes the dense pass / CheckMismatches use and once as one-hot planes (is-A, is-C,
+// is-G, is-T, is-not-N) for the bit-sliced seed filter.
 template <int NB, typename Cell>
 __device__ __forceinline__ void stage_window(const PgDevRef &ref, Search<Cell> &S, long long wo, int lo, int hi,
                                              int lane)
 {
-    const int w0 = lo >> 5;
-    const int nwords = ((hi + 31) >> 5) - w0 + 2;
+    const int nw = ((hi - lo + 31) >> 5) + 2;
+    const u32 sh = (u32)(lo & 31);
     __syncthreads();
     {
-        const long long g0 = wo + (long long)w0;
+        const long long g0 = wo + (long long)(lo >> 5);     // arithmetic shift = floor
         const u32 *glo = ref.lo + g0, *ghi = ref.hi + g0, *gnn = ref.nn + g0;
-        for (int i = lane; i < nwords; i += WAVE) S.win[i] = make_uint4(glo[i], ghi[i], gnn[i], 0u);
+        constexpr int st = (int)PG_WIN_WORDS(NB);
+        for (int i = lane; i < nw; i += WAVE) {
+            const u32 x = __builtin_amdgcn_alignbit(glo[i + 1], glo[i], sh);
+            const u32 y = __builtin_amdgcn_alignbit(ghi[i + 1], ghi[i], sh);
+            const u32 z = __builtin_amdgcn_alignbit(gnn[i + 1], gnn[i], sh);
+            S.win[i] = make_uint4(x, y, z, 0u);
+            const u32 ok = ~z;
+            S.eq[i] = ~x & ~y & ok;
+            S.eq[st + i] = x & ~y & ok;
+            S.eq[2 * st + i] = ~x & y & ok;
+            S.eq[3 * st + i] = x & y & ok;
+            S.eq[4 * st + i] = ok;
+        }
     }
     __syncthreads();
     S.win_wo = wo;
-    S.wbase = w0 << 5;
+    S.wbase = lo;
     S.win_lo = lo;
     S.win_hi = hi;
 }
 
-// Scan window positions [s, e) of a chromosome (wo = word index of its AbsLoc 0).
-// Returns the number of seeds (NumberOfHits, farend_searcher.cpp:83).
-// Scan of one window.  PREFILTER: lane = window position p; the first 32 consumed bases of the candidate
-// at p (one funnel extract per plane) decide "seed" and "can still matter at the first reportable
-// length"; survivors are compacted into the LDS queue and go through dense_pass 64 at a time.
-template <int NB, typename Cell, bool MIXED>
-__device__ __forceinline__ u32 scan_impl32(const PgDevRef &ref, const PgDevParams &prm, Search<Cell> &S,
-                                           const Query<NB> &Q, long long wo, int s, int e, int origin, u32 region,
-                                           int lane)
+__device__ __forceinline__ u32 bfi32(u32 m, u32 a, u32 b) { return (m & a) | (~m & b); }
+__device__ __forceinline__ u32 bits32(int lo, int hi)      // bits [lo,hi), clamped to [0,32]
 {
-    u32 hits = 0;
-    if (!Q.first_ok) return 0;
-    const Planes<NB> &qp = Q.use_rv ? *Q.rv : *Q.fw;
-    const u32 q0lo = (u32)qp.lo[0], q0hi = (u32)qp.hi[0], q0nn = (u32)qp.nn[0], q0oo = (u32)qp.oo[0];
-    const u32 pre_mask = S.bps >= 32 ? 0xffffffffu : ((1u << S.bps) - 1u);
-    // Which seeds matter (exact, DESIGN.md "relevance"): a candidate at level k at length L can only
-    // influence the result if k <= g_maxMismatch[L] + ADD -- otherwise either a lower level exists (and
-    // lo + ADD < k), or it is itself the lowest level and the search aborts at L with or without it.
-    // So a seed is kept iff level(bps) <= g_maxMismatch[bps] + ADD, or it is still alive (< T mismatches)
-    // after the 32 (or len-1) bases the prefilter sees and may become relevant further on.
-    const int Wv = S.len - 1 < 32 ? S.len - 1 : 32;
-    const u32 w_mask = Wv >= 32 ? 0xffffffffu : ((1u << Wv) - 1u);
-    int cap0 = max_mismatch_at(prm, S.bps) + S.add_mm;
-    for (int k = 0; k < PG_MM_BREAKS; k++)
-        if ((int)prm.mm_bp[k] > S.bps && (int)prm.mm_bp[k] <= Wv) cap0 = S.T - 1;   // breakpoint inside the window
-    if (cap0 > S.T - 1) cap0 = S.T - 1;
-    for (int cs = s; cs < e; cs += (int)PG_CHUNK) {
-        const int ce = cs + (int)PG_CHUNK < e ? cs + (int)PG_CHUNK : e;
-        // the chunk plus 64 NB bases of overhang on both sides must be in LDS
-        if (!(wo == S.win_wo && cs - 64 * NB >= S.win_lo && ce + 64 * NB <= S.win_hi))
-            stage_window<NB, Cell>(ref, S, wo, cs - 64 * NB, ce + 64 * NB, lane);
-        const int wbase = S.wbase;
-        int qn = 0;     // queued survivors (uniform)
-        for (int base = cs; base < ce; base += PG_PF * WAVE) {
-            // ---- prefilter, two 64-position rounds per iteration, no branches: the first 32 consumed
-            // bases of the candidate at p decide "seed" and "still alive at the first reportable length"
-            bool surv[2] = {false, false}, seedv[2] = {false, false}, isBv[2] = {false, false};
-            u32 relv[2] = {0u, 0u};
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > 32 ? 32 : hi;
+    const u32 hm = hi >= 32 ? 0xffffffffu : ((1u << (hi & 31)) - 1u);
+    return lo < hi ? (hm & ~((1u << (lo & 31)) - 1u)) : 0u;
+}
+
+#ifndef PG_SEED_J
+#define PG_SEED_J(T) (2 * (T) + 4)     // consumed bases the seed filter looks at
+#endif
+
+// SEED FILTER, bit sliced: the lane owns the 32 window positions of word `lane` of the chunk and returns
+// the mask of positions whose candidate (of kind F or B) can matter.  Position bit i, consumed base j
+// reads reference base p+j (F) / p-j (B): one alignbit of the one-hot plane of read base j.  Mismatch
+// counts are kept bit sliced (a 4-bit ripple counter per position + overflow), 9 VALU per base for 32
+// positions.  Which candidates matter (exact, DESIGN.md "relevance"): a candidate at level k at
+// length L can only influence the result if k <= g_maxMismatch[L] + ADD -- otherwise either a lower
+// level exists (lo + ADD < k) or it is the lowest level itself and the search aborts at L with or
+// without it.  With J > bps bases inspected: relevant at some L in [bps, J] implies
+// c(bps) <= g_maxMismatch[J] + ADD (the table is monotone); relevant later implies alive after J bases,
+// c(J) <= T-1.  With J <= bps only the second test applies.  Anything kept beyond that is harmless.
+// positions whose bit-sliced mismatch count (c3 c2 c1 c0, ov = overflowed) is <= thr (wave-uniform)
+__device__ __forceinline__ u32 count_le(u32 c0, u32 c1, u32 c2, u32 c3, u32 ov, int thr)
+{
+    const u32 c[4] = { c0, c1, c2, c3 };
+    u32 eq = ~ov, lt = 0u;
 #pragma unroll
-            for (int h = 0; h < PG_PF; h++) {
-                const int pp = base + 64 * h + lane;
-                const bool act = pp < ce;
-                const int p = act ? pp : ce - 1;
-                const u32 rel = (u32)(p - wbase);
-                const u32 wi = rel >> 5, sh = rel & 31u;
-                const uint4 wm = S.win[wi - 1], wc = S.win[wi], wp = S.win[wi + 1];
-                const u32 bl = (wc.x >> sh) & 1u, bh = (wc.y >> sh) & 1u, bn = (wc.z >> sh) & 1u;
-                const u32 xl = bl ^ (q0lo & 1u), xh = bh ^ (q0hi & 1u);
-                const bool seedF = Q.allowF && !bn && xl == (u32)Q.cF && xh == (u32)Q.cF;
-                const bool seedB = Q.allowB && !bn && xl == (u32)Q.cB && xh == (u32)Q.cB;
-                const bool isB = MIXED ? seedB : Q.allowB;
-                // forward: bits [p, p+32); backward: bits [p-31, p] reversed
-                u32 rlo, rhi, rnn;
-                if (MIXED) {
-                    const u32 s2 = sh + (isB ? 1u : 0u);
-                    rlo = (u32)((((u64)(isB ? wc.x : wp.x) << 32) | (isB ? wm.x : wc.x)) >> s2);
-                    rhi = (u32)((((u64)(isB ? wc.y : wp.y) << 32) | (isB ? wm.y : wc.y)) >> s2);
-                    rnn = (u32)((((u64)(isB ? wc.z : wp.z) << 32) | (isB ? wm.z : wc.z)) >> s2);
-                    const u32 blo = __brev(rlo), bhi2 = __brev(rhi), bnn = __brev(rnn);
-                    rlo = isB ? blo : rlo;
-                    rhi = isB ? bhi2 : rhi;
-                    rnn = isB ? bnn : rnn;
-                } else if (Q.allowB) {          // wave-uniform kind: no selects
-                    rlo = __brev((u32)((((u64)wc.x << 32) | wm.x) >> (sh + 1u)));
-                    rhi = __brev((u32)((((u64)wc.y << 32) | wm.y) >> (sh + 1u)));
-                    rnn = __brev((u32)((((u64)wc.z << 32) | wm.z) >> (sh + 1u)));
-                } else {
-                    rlo = __builtin_amdgcn_alignbit(wp.x, wc.x, sh);
-                    rhi = __builtin_amdgcn_alignbit(wp.y, wc.y, sh);
-                    rnn = __builtin_amdgcn_alignbit(wp.z, wc.z, sh);
+    for (int i = 3; i >= 0; i--) {
+        const u32 ti = ((thr >> i) & 1) ? ~0u : 0u;
+        lt |= eq & ~c[i] & ti;
+        eq &= ~(c[i] ^ ti);
+    }
+    return thr >= 15 ? ~ov : (lt | eq);
+}
+
+template <int NB, typename Cell>
+__device__ __forceinline__ u32 seed_filter(const PgDevParams &prm, const Search<Cell> &S, const Query<NB> &Q,
+                                           bool kindB, int lane)
+{
+    u32 lo = (u32)q_lo<NB>(Q, 0), hi = (u32)q_hi<NB>(Q, 0);
+    const u32 nn = (u32)q_nn<NB>(Q, 0), oo = (u32)q_oo<NB>(Q, 0);
+    if (kindB ? Q.cB : Q.cF) { lo = ~lo; hi = ~hi; }
+    const u32 acgt = ~(nn | oo);
+    const int T = S.T;
+    int J = S.len - 1 < 32 ? S.len - 1 : 32;
+    if (J > PG_SEED_J(T)) J = PG_SEED_J(T);
+    const int jb = S.bps < J ? S.bps : J;
+    const u32 jmask = bits32(1, J), g0mask = bits32(1, jb);
+    int cap0 = max_mismatch_at(prm, J) + S.add_mm;        // min(T-1, g_maxMismatch[J] + ADD)
+    if (cap0 > T - 1) cap0 = T - 1;
+    const int a = 2 * NB + lane - (kindB ? 1 : 0);         // LDS word holding the low half of the pair
+    constexpr int st = (int)PG_WIN_WORDS(NB);              // compile-time row stride: immediate LDS offsets
+
+    const int x0 = (int)((lo & 1u) | ((hi & 1u) << 1));    // first base is ACGT (first_ok)
+    const u32 seed = S.eq[x0 * st + 2 * NB + lane];
+    // read symbols: A C G T N other; bases [1, jb) first, snapshot, then bases [jb, J)
+    const u32 sym[6] = { ~lo & ~hi & acgt, lo & ~hi & acgt, ~lo & hi & acgt, lo & hi & acgt, nn, oo };
+    u32 wl[6], wh[6];
+#pragma unroll
+    for (int X = 0; X < 5; X++) {
+        wl[X] = S.eq[X * st + a];
+        wh[X] = S.eq[X * st + a + 1];
+    }
+    wl[5] = wh[5] = 0u;                                     // symbol 5 (not ACGTN) never matches
+    u32 c0 = 0u, c1 = 0u, c2 = 0u, c3 = 0u, ov = 0u;        // mismatch count per position, bit sliced
+    u32 snap = 0u;
+#pragma unroll
+    for (int it = 0; it < 12; it++) {
+        const int X = it >= 6 ? it - 6 : it;
+        if (it == 6) snap = count_le(c0, c1, c2, c3, ov, cap0);
+        u32 pm = sym[X] & (it >= 6 ? (jmask & ~g0mask) : g0mask);
+        while (pm != 0u) {
+            const int j = __ffs((int)pm) - 1;
+            pm &= pm - 1u;
+            const u32 m = __builtin_amdgcn_alignbit(wh[X], wl[X], (u32)(kindB ? 32 - j : j));
+            const u32 k0 = bfi32(m, 0u, c0);                // carry = count bit & mismatch
+            c0 = ~(c0 ^ m);
+            const u32 k1 = c1 & k0;
+            c1 ^= k0;
+            const u32 k2 = c2 & k1;
+            c2 ^= k1;
+            ov |= c3 & k2;
+            c3 ^= k2;
+        }
+    }
+    return seed & (snap | count_le(c0, c1, c2, c3, ov, T - 1));
+}
+
+// Scan the positions of [s, e) outside [xs, xe) (wo = word index of AbsLoc 0 of the chromosome).
+// The window is cut into 2048-position chunks on the grid g0 + 2048 k; a chunk is staged into LDS
+// (up to e_max, so that later nested ranges find it resident), every lane filters one 32-position
+// word per candidate kind (seed_filter), the surviving positions are compacted into the LDS queue
+// and go through dense_pass 64 at a time.  cache*: filter masks of chunk 0 of the far-end window,
+// computed once and reused by the nested ranges.
+template <int NB, typename Cell, bool MIXED>
+__device__ __forceinline__ void scan_impl(const PgDevRef &ref, const PgDevParams &prm, Search<Cell> &S,
+                                          const Query<NB> &Q, long long wo, int g0, int s, int e, int e_max,
+                                          int xs, int xe, int origin, u32 region, int lane,
+                                          bool use_cache, u32 &cacheF, u32 &cacheB, bool &cache_valid)
+{
+    if (!Q.first_ok || s >= e) return;
+    const int k0 = (s - g0) >> PG_CHUNK_SHIFT, k1 = (e - 1 - g0) >> PG_CHUNK_SHIFT;   // floor
+    for (int k = k0; k <= k1; k++) {
+        const int cs = g0 + (k << PG_CHUNK_SHIFT);
+        const int ns = s > cs ? s : cs;
+        const int ne = e < cs + (int)PG_CHUNK ? e : cs + (int)PG_CHUNK;
+        if (ns >= xs && ne <= xe) continue;                 // nothing new in this chunk
+        const int wb = cs - 64 * NB;
+        if (!(wo == S.win_wo && S.wbase == wb && ne + 64 * NB <= S.win_hi)) {
+            const int se = e_max < cs + (int)PG_CHUNK ? e_max : cs + (int)PG_CHUNK;
+            stage_window<NB, Cell>(ref, S, wo, wb, se + 64 * NB, lane);
+        }
+        const int pbase = cs + 32 * lane;
+        const u32 rmask = bits32(ns - pbase, ne - pbase) & ~bits32(xs - pbase, xe - pbase);
+        const bool cached = use_cache && k == 0 && cache_valid;
+        int qn = 0;                                          // queued survivors (uniform)
+#pragma unroll 1
+        for (int kb = 0; kb < 3; kb++) {                     // kind F, kind B, drain
+            u32 pm = 0u;
+            if (kb < 2 && (kb ? Q.allowB : Q.allowF)) {
+                u32 m;
+                if (cached) m = kb ? cacheB : cacheF;
+                else {
+                    m = seed_filter<NB, Cell>(prm, S, Q, kb != 0, lane);
+                    if (use_cache && k == 0) { if (kb) cacheB = m; else cacheF = m; }
                 }
-                const u32 cm = (isB ? Q.cB : Q.cF) ? 0xffffffffu : 0u;
-                const u32 d = (rlo ^ q0lo ^ cm) | (rhi ^ q0hi ^ cm);
-                const u32 mis = (d & ~q0nn) | rnn | q0oo;
-                seedv[h] = act && (seedF || seedB);
-                surv[h] = seedv[h] && (S.bps > 32 || __popc(mis & pre_mask) <= cap0 || __popc(mis & w_mask) < S.T);
-                isBv[h] = isB;
-                relv[h] = rel;
+                pm = m & rmask;
             }
-            const u64 sd0 = ballot64(seedv[0]), sd1 = ballot64(seedv[1]);
-            hits += (u32)(__popcll(sd0) + __popcll(sd1));
-            const u64 sm0 = ballot64(surv[0]), sm1 = ballot64(surv[1]);
-            if (sm0 | sm1) {
-                const int n0 = __popcll(sm0);
-                if (surv[0]) S.queue[qn + __popcll(sm0 & low_bits(lane))] = (relv[0] << 1) | (isBv[0] ? 1u : 0u);
-                if (surv[1]) S.queue[qn + n0 + __popcll(sm1 & low_bits(lane))] = (relv[1] << 1) | (isBv[1] ? 1u : 0u);
-                qn += n0 + __popcll(sm1);
-                S.nsurv += n0 + __popcll(sm1);
-                while (qn >= WAVE) {
+            for (;;) {
+                const bool more = __any(pm != 0u);
+                if (more) {
+                    const bool act = pm != 0u;
+                    const int bit = __ffs((int)pm) - 1;
+                    pm &= pm - 1u;
+                    const u64 bm = ballot64(act);
+                    if (act)
+                        S.queue[qn + __popcll(bm & low_bits(lane))] =
+                            ((u32)(64 * NB + 32 * lane + bit) << 1) | (u32)kb;
+                    const int add = __popcll(bm);
+                    qn += add;
+                    S.nsurv += add;
+                }
+                const bool drain = !more && kb == 2 && qn > 0;
+                if (qn >= WAVE || drain) {
+                    const int n = qn < WAVE ? qn : WAVE;
                     __syncthreads();
 #ifndef PG_ABL_NODENSE
-                    dense_pass<NB, Cell, MIXED>(S, Q, wbase, origin, region, WAVE, lane);
+                    dense_pass<NB, Cell, MIXED>(S, Q, wb, origin, region, n, lane);
 #endif
                     __syncthreads();
                     // move the remainder (< 128 entries) to the front
-                    const int rem = qn - WAVE;
-                    u32 m0 = (lane < rem) ? S.queue[WAVE + lane] : 0u;
-                    u32 m1 = (WAVE + lane < rem) ? S.queue[2 * WAVE + lane] : 0u;
+                    const int rem = qn - n;
+                    const u32 m0 = (lane < rem) ? S.queue[WAVE + lane] : 0u;
+                    const u32 m1 = (WAVE + lane < rem) ? S.queue[2 * WAVE + lane] : 0u;
                     __syncthreads();
                     if (lane < rem) S.queue[lane] = m0;
                     if (WAVE + lane < rem) S.queue[WAVE + lane] = m1;
                     qn = rem;
-                }
+                } else if (!more) break;
             }
         }
-        if (qn > 0) {
-            __syncthreads();
-#ifndef PG_ABL_NODENSE
-            dense_pass<NB, Cell, MIXED>(S, Q, wbase, origin, region, qn, lane);
-#endif
-        }
+        if (use_cache && k == 0) cache_valid = true;
     }
     __syncthreads();
-    return hits;
 }
 
 template <int NB, typename Cell>
-__device__ __forceinline__ u32 scan_range(const PgDevRef &ref, const PgDevParams &prm, Search<Cell> &S,
-                                          const Query<NB> &Q, long long wo, int s, int e, int origin, u32 region,
-                                          int lane)
+__device__ __forceinline__ void scan_range(const PgDevRef &ref, const PgDevParams &prm, Search<Cell> &S,
+                                           const Query<NB> &Q, long long wo, int g0, int s, int e, int e_max,
+                                           int xs, int xe, int origin, u32 region, int lane,
+                                           bool use_cache, u32 &cacheF, u32 &cacheB, bool &cache_valid)
 {
-    if (Q.allowF && Q.allowB) return scan_impl32<NB, Cell, true>(ref, prm, S, Q, wo, s, e, origin, region, lane);
-    return scan_impl32<NB, Cell, false>(ref, prm, S, Q, wo, s, e, origin, region, lane);
+    // window coordinates come out of LDS / per-read loads: tell the compiler they are wave-uniform
+    g0 = uni(g0); s = uni(s); e = uni(e); e_max = uni(e_max); xs = uni(xs); xe = uni(xe); origin = uni(origin);
+    if (Q.allowF && Q.allowB)
+        scan_impl<NB, Cell, true>(ref, prm, S, Q, wo, g0, s, e, e_max, xs, xe, origin, region, lane,
+                                  use_cache, cacheF, cacheB, cache_valid);
+    else
+        scan_impl<NB, Cell, false>(ref, prm, S, Q, wo, g0, s, e, e_max, xs, xe, origin, region, lane,
+                                   use_cache, cacheF, cacheB, cache_valid);
 }
 
 // ---------------------------------------------------------------------------------
@@ -466,15 +576,36 @@ __device__ __forceinline__ int evaluate(const PgDevRef &ref, const PgDevParams &
         if (lane < S.T) S.carry[lane] = g;
     }
     __syncthreads();
-    // lanes as (level, chunk) for the prefix over L: 8 chunks of 8 cells per level (T <= 8), else
-    // 4 chunks of 16 cells; a level's lanes sit inside one 16-lane row so the scan is pure DPP
+    // 32-bit cells: lanes own L and one DPP wave scan per level turns the differences into G[k](L);
+    // lane k of cv carries G[k] at the end of the previous 64-length round.
+    // 64-bit cells: lanes as (level, chunk) for the prefix over L: 8 chunks of 8 cells per level
+    // (T <= 8), else 4 chunks of 16 cells; a level's lanes sit inside one 16-lane row (DPP row scans)
+    constexpr bool SCAN32 = sizeof(Cell) == 4;
     const int CPL = S.T <= 8 ? 8 : 4;            // chunks per level
     const int pk = lane / CPL, pc = lane & (CPL - 1);
     const bool pact = pk < S.T;
+    u32 cv = 0u;
+    if (SCAN32) cv = lane < S.T ? (u32)S.carry[lane] : 0u;
     bool aborted = false;
     for (int r0 = S.bps; r0 <= S.len - 1 && !aborted; r0 += WAVE) {
-        // ---- phase 1: absolute G[k](L) for L in [r0, r0+64) into pref[k][L-r0]
-        {
+        const int L = r0 + lane;
+        const bool valid = L <= S.len - 1;
+        int lo = -1;
+        u32 cnt_lo = 0, sumw = 0;
+        u64 id_lo = 0;
+        if (SCAN32) {
+            for (int k = 0; k < S.T; k++) {
+                const u32 d = valid ? (u32)S.hist[k * S.lh + L] : 0u;
+                const u32 ck = (u32)__builtin_amdgcn_readlane((int)cv, k);
+                const u32 g = wave_scan(d) + ck;
+                const u32 g63 = (u32)__builtin_amdgcn_readlane((int)g, 63);
+                cv = lane == k ? g63 : cv;
+                const u32 cnt = g & ((1u << F::CB) - 1u);
+                if (lo < 0 && k <= S.M && cnt > 0) { lo = k; cnt_lo = cnt; }
+                if (lo >= 0 && k == lo + S.add_mm) { sumw = cnt; id_lo = (u64)(g >> F::CB); }
+            }
+        } else {
+            // ---- phase 1: absolute G[k](L) for L in [r0, r0+64) into pref[k][L-r0]
             const int nvalid = S.len - r0 < WAVE ? S.len - r0 : WAVE;   // lengths r0 .. len-1
             const int CS = (nvalid + CPL - 1) / CPL;                     // cells per chunk
             const int j0 = pc * CS, j1 = (j0 + CS < WAVE) ? j0 + CS : WAVE;
@@ -493,20 +624,16 @@ __device__ __forceinline__ int evaluate(const PgDevRef &ref, const PgDevParams &
             __syncthreads();
             if (pact && pc == CPL - 1) S.carry[pk] = acc;
             __syncthreads();
+            // ---- phase 2: lanes own L
+            for (int i = 0; i < S.T; i++) {
+                Cell c = valid ? S.pref[i * WAVE + lane] : (Cell)0;
+                u32 cnt = (u32)(c & (Cell)((1ull << F::CB) - 1ull));
+                if (lo < 0 && i <= S.M && cnt > 0) { lo = i; cnt_lo = cnt; }
+                if (lo >= 0 && i == lo + S.add_mm) { sumw = cnt; id_lo = (u64)(c >> F::CB); }
+            }
         }
-        // ---- phase 2: lanes own L
-        const int L = r0 + lane;
-        const bool valid = L <= S.len - 1;
-        int lo = -1;
-        u32 cnt_lo = 0, sumw = 0;
-        u64 id_lo = 0;
-        for (int i = 0; i < S.T; i++) {
-            Cell c = valid ? S.pref[i * WAVE + lane] : (Cell)0;
-            u32 cnt = (u32)(c & (Cell)((1ull << F::CB) - 1ull));
-            if (lo < 0 && i <= S.M && cnt > 0) { lo = i; cnt_lo = cnt; }
-            if (lo >= 0 && i == lo + S.add_mm) { sumw = cnt; id_lo = (u64)(c >> F::CB); }
-        }
-        const int mmL = valid ? max_mismatch_at(prm, L) : 0;
+        int mmL = 0;                                  // g_maxMismatch[L] (<= M for L <= len)
+        for (int k = 0; k < S.M; k++) mmL += (valid && (u32)L >= prm.mm_bp[k]) ? 1 : 0;
         // "if (minimumNumberOfMismatches(...) > g_maxMismatch[L]) return;"
         const bool abortL = valid && ((lo < 0 ? S.M + 1 : lo) > mmL);
         const u64 ab = ballot64(abortL);
@@ -600,7 +727,7 @@ __device__ __forceinline__ void zero_hist(const Search<Cell> &S, int lane)
 
 // ---------------------------------------------------------------------------------
 template <int NB>
-__device__ void load_planes(const uint8_t *seq, int len, int lane, Planes<NB> &fw, Planes<NB> &rv)
+__device__ __forceinline__ void load_planes(const uint8_t *seq, int len, int lane, Planes<NB> &fw, Planes<NB> &rv)
 {
 #pragma unroll
     for (int b = 0; b < NB; b++) {
@@ -638,7 +765,7 @@ __device__ __forceinline__ u32 pool_alloc(const PgDevBatch &B, int n, int lane, 
 template <int NB>
 __device__ __forceinline__ bool first_base_ok(const Query<NB> &Q)
 {
-    const u64 x = Q.use_rv ? (Q.rv->nn[0] | Q.rv->oo[0]) : (Q.fw->nn[0] | Q.fw->oo[0]);
+    const u64 x = q_nn<NB>(Q, 0) | q_oo<NB>(Q, 0);
     return (x & 1ull) == 0ull;
 }
 
@@ -664,6 +791,8 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
     S.pref = (Cell *)(smem + lay.pref_off);
     S.queue = (u32 *)(smem + lay.queue_off);
     S.win = (uint4 *)(smem + lay.win_off);
+    S.eq = (u32 *)(smem + lay.eq_off);
+    S.eq_stride = (int)lay.win_words;
     pg_run *runs_tmp = (pg_run *)(smem + lay.runs_off);
     S.lh = (int)lay.lh;
     S.win_wo = -1;
@@ -673,7 +802,7 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
     const u64 off = B.seq_off[rid];
     const int len = (int)(B.seq_off[rid + 1] - off);
     const uint8_t *seq = B.seq + off;
-    const int chr = B.chr[rid];
+    const int chr = uni((int)B.chr[rid]);
     const long long chr_wo = (long long)ref.chr_word_off[chr];
     const int chr_size = (int)ref.chr_size[chr];
     S.len = len;
@@ -692,18 +821,18 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
     return;
 #endif
 
-    float alg = (mode & PG_MODE_CLOSE) ? (float)len : 0.f;   // the read itself is counted once
+    int alg8 = (mode & PG_MODE_CLOSE) ? 8 * len : 0;         // algorithmic bytes x 8; the read itself is counted once
     int flipped = 0, close_max = 0, n_close = 0, n_far = 0, far_max = 0;
     u32 close_last = 0, close_base = 0, far_base = 0;
 
     const bool do_close = (mode & PG_MODE_CLOSE) != 0, do_far = (mode & PG_MODE_FAR) != 0;
-    const char strand = do_close ? (char)B.strand[rid] : '+';
-    const int apos = do_close ? (int)(B.pos[rid] + (int)prm.spacer) : 0;
-    const int isz = do_close ? (int)B.isz[rid] : 0;
+    const char strand = do_close ? (char)uni((int)B.strand[rid]) : '+';   // byte loads go through VMEM
+    const int apos = do_close ? uni((int)(B.pos[rid] + (int)prm.spacer)) : 0;
+    const int isz = do_close ? uni((int)B.isz[rid]) : 0;
     if (!do_close) {
-        flipped = B.rc_flag[rid];
-        close_last = B.close_last_abs[rid];
-        close_max = B.close_max_len[rid];
+        flipped = uni((int)B.rc_flag[rid]);
+        close_last = (u32)uni((int)B.close_last_abs[rid]);
+        close_max = uni((int)B.close_max_len[rid]);
     }
     int nbd = 0;
     const pg_window *bd = nullptr;
@@ -718,8 +847,9 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
 
     // far-range bookkeeping (nested windows)
     int ps = 0, pe = 0, span = 64, reach = 0;
-    u32 hits = 0;
-    float close_bases = 0.f, far_bases = 0.f;
+    int close_bases = 0, far_bases = 0;
+    u32 cacheF = 0u, cacheB = 0u;                    // seed-filter masks of the innermost far-end chunk
+    bool cache_valid = false;
 
     int step = do_close ? 0 : 4;
     if (do_close && !(len - 1 >= prm.min_close && (strand == '+' || strand == '-')))
@@ -738,8 +868,9 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
         Query<NB> Q;
         Q.fw = &A;
         Q.rv = &Ar;
-        int nwin = 0;                 // windows to scan this step (<= 2, or nbd)
-        int s1 = 0, e1 = 0, s2 = 0, e2 = 0;
+        int nwin = 0;                 // windows to scan this step (<= 1, or nbd)
+        int s1 = 0, e1 = 0;           // positions [s1, e1) minus [xs, xe) are new in this step
+        int xs = 0, xe = 0, g0 = 0, emax = 0;
         int origin = 0;
         bool zero = false;
         if (is_close) {
@@ -761,10 +892,11 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
             Q.antisenseF = true;      // CheckLeft_Close: FORWARD, ANTISENSE
             Q.antisenseB = false;     // CheckRight_Close: BACKWARD, SENSE
             origin = s1;
+            g0 = s1;
+            emax = e1;
             nwin = 1;
             zero = true;
-            hits = 0;
-            close_bases = (float)(e1 > s1 ? e1 - s1 : 0);
+            close_bases = e1 > s1 ? e1 - s1 : 0;
         } else {
             S.bps = 10;               // farend_searcher.cpp:90
             // cur = flipped ? RC(orig) : orig.  Plus strand consumes cur left to right, Minus strand
@@ -778,35 +910,28 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
                 if (nbd == 0) { step++; continue; }
                 nwin = nbd;
                 zero = true;
-                hits = 0;
             } else {
                 const int center = (int)close_last;
                 origin = center - maxspan;
-                if (step == 5) {
-                    zero = true; hits = 0; ps = pe = 0; span = 64;
-                    // one LDS fill serves the nested ranges up to 2048 bases (all of them at -x <= 2)
-                    const int half = maxspan < (int)PG_CHUNK / 2 ? maxspan : (int)PG_CHUNK / 2;
-                    stage_window<NB, Cell>(ref, S, chr_wo, center - half - 64 * NB, center + half + 64 * NB, lane);
-                }
-                // window of this range, clipped to the non-spacer part (pindel.cpp:1034-1043)
+                if (step == 5) { zero = true; ps = pe = 0; span = 64; cache_valid = false; }
+                // window of this range, clipped to the non-spacer part (pindel.cpp:1034-1043); the
+                // histogram is additive, so only the flanks the previous ranges did not cover are
+                // scanned.  Chunk grid: the innermost 2048 positions are one chunk (one LDS fill and
+                // one seed-filter pass serve the ranges up to 1024).
                 int s, e;
                 if ((u32)center > (u32)span + prm.spacer) s = center - span; else s = (int)prm.spacer;
                 if ((u32)center + (u32)span + prm.spacer < (u32)chr_size) e = center + span;
                 else e = chr_size - (int)prm.spacer;
+                g0 = center - (int)PG_CHUNK / 2;
+                if ((u32)center + (u32)maxspan + prm.spacer < (u32)chr_size) emax = center + maxspan;
+                else emax = chr_size - (int)prm.spacer;
                 if (s < e) {
+                    s1 = s; e1 = e; nwin = 1;
+                    xs = ps; xe = pe;
                     if (ps < pe) {
-                        // only the new flanks; the histogram is additive
-                        const int le = e < ps ? e : ps;
-                        const int rs = s > pe ? s : pe;
-                        if (s < le) { s1 = s; e1 = le; nwin = 1; }
-                        if (rs < e) {
-                            if (nwin == 0) { s1 = rs; e1 = e; } else { s2 = rs; e2 = e; }
-                            nwin++;
-                        }
                         ps = s < ps ? s : ps;
                         pe = e > pe ? e : pe;
                     } else {
-                        s1 = s; e1 = e; nwin = 1;
                         ps = s; pe = e;
                     }
                     reach = pe - ps;
@@ -817,7 +942,7 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
         Q.first_ok = first_base_ok<NB>(Q);
         if (!is_close && !Q.first_ok) break;         // far end: first base N (or not ACGT): nothing to find
         PT_MARK(5)
-        if (zero) { zero_hist(S, lane); S.nsurv = 0; nsurv_eval = -1; }
+        if (zero) { zero_hist(S, opaque(lane)); S.nsurv = 0; nsurv_eval = -1; }
         PT_MARK(4)
         // ---------------- scan
 #ifdef PG_ABL_NOSCAN
@@ -825,7 +950,7 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
 #endif
         for (int w = 0; w < nwin; w++) {
             long long wo = chr_wo;
-            int s, e, org = origin;
+            int s = s1, e = e1, org = origin;
             u32 region = 0;
             if (step == 4) {
                 const pg_window bw = bd[w];
@@ -836,16 +961,16 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
                 e = bw.end > csz ? csz : bw.end;
                 org = st;
                 region = (u32)w;
-                far_bases += (float)(e > s ? e - s : 0) + 2.f * len;
-            } else {
-                s = w == 0 ? s1 : s2;
-                e = w == 0 ? e1 : e2;
+                g0 = s;
+                emax = e;
+                far_bases += (e > s ? e - s : 0) + 2 * len;
             }
-            hits += scan_range<NB, Cell>(ref, prm, S, Q, wo, s, e, org, region, lane);
+            scan_range<NB, Cell>(ref, prm, S, Q, wo, g0, s, e, emax, xs, xe, org, region, opaque(lane),
+                                 step >= 5, cacheF, cacheB, cache_valid);
         }
         PT_MARK(1)
 #if defined(PG_STOP_AFTER) && PG_STOP_AFTER == 1
-        if (lane == 0) B.rc_flag[rid] = (uint8_t)hits;
+        if (lane == 0) B.rc_flag[rid] = (uint8_t)S.nsurv;
         return;
 #endif
         // ---------------- evaluate (NumberOfHits == 0 leaves UP_Far untouched, farend_searcher.cpp:87)
@@ -862,7 +987,7 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
         const bool fresh = S.nsurv != nsurv_eval && S.nsurv > 0;
         if (!fresh && is_close) close_max = 0;
         nsurv_eval = S.nsurv;
-        if ((is_close || hits > 0) && fresh) {
+        if (fresh) {
             const RegionInfo R = { chr, chr_wo, origin, step == 4 ? bd : nullptr };
             const u32 *tmp32 = (const u32 *)runs_tmp;
             int n = 0, mx = 0, kept = 0, wr = 0, pass = 0, skip = 0;
@@ -874,7 +999,7 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
 #ifdef PG_ABL_NOEVAL
                     int nn = 0; mm = 0;
 #else
-                    int nn = evaluate<NB, Cell>(ref, prm, S, Q, R, runs_tmp, skip, PG_RUN_TMP, mm, lane);
+                    int nn = evaluate<NB, Cell>(ref, prm, S, Q, R, runs_tmp, skip, PG_RUN_TMP, mm, opaque(lane));
 #endif
                     if (pass == 0) { n = uni(nn); mx = uni(mm); }
                     PT_MARK(2)
@@ -903,9 +1028,9 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
                 }
                 if (pass == 1 || (pass == 2 && skip == 0 && n <= PG_RUN_TMP)) {
                     const int li = (n - 1) - (pass == 1 ? skip : 0);
-                    last0 = tmp32[3 * li];
-                    last1 = tmp32[3 * li + 1];
-                    last2 = tmp32[3 * li + 2];
+                    last0 = (u32)uni((int)tmp32[3 * li]);
+                    last1 = (u32)uni((int)tmp32[3 * li + 1]);
+                    last2 = (u32)uni((int)tmp32[3 * li + 2]);
                     if (pass == 1) { pass = 2; skip = 0; continue; }
                 }
                 // one chunk of runs, one run per lane
@@ -963,7 +1088,7 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
     if (do_close && n_close == 0) { flipped = 0; close_max = 0; }   // back to the original orientation
 
     if (do_close) {
-        alg += 0.375f * (close_bases + 2.f * len) + 12.0f * (float)n_close;
+        alg8 += 3 * (close_bases + 2 * len) + 96 * n_close;   // 3 bits per base, 12 bytes per run
         if (lane == 0) {
             B.rc_flag[rid] = (uint8_t)flipped;
             B.close_last_abs[rid] = close_last;
@@ -973,8 +1098,8 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
         }
     }
     if (do_far) {
-        if (far_ready) far_bases += (float)reach + 2.f * len;
-        alg += 0.375f * far_bases + 12.0f * (float)n_far;
+        if (far_ready) far_bases += reach + 2 * len;
+        alg8 += 3 * far_bases + 96 * n_far;
         if (lane == 0) { B.far_run_off[rid] = far_base; B.far_run_cnt[rid] = (u32)n_far; }
     }
 #ifdef PG_PHASE_TIMING
@@ -986,8 +1111,8 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
     return;
 #endif
     if (B.alg_bytes && lane == 0) {
-        if (do_close) B.alg_bytes[rid] = (u32)(alg + 0.5f);
-        else B.alg_bytes[rid] += (u32)(alg + 0.5f);        // the far-end launch adds to the close-end launch
+        if (do_close) B.alg_bytes[rid] = (u32)(alg8 + 4) >> 3;
+        else B.alg_bytes[rid] += (u32)(alg8 + 4) >> 3;        // the far-end launch adds to the close-end launch
     }
 }
 
