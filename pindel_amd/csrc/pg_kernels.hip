@@ -160,40 +160,26 @@ __device__ __forceinline__ Cell cell_pack(u64 rel, bool isB, u32 region)
     return (Cell)(1ull | (id << F::CB));
 }
 
-// Wave-uniform description of the read for one orientation: bit planes in
-// CONSUMPTION order (bit j of block b = base 64b+j the growth consumes).
-template <int NB>
-struct Planes {
-    u64 lo[NB], hi[NB], nn[NB], oo[NB];   // code bit0, code bit1, is 'N', is other (never matches)
-};
+// The read's bit planes live in LDS (not in SGPRs: 32+ SGPRs of planes would be spilled to VGPR lanes and
+// come back through v_readlane, which issues on the VALU this kernel is bound by; an LDS broadcast
+// read does not).  Layout: u64 qp[2 orientations][4 planes][NB blocks]; orientation 0 = the read left
+// to right, 1 = reversed; planes in CONSUMPTION order (bit j of block b = base 64b+j the growth
+// consumes): code bit0, code bit1, is 'N', is other (never matches).
+enum { QP_LO = 0, QP_HI = 1, QP_NN = 2, QP_OO = 3 };
 
-// Everything a search needs to know about the query.  The read's planes exist twice (original
-// orientation: forward and reversed consumption order); a query selects one of them.
+// Everything a search needs to know about the query.
 template <int NB>
 struct Query {
-    const Planes<NB> *fw, *rv;
-    bool use_rv;         // base planes (before complement) = use_rv ? *rv : *fw
+    const u64 *qp;       // planes of the base orientation (before complement): qp[plane * NB + block]
     bool allowF, allowB; // candidate kinds searched
     bool cF, cB;         // complement flag per kind
     bool antisenseF, antisenseB;  // Strand reported for a point of that kind
     bool first_ok;       // first consumed base is one of ACGT
 };
-
-// Plane word b of the query's base orientation.  Both loads are unconditional and the select is on
-// values: a branchy "use_rv ? rv->x : fw->x" lets the optimizer merge the two loads into one load
-// through a selected pointer, which keeps the planes (and the Query) in scratch memory instead of SGPRs.
-#define PG_QPLANE(name)                                                                       \
-    template <int NB>                                                                         \
-    __device__ __forceinline__ u64 q_##name(const Query<NB> &Q, int b)                        \
-    {                                                                                         \
-        const u64 f = Q.fw->name[b], r = Q.rv->name[b];                                       \
-        return Q.use_rv ? r : f;                                                              \
-    }
-PG_QPLANE(lo)
-PG_QPLANE(hi)
-PG_QPLANE(nn)
-PG_QPLANE(oo)
-#undef PG_QPLANE
+template <int NB> __device__ __forceinline__ u64 q_lo(const Query<NB> &Q, int b) { return Q.qp[QP_LO * NB + b]; }
+template <int NB> __device__ __forceinline__ u64 q_hi(const Query<NB> &Q, int b) { return Q.qp[QP_HI * NB + b]; }
+template <int NB> __device__ __forceinline__ u64 q_nn(const Query<NB> &Q, int b) { return Q.qp[QP_NN * NB + b]; }
+template <int NB> __device__ __forceinline__ u64 q_oo(const Query<NB> &Q, int b) { return Q.qp[QP_OO * NB + b]; }
 
 template <typename Cell>
 struct Search {
@@ -404,8 +390,8 @@ template <int NB, typename Cell>
 __device__ __forceinline__ u32 seed_filter(const PgDevParams &prm, const Search<Cell> &S, const Query<NB> &Q,
                                            bool kindB, int lane)
 {
-    u32 lo = (u32)q_lo<NB>(Q, 0), hi = (u32)q_hi<NB>(Q, 0);
-    const u32 nn = (u32)q_nn<NB>(Q, 0), oo = (u32)q_oo<NB>(Q, 0);
+    u32 lo = (u32)uni((int)(u32)q_lo<NB>(Q, 0)), hi = (u32)uni((int)(u32)q_hi<NB>(Q, 0));
+    const u32 nn = (u32)uni((int)(u32)q_nn<NB>(Q, 0)), oo = (u32)uni((int)(u32)q_oo<NB>(Q, 0));
     if (kindB ? Q.cB : Q.cF) { lo = ~lo; hi = ~hi; }
     const u32 acgt = ~(nn | oo);
     const int T = S.T;
@@ -727,7 +713,7 @@ __device__ __forceinline__ void zero_hist(const Search<Cell> &S, int lane)
 
 // ---------------------------------------------------------------------------------
 template <int NB>
-__device__ __forceinline__ void load_planes(const uint8_t *seq, int len, int lane, Planes<NB> &fw, Planes<NB> &rv)
+__device__ __forceinline__ void load_planes(const uint8_t *seq, int len, int lane, u64 *qp)
 {
 #pragma unroll
     for (int b = 0; b < NB; b++) {
@@ -738,15 +724,17 @@ __device__ __forceinline__ void load_planes(const uint8_t *seq, int len, int lan
         // code: A=0 C=1 G=2 T=3
         bool fA = cf == 'A', fC = cf == 'C', fG = cf == 'G', fT = cf == 'T', fN = cf == 'N';
         bool rA = cr == 'A', rC = cr == 'C', rG = cr == 'G', rT = cr == 'T', rN = cr == 'N';
-        fw.lo[b] = ballot64(fC || fT);
-        fw.hi[b] = ballot64(fG || fT);
-        fw.nn[b] = ballot64(fN);
-        fw.oo[b] = ballot64(in && !(fA || fC || fG || fT || fN));
-        rv.lo[b] = ballot64(rC || rT);
-        rv.hi[b] = ballot64(rG || rT);
-        rv.nn[b] = ballot64(rN);
-        rv.oo[b] = ballot64(in && !(rA || rC || rG || rT || rN));
+        const u64 flo = ballot64(fC || fT), fhi = ballot64(fG || fT), fnn = ballot64(fN);
+        const u64 foo = ballot64(in && !(fA || fC || fG || fT || fN));
+        const u64 rlo = ballot64(rC || rT), rhi = ballot64(rG || rT), rnn = ballot64(rN);
+        const u64 roo = ballot64(in && !(rA || rC || rG || rT || rN));
+        if (lane == 0) {
+            qp[QP_LO * NB + b] = flo; qp[QP_HI * NB + b] = fhi; qp[QP_NN * NB + b] = fnn; qp[QP_OO * NB + b] = foo;
+            u64 *qr = qp + 4 * NB;
+            qr[QP_LO * NB + b] = rlo; qr[QP_HI * NB + b] = rhi; qr[QP_NN * NB + b] = rnn; qr[QP_OO * NB + b] = roo;
+        }
     }
+    __syncthreads();
 }
 
 // Bump-allocates n runs in this workgroup's pool shard (one atomic per wave); returns the pool
@@ -765,8 +753,8 @@ __device__ __forceinline__ u32 pool_alloc(const PgDevBatch &B, int n, int lane, 
 template <int NB>
 __device__ __forceinline__ bool first_base_ok(const Query<NB> &Q)
 {
-    const u64 x = q_nn<NB>(Q, 0) | q_oo<NB>(Q, 0);
-    return (x & 1ull) == 0ull;
+    const u32 x = (u32)uni((int)(u32)(q_nn<NB>(Q, 0) | q_oo<NB>(Q, 0)));
+    return (x & 1u) == 0u;
 }
 
 // One read per 64-thread workgroup.  The read goes through a sequence of search STEPS that share
@@ -813,11 +801,11 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
     S.thr = prm.thr_tab[len];
 
     PT_DECL
-    Planes<NB> A, Ar;   // original orientation: forward and reversed consumption order
-    load_planes<NB>(seq, len, lane, A, Ar);
+    u64 *qplanes = (u64 *)(smem + lay.qp_off);   // [0]: forward, [1]: reversed consumption order
+    load_planes<NB>(seq, len, lane, qplanes);
     PT_MARK(0)
 #if defined(PG_STOP_AFTER) && PG_STOP_AFTER == 0
-    if (lane == 0) B.rc_flag[rid] = (uint8_t)(A.lo[0] ^ Ar.hi[0]);
+    if (lane == 0) B.rc_flag[rid] = (uint8_t)(qplanes[0] ^ qplanes[4 * NB + NB]);
     return;
 #endif
 
@@ -866,8 +854,6 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
         }
         // ---------------- configure the step
         Query<NB> Q;
-        Q.fw = &A;
-        Q.rv = &Ar;
         int nwin = 0;                 // windows to scan this step (<= 1, or nbd)
         int s1 = 0, e1 = 0;           // positions [s1, e1) minus [xs, xe) are new in this step
         int xs = 0, xe = 0, g0 = 0, emax = 0;
@@ -879,7 +865,7 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
             S.bps = prm.min_close;
             // '+' anchor: CurrentReadSeq = RC(cur), grown left to right (pindel.cpp:2271-2291)
             // '-' anchor: CurrentReadSeq = cur, grown right to left     (pindel.cpp:2298-2319)
-            Q.use_rv = !flipped;
+            Q.qp = qplanes + (!flipped ? 4 * NB : 0);
             if (strand == '+') {
                 Q.cF = !flipped; Q.cB = false; Q.allowF = true; Q.allowB = false;
                 s1 = apos - Rg * isz;
@@ -901,7 +887,7 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
             S.bps = 10;               // farend_searcher.cpp:90
             // cur = flipped ? RC(orig) : orig.  Plus strand consumes cur left to right, Minus strand
             // consumes complement(cur) walking the reference right to left.
-            Q.use_rv = flipped;
+            Q.qp = qplanes + (flipped ? 4 * NB : 0);
             Q.cF = flipped; Q.cB = !flipped;
             Q.allowF = Q.allowB = true;
             Q.antisenseF = false;     // FORWARD, SENSE
