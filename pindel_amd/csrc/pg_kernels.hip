@@ -61,7 +61,7 @@ typedef unsigned int u32;
 #define PG_PF 1      // prefilter rounds (64 positions each) per loop iteration
 #endif
 #ifndef PG_WAVES_PER_EU
-#define PG_WAVES_PER_EU 4   // register budget the kernel is compiled for (waves per SIMD)
+#define PG_WAVES_PER_EU 5   // register budget the kernel is compiled for (waves per SIMD): 96 VGPRs
 #endif
 
 __device__ __forceinline__ u64 ballot64(bool p) { return __ballot(p); }
@@ -580,16 +580,25 @@ __device__ __forceinline__ int evaluate(const PgDevRef &ref, const PgDevParams &
         u32 cnt_lo = 0, sumw = 0;
         u64 id_lo = 0;
         if (SCAN32) {
+            u32 zc = 0u, n1 = 0u, idr = 0u;
             for (int k = 0; k < S.T; k++) {
                 const u32 d = valid ? (u32)S.hist[k * S.lh + L] : 0u;
                 const u32 ck = (u32)__builtin_amdgcn_readlane((int)cv, k);
                 const u32 g = wave_scan(d) + ck;
                 const u32 g63 = (u32)__builtin_amdgcn_readlane((int)g, 63);
                 cv = lane == k ? g63 : cv;
+                // G[k](L) is non-decreasing in k, so three counters say everything the rules need:
+                // zc = levels <= M with G = 0 (= the lowest non-empty level, M+1 if none), n1 = levels
+                // with G = 1 (a block starting at zc when G[zc] = 1, hence G[zc] = G[zc+ADD] = 1 <=>
+                // n1 > ADD) and the candidate id of any level with G = 1 (the same single candidate)
                 const u32 cnt = g & ((1u << F::CB) - 1u);
-                if (lo < 0 && k <= S.M && cnt > 0) { lo = k; cnt_lo = cnt; }
-                if (lo >= 0 && k == lo + S.add_mm) { sumw = cnt; id_lo = (u64)(g >> F::CB); }
+                zc += (k <= S.M && cnt == 0u) ? 1u : 0u;
+                n1 += cnt == 1u ? 1u : 0u;
+                idr = cnt == 1u ? (g >> F::CB) : idr;
             }
+            lo = (int)zc <= S.M ? (int)zc : -1;
+            cnt_lo = sumw = n1 > (u32)S.add_mm ? 1u : 0u;
+            id_lo = (u64)idr;
         } else {
             // ---- phase 1: absolute G[k](L) for L in [r0, r0+64) into pref[k][L-r0]
             const int nvalid = S.len - r0 < WAVE ? S.len - r0 : WAVE;   // lengths r0 .. len-1
