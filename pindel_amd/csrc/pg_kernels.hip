@@ -11,12 +11,14 @@
 // kernel computes the same thing differently (DESIGN.md "kernel formulation"):
 //
 //   * The chromosome lives in HBM as three bit planes (2-bit code planar + N plane).
-//     A window chunk is staged into LDS with coalesced dword loads.
-//   * PREFILTER: each lane owns one window position p.  One 32-base funnel extract +
-//     XOR against the read's (wave-uniform, ballot-built) planes decides whether p
-//     seeds a candidate and whether that candidate is still alive (fewer than
-//     TOTAL_SNP_ERROR_CHECKED mismatches) at the first reportable length.  Survivors
-//     (~10 % of positions) are compacted into an LDS queue with ballots.
+//     A window chunk (2048 positions + overhang) is staged into LDS with coalesced dword
+//     loads, as code planes and as one-hot planes (is-A/C/G/T/not-N).
+//   * SEED FILTER, bit sliced: each lane owns the 32 window positions of one LDS word.
+//     The match mask of consumed base j for all 32 positions is one v_alignbit of the
+//     one-hot plane of that read symbol; mismatch counts live in a 4-bit ripple counter
+//     of 32-bit slices.  It keeps exactly the seeds that can matter (DESIGN.md
+//     "relevance"); survivors (~2 % of positions) are enumerated into an LDS queue.
+//     At the far end one filter pass per strand serves all nested ranges.
 //   * DENSE PASS: 64 queued candidates at a time, one per lane.  The mismatch pattern
 //     of the read placed at p comes 64 bases per step (funnel shifts + XOR, no
 //     per-base loop).  A candidate's life is the short list "at length L it leaves
@@ -26,17 +28,19 @@
 //     Candidates are order independent in the reference (a point is only emitted
 //     when a level holds exactly one position), so per-level COUNTS plus the identity
 //     of a singleton are all that is needed.
-//   * EVALUATE: a chunked prefix sum over L turns the differences into G[k](L); lanes
-//     then own lengths L and apply the reference's abort / emission rules to 64
-//     lengths at once, CheckMismatches is redone with the same plane arithmetic, and
-//     consecutive points are emitted as run-length-encoded runs.
-//   * Nested far-end ranges (128, 512, 2048 ... bases) only scan the new flanks:
+//   * EVALUATE: lanes own lengths L; a DPP wave scan per level turns the differences
+//     into G[k](L); the reference's abort / emission rules are applied to 64 lengths at
+//     once, CheckMismatches is redone with the same plane arithmetic, and consecutive
+//     points are emitted as run-length-encoded runs.
+//   * Nested far-end ranges (128, 512, 2048 ... bases) only add the new flanks:
 //     the histogram is additive over disjoint position sets.
 //
-// The kernel is latency bound, so LDS per workgroup is kept small
-// to run 8 waves per SIMD: histogram cells are 32-bit (16-bit count + 16-bit id) whenever
-// every search window of the launch has at most 32 768 positions (Pindel defaults), and
-// 64-bit otherwise (large -x, BreakDancer clusters).
+// The kernel is VALU-issue bound: what counts is the number of
+// vector instructions per read and the resident waves per SIMD (LDS per workgroup and
+// VGPRs).  Histogram cells are 32-bit (16-bit count + 16-bit id) whenever every search
+// window of the launch has at most 32 768 positions (Pindel defaults), and 64-bit
+// otherwise (large -x, BreakDancer clusters).  The read's own bit planes live in LDS:
+// as SGPRs they get spilled to VGPR lanes and every use costs a v_readlane on the VALU.
 //
 // No MFMA: this is bit/byte comparison work, not a contraction.
 #include <hip/hip_runtime.h>
@@ -56,9 +60,6 @@ typedef unsigned int u32;
 #else
 #define PT_DECL
 #define PT_MARK(k)
-#endif
-#ifndef PG_PF
-#define PG_PF 1      // prefilter rounds (64 positions each) per loop iteration
 #endif
 #ifndef PG_WAVES_PER_EU
 #define PG_WAVES_PER_EU 5   // register budget the kernel is compiled for (waves per SIMD): 96 VGPRs
