@@ -427,14 +427,19 @@ __device__ __forceinline__ u32 seed_filter(const PgDevParams &prm, const Search<
             const int j = __ffs((int)pm) - 1;
             pm &= pm - 1u;
             const u32 m = __builtin_amdgcn_alignbit(wh[X], wl[X], (u32)(kindB ? 32 - j : j));
-            const u32 k0 = bfi32(m, 0u, c0);                // carry = count bit & mismatch
-            c0 = ~(c0 ^ m);
-            const u32 k1 = c1 & k0;
-            c1 ^= k0;
-            const u32 k2 = c2 & k1;
-            c2 ^= k1;
-            ov |= c3 & k2;
-            c3 ^= k2;
+            // count += mismatch (= ~m), in place: 8 VALU instructions.  Written as asm because the
+            // compiler's version of the same ripple rotates the counter through three extra v_mov.
+            u32 k0, k1;
+            asm("v_bfi_b32 %5, %7, 0, %0\n\t"          // k0 = ~m & c0
+                "v_xnor_b32 %0, %0, %7\n\t"            // c0 ^= ~m
+                "v_and_b32 %6, %1, %5\n\t"             // k1 = c1 & k0
+                "v_xor_b32 %1, %1, %5\n\t"             // c1 ^= k0
+                "v_and_b32 %5, %2, %6\n\t"             // k2 = c2 & k1
+                "v_xor_b32 %2, %2, %6\n\t"             // c2 ^= k1
+                "v_and_or_b32 %4, %3, %5, %4\n\t"      // ov |= c3 & k2
+                "v_xor_b32 %3, %3, %5"                   // c3 ^= k2
+                : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(ov), "=&v"(k0), "=&v"(k1)
+                : "v"(m));
         }
     }
     return seed & (snap | count_le(c0, c1, c2, c3, ov, T - 1));
