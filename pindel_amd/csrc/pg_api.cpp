@@ -31,7 +31,7 @@ struct pg_ctx {
     uint32_t mm[512]{};
     uint16_t thr[512]{};
     uint16_t *d_thr = nullptr;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, copy_stream = nullptr;   // kernels / host-to-device input copies
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // reference
     std::vector<std::string> names;
@@ -242,7 +242,9 @@ int validate_and_measure(pg_ctx *ctx, const pg_read_batch *reads, uint32_t *max_
     return PG_OK;
 }
 
-int upload_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_device_batch **out)
+// Validates the batch and allocates its device buffers.  copy = true also copies the inputs
+// (synchronously); otherwise the caller streams them in (search_host).  off = read offsets rebased to 0.
+int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, std::vector<uint64_t> &off, pg_device_batch **out)
 {
     uint32_t max_len = 0, levels = 0;
     int rc = validate_and_measure(ctx, reads, &max_len, &levels);
@@ -255,49 +257,62 @@ int upload_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_device_batch **out)
     const size_t n = b->n;
     const uint64_t base0 = n ? reads->seq_off[0] : 0;
     const uint64_t nseq = n ? reads->seq_off[n] - base0 : 0;
-    std::vector<uint64_t> off(n + 1);
+    off.resize(n + 1);
     for (size_t i = 0; i <= n; i++) off[i] = (n ? reads->seq_off[i] : 0) - base0;
-#define UP(field, src, cnt)                                            \
-    if ((rc = dev_upload(ctx, &b->field, src, cnt)) != PG_OK) {        \
-        free_batch_buffers(b);                                         \
-        delete b;                                                      \
-        return rc;                                                     \
-    }
 #define AL(field, cnt)                                                 \
     if ((rc = dev_alloc(ctx, &b->field, cnt)) != PG_OK) {              \
         free_batch_buffers(b);                                         \
         delete b;                                                      \
         return rc;                                                     \
     }
-    UP(seq, reads->seq ? reads->seq + base0 : nullptr, (size_t)nseq);
-    UP(seq_off, off.data(), n + 1);
-    UP(strand, reads->anchor_strand, n);
-    UP(pos, reads->anchor_pos, n);
-    UP(isz, reads->insert_size, n);
-    UP(chr, reads->chr_id, n);
+    AL(seq, (size_t)nseq);
+    AL(seq_off, n + 1);
+    AL(strand, n);
+    AL(pos, n);
+    AL(isz, n);
+    AL(chr, n);
     AL(rc_flag, n);
     AL(close_last, n);
     AL(close_max, n);
     AL(close_off, n);
-    AL(close_cnt, n);
+    AL(close_cnt, n + 1);            // + 1: the device-side CSR scan runs over n + 1 counts
     AL(far_off, n);
-    AL(far_cnt, n);
+    AL(far_cnt, n + 1);
     AL(alg, n);
     AL(pool_used, PG_POOL_SHARDS * 16);
     b->pool_shard_cap = (uint32_t)std::min<uint64_t>((3ull * n) / PG_POOL_SHARDS + 96ull, 0x7fffffffull / PG_POOL_SHARDS);
     if (getenv("PG_TEST_TINY_POOL")) b->pool_shard_cap = 1;      // tests: force the overflow/regrow path
     AL(pool, (size_t)b->pool_shard_cap * PG_POOL_SHARDS);
-#undef UP
 #undef AL
-    hipMemset(b->close_cnt, 0, std::max<size_t>(n, 1) * sizeof(uint32_t));
-    hipMemset(b->far_cnt, 0, std::max<size_t>(n, 1) * sizeof(uint32_t));
+    hipMemset(b->close_cnt, 0, (n + 1) * sizeof(uint32_t));
+    hipMemset(b->far_cnt, 0, (n + 1) * sizeof(uint32_t));
     hipMemset(b->close_off, 0, std::max<size_t>(n, 1) * sizeof(uint32_t));
     hipMemset(b->far_off, 0, std::max<size_t>(n, 1) * sizeof(uint32_t));
     hipMemset(b->rc_flag, 0, std::max<size_t>(n, 1));
     hipMemset(b->close_max, 0, std::max<size_t>(n, 1) * sizeof(uint16_t));
     hipMemset(b->alg, 0, std::max<size_t>(n, 1) * sizeof(uint32_t));
+    if (copy && n) {
+        hipError_t e = hipSuccess;
+        if (nseq) e = hipMemcpy(b->seq, reads->seq + base0, (size_t)nseq, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(b->seq_off, off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(b->strand, reads->anchor_strand, n, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(b->pos, reads->anchor_pos, n * sizeof(int32_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(b->isz, reads->insert_size, n * sizeof(int16_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(b->chr, reads->chr_id, n * sizeof(int32_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            free_batch_buffers(b);
+            delete b;
+            return fail(ctx, PG_E_DEVICE, std::string("input upload: ") + hipGetErrorString(e));
+        }
+    }
     *out = b;
     return PG_OK;
+}
+
+int upload_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_device_batch **out)
+{
+    std::vector<uint64_t> off;
+    return alloc_batch(ctx, reads, true, off, out);
 }
 
 PgDevBatch dev_batch(const pg_device_batch *b)
@@ -327,35 +342,58 @@ PgDevBatch dev_batch(const pg_device_batch *b)
     return d;
 }
 
+bool small_cells(const pg_ctx *ctx, const pg_device_batch *b)
+{
+    // 32-bit histogram cells when every window of this launch has <= 32768 positions
+    // (ranges 128*4^x, close windows 3*InsertSize) and there are no BreakDancer regions
+    return !b->bd_off && ctx->prm.max_range_index <= 4 && 3ll * b->max_isz <= PG_SMALL_MAX_WINDOW &&
+           !getenv("PG_FORCE_WIDE_CELLS");
+}
+
+// Launches the search for reads [lo, lo + cnt) of the batch on the ctx stream.
+int launch_range(pg_ctx *ctx, pg_device_batch *b, int mode, uint32_t lo, uint32_t cnt)
+{
+    PgDevRef ref = dev_ref(ctx);
+    PgDevParams prm = dev_params(ctx);
+    PgDevBatch d = dev_batch(b);
+    d.first_read = lo;
+    d.n_reads = cnt;
+    int lrc = pg_launch_search(&ref, &prm, &d, mode, b->max_len, b->levels, small_cells(ctx, b) ? 1 : 0, ctx->stream);
+    if (lrc != 0) return fail(ctx, PG_E_DEVICE, std::string("kernel launch: ") + hipGetErrorString((hipError_t)lrc));
+    return PG_OK;
+}
+
+// After the launches of a search: total runs, and whether a pool shard overflowed (worst > capacity).
+int read_cursors(pg_ctx *ctx, pg_device_batch *b, uint32_t *worst, uint64_t *total)
+{
+    std::vector<uint32_t> cursors(PG_POOL_SHARDS * 16);
+    HIP_TRY(ctx, hipMemcpy(cursors.data(), b->pool_used, cursors.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    *worst = 0;
+    *total = 0;
+    for (uint32_t s = 0; s < PG_POOL_SHARDS; s++) {
+        *worst = std::max(*worst, cursors[s * 16]);
+        *total += cursors[s * 16];
+    }
+    return PG_OK;
+}
+
 // Runs the kernel(s) of `mode`; if a pool shard overflowed, the pool is regrown and the launch
 // repeated (still entirely on the GPU).
 int run_search(pg_ctx *ctx, pg_device_batch *b, int mode)
 {
     if (ctx->names.empty()) return fail(ctx, PG_E_NO_REFERENCE, "no reference loaded");
-    PgDevRef ref = dev_ref(ctx);
-    PgDevParams prm = dev_params(ctx);
-    std::vector<uint32_t> cursors(PG_POOL_SHARDS * 16);
     for (int attempt = 0; attempt < 8; attempt++) {
         HIP_TRY(ctx, hipMemsetAsync(b->pool_used, 0, PG_POOL_SHARDS * 16 * sizeof(uint32_t), ctx->stream));
-        PgDevBatch d = dev_batch(b);
         HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-        // 32-bit histogram cells when every window of this launch has <= 32768 positions
-        // (ranges 128*4^x, close windows 3*InsertSize) and there are no BreakDancer regions
-        const bool small = !b->bd_off && ctx->prm.max_range_index <= 4 &&
-                           3ll * b->max_isz <= PG_SMALL_MAX_WINDOW && !getenv("PG_FORCE_WIDE_CELLS");
-        int lrc = pg_launch_search(&ref, &prm, &d, mode, b->max_len, b->levels, small ? 1 : 0, ctx->stream);
-        if (lrc != 0) return fail(ctx, PG_E_DEVICE, std::string("kernel launch: ") + hipGetErrorString((hipError_t)lrc));
+        int rc = launch_range(ctx, b, mode, 0, b->n);
+        if (rc) return rc;
         HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         float ms = 0.f;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-        HIP_TRY(ctx, hipMemcpy(cursors.data(), b->pool_used, cursors.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         uint32_t worst = 0;
         uint64_t total = 0;
-        for (uint32_t s = 0; s < PG_POOL_SHARDS; s++) {
-            worst = std::max(worst, cursors[s * 16]);
-            total += cursors[s * 16];
-        }
+        if ((rc = read_cursors(ctx, b, &worst, &total))) return rc;
         if (worst <= b->pool_shard_cap) {
             ctx->last_ms = ms;
             ctx->last_runs = total;
@@ -366,7 +404,7 @@ int run_search(pg_ctx *ctx, pg_device_batch *b, int mode)
         // overflow: grow the pool and redo the launch
         uint32_t ncap = (uint32_t)std::min<uint64_t>((uint64_t)worst + worst / 4 + 64, 0x7fffffffull / PG_POOL_SHARDS);
         pg_run *npool = nullptr;
-        int rc = dev_alloc(ctx, &npool, (size_t)ncap * PG_POOL_SHARDS);
+        rc = dev_alloc(ctx, &npool, (size_t)ncap * PG_POOL_SHARDS);
         if (rc) return rc;
         (void)hipFree(b->pool);
         b->pool = npool;
@@ -375,44 +413,71 @@ int run_search(pg_ctx *ctx, pg_device_batch *b, int mode)
     return fail(ctx, PG_E_DEVICE, "run pool kept overflowing");
 }
 
+// Results to the host: the runs are gathered into read order on the device (prefix sums of the per-read
+// counts + one gather kernel per list), so only the compact CSR crosses PCIe.
 int download(pg_ctx *ctx, pg_device_batch *b, pg_result *r)
 {
     const size_t n = b->n;
     r->n = b->n;
-    std::vector<uint32_t> coff(n), ccnt(n), foff(n), fcnt(n);
-    const size_t used = (size_t)b->pool_shard_cap * PG_POOL_SHARDS;   // the pool is sparse: copy all shards
-    std::vector<pg_run> pool(used);
-    if (n) {
-        HIP_TRY(ctx, hipMemcpy(coff.data(), b->close_off, n * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(ctx, hipMemcpy(ccnt.data(), b->close_cnt, n * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(ctx, hipMemcpy(foff.data(), b->far_off, n * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(ctx, hipMemcpy(fcnt.data(), b->far_cnt, n * 4, hipMemcpyDeviceToHost));
-    }
-    if (used) HIP_TRY(ctx, hipMemcpy(pool.data(), b->pool, (size_t)used * sizeof(pg_run), hipMemcpyDeviceToHost));
-    r->rc_flag.resize(n);
-    r->close_last.resize(n);
-    r->close_max.resize(n);
-    if (n) {
-        HIP_TRY(ctx, hipMemcpy(r->rc_flag.data(), b->rc_flag, n, hipMemcpyDeviceToHost));
-        HIP_TRY(ctx, hipMemcpy(r->close_last.data(), b->close_last, n * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(ctx, hipMemcpy(r->close_max.data(), b->close_max, n * 2, hipMemcpyDeviceToHost));
-    }
     const bool has_close = b->modes_done & PG_MODE_CLOSE, has_far = b->modes_done & PG_MODE_FAR;
     r->close_off.assign(n + 1, 0);
     r->far_off.assign(n + 1, 0);
-    for (size_t i = 0; i < n; i++) {
-        r->close_off[i + 1] = r->close_off[i] + (has_close ? ccnt[i] : 0);
-        r->far_off[i + 1] = r->far_off[i] + (has_far ? fcnt[i] : 0);
+    r->close_runs.clear();
+    r->far_runs.clear();
+    r->rc_flag.resize(n);
+    r->close_last.resize(n);
+    r->close_max.resize(n);
+    if (!n) return PG_OK;
+    uint32_t *csr[2] = { nullptr, nullptr };
+    pg_run *outp[2] = { nullptr, nullptr };
+    void *tmp = nullptr;
+    auto cleanup = [&](int code) {
+        for (int k = 0; k < 2; k++) {
+            if (csr[k]) (void)hipFree(csr[k]);
+            if (outp[k]) (void)hipFree(outp[k]);
+        }
+        if (tmp) (void)hipFree(tmp);
+        return code;
+    };
+#define TRY2(call)                                                                           \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return cleanup(fail(ctx, e_ == hipErrorOutOfMemory ? PG_E_NOMEM : PG_E_DEVICE,   \
+                                std::string(#call) + ": " + hipGetErrorString(e_)));         \
+    } while (0)
+    const size_t tmp_bytes = pg_scan_tmp_bytes((uint32_t)n);
+    TRY2(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
+    const uint32_t *cnts[2] = { b->close_cnt, b->far_cnt }, *offs[2] = { b->close_off, b->far_off };
+    const bool has[2] = { has_close, has_far };
+    uint32_t totals[2] = { 0, 0 };
+    for (int k = 0; k < 2; k++) {
+        if (!has[k]) continue;
+        TRY2(hipMalloc((void **)&csr[k], (n + 1) * sizeof(uint32_t)));
+        TRY2((hipError_t)pg_compact_runs(nullptr, nullptr, cnts[k], csr[k], nullptr, (uint32_t)n, tmp, tmp_bytes, 0, ctx->stream));
+        TRY2(hipMemcpyAsync(&totals[k], csr[k] + n, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     }
-    r->close_runs.resize(r->close_off[n]);
-    r->far_runs.resize(r->far_off[n]);
-    for (size_t i = 0; i < n; i++) {
-        if (has_close && ccnt[i])
-            memcpy(&r->close_runs[r->close_off[i]], &pool[coff[i]], (size_t)ccnt[i] * sizeof(pg_run));
-        if (has_far && fcnt[i])
-            memcpy(&r->far_runs[r->far_off[i]], &pool[foff[i]], (size_t)fcnt[i] * sizeof(pg_run));
+    TRY2(hipStreamSynchronize(ctx->stream));
+    std::vector<uint32_t> h_csr(n + 1);
+    for (int k = 0; k < 2; k++) {
+        if (!has[k]) continue;
+        std::vector<pg_run> &runs = k ? r->far_runs : r->close_runs;
+        std::vector<uint64_t> &off64 = k ? r->far_off : r->close_off;
+        runs.resize(totals[k]);
+        if (totals[k]) {
+            TRY2(hipMalloc((void **)&outp[k], (size_t)totals[k] * sizeof(pg_run)));
+            TRY2((hipError_t)pg_compact_runs(b->pool, offs[k], cnts[k], csr[k], outp[k], (uint32_t)n, nullptr, 0, 1, ctx->stream));
+            TRY2(hipMemcpyAsync(runs.data(), outp[k], (size_t)totals[k] * sizeof(pg_run), hipMemcpyDeviceToHost, ctx->stream));
+        }
+        TRY2(hipMemcpyAsync(h_csr.data(), csr[k], (n + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        TRY2(hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i <= n; i++) off64[i] = h_csr[i];
     }
-    return PG_OK;
+    TRY2(hipMemcpy(r->rc_flag.data(), b->rc_flag, n, hipMemcpyDeviceToHost));
+    TRY2(hipMemcpy(r->close_last.data(), b->close_last, n * 4, hipMemcpyDeviceToHost));
+    TRY2(hipMemcpy(r->close_max.data(), b->close_max, n * 2, hipMemcpyDeviceToHost));
+#undef TRY2
+    return cleanup(PG_OK);
 }
 
 }  // namespace
@@ -487,6 +552,7 @@ void pg_destroy(pg_ctx *ctx)
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
+    if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     delete ctx;
 }
 
@@ -697,27 +763,87 @@ int pg_device_batch_algorithmic_bytes(pg_ctx *ctx, pg_device_batch *b, double *b
 }
 
 // ---------------------------------------------------------------- host in / host out
+// Host buffers in, host results out.  The inputs are streamed to the GPU in chunks on a second stream
+// while the kernel already searches the previous chunk (the kernel takes a read range of the batch);
+// results come back as device-built CSR.
 static int search_host(pg_ctx *ctx, const pg_read_batch *reads, int mode, pg_result **out)
 {
     if (!ctx || !out) return PG_E_INVALID;
     *out = nullptr;
     pg_device_batch *b = nullptr;
-    int rc = upload_batch(ctx, reads, &b);
+    std::vector<uint64_t> off;
+    int rc = alloc_batch(ctx, reads, false, off, &b);
     if (rc) return rc;
-    rc = run_search(ctx, b, mode);
-    pg_result *r = nullptr;
-    if (!rc) {
-        r = new pg_result();
-        rc = download(ctx, b, r);
+    auto bail = [&](int code) {
+        free_batch_buffers(b);
+        delete b;
+        return code;
+    };
+#define TRY3(call)                                                                           \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return bail(fail(ctx, e_ == hipErrorOutOfMemory ? PG_E_NOMEM : PG_E_DEVICE,      \
+                             std::string(#call) + ": " + hipGetErrorString(e_)));            \
+    } while (0)
+    const uint32_t n = b->n;
+    if (n) {
+        if (!ctx->copy_stream) TRY3(hipStreamCreate(&ctx->copy_stream));
+        static const uint32_t chunk = getenv("PG_HOST_CHUNK") ? (uint32_t)std::max(1, atoi(getenv("PG_HOST_CHUNK"))) : (1u << 18);
+        const uint64_t base0 = reads->seq_off[0];
+        std::vector<hipEvent_t> evs;
+        TRY3(hipMemsetAsync(b->pool_used, 0, PG_POOL_SHARDS * 16 * sizeof(uint32_t), ctx->stream));
+        TRY3(hipEventRecord(ctx->ev0, ctx->stream));
+        hipError_t e = hipSuccess;
+        for (uint32_t lo = 0; lo < n && e == hipSuccess && rc == PG_OK; lo += chunk) {
+            const uint32_t hi = (uint32_t)std::min<uint64_t>((uint64_t)lo + chunk, n), cn = hi - lo;
+            hipStream_t cs = ctx->copy_stream;
+            if (off[hi] > off[lo])
+                e = hipMemcpyAsync(b->seq + off[lo], reads->seq + base0 + off[lo], (size_t)(off[hi] - off[lo]), hipMemcpyHostToDevice, cs);
+            if (e == hipSuccess) e = hipMemcpyAsync(b->seq_off + lo, off.data() + lo, (size_t)(cn + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, cs);
+            if (e == hipSuccess) e = hipMemcpyAsync(b->strand + lo, reads->anchor_strand + lo, cn, hipMemcpyHostToDevice, cs);
+            if (e == hipSuccess) e = hipMemcpyAsync(b->pos + lo, reads->anchor_pos + lo, (size_t)cn * sizeof(int32_t), hipMemcpyHostToDevice, cs);
+            if (e == hipSuccess) e = hipMemcpyAsync(b->isz + lo, reads->insert_size + lo, (size_t)cn * sizeof(int16_t), hipMemcpyHostToDevice, cs);
+            if (e == hipSuccess) e = hipMemcpyAsync(b->chr + lo, reads->chr_id + lo, (size_t)cn * sizeof(int32_t), hipMemcpyHostToDevice, cs);
+            hipEvent_t ev = nullptr;
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e == hipSuccess) {
+                evs.push_back(ev);
+                e = hipEventRecord(ev, cs);
+            }
+            if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ev, 0);
+            if (e == hipSuccess) rc = launch_range(ctx, b, mode, lo, cn);
+        }
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev1, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        for (hipEvent_t ev : evs) (void)hipEventDestroy(ev);
+        if (rc) return bail(rc);
+        TRY3(e);
+        float ms = 0.f;
+        TRY3(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        uint32_t worst = 0;
+        uint64_t total = 0;
+        if ((rc = read_cursors(ctx, b, &worst, &total))) return bail(rc);
+        if (worst <= b->pool_shard_cap) {
+            ctx->last_ms = ms;
+            ctx->last_runs = total;
+            b->runs_used = total;
+            b->modes_done |= mode;
+        } else if ((rc = run_search(ctx, b, mode))) {      // a pool shard overflowed: regrow and search again
+            return bail(rc);
+        }
+    } else {
+        b->modes_done |= mode;
     }
-    free_batch_buffers(b);
-    delete b;
+#undef TRY3
+    pg_result *r = new pg_result();
+    rc = download(ctx, b, r);
     if (rc) {
         delete r;
-        return rc;
+        return bail(rc);
     }
     *out = r;
-    return PG_OK;
+    return bail(PG_OK);
 }
 
 int pg_close_end_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_result **out)

@@ -127,6 +127,11 @@ extern "C" {
 // 32-bit histogram cells (see above for when that is valid).
 int pg_launch_search(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch *batch,
                      int mode, uint32_t max_len, uint32_t levels, int small_cells, void *stream);
+// Device-side CSR of a result list: first the scan (gather = 0: csr[0..n] = exclusive sums of cnt, cnt has
+// n + 1 readable entries), then the gather (gather = 1: out[csr[i] + k] = pool[off[i] + k]).
+size_t pg_scan_tmp_bytes(uint32_t n);
+int pg_compact_runs(const pg_run *pool, const uint32_t *off, const uint32_t *cnt, uint32_t *csr,
+                    pg_run *out, uint32_t n, void *tmp, size_t tmp_bytes, int gather, void *stream);
 #ifdef __cplusplus
 }
 #endif

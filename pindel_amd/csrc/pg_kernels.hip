@@ -1139,6 +1139,44 @@ static void launch(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch
                            *ref, *prm, *batch, max_len, levels);
 }
 
+// ---------------------------------------------------------------------------------
+// Results to CSR on the device: the kernel leaves each read's runs somewhere in its pool shard; before
+// the copy to the host they are gathered in read order (offsets = exclusive prefix sums of the per-read
+// counts), so that only the compact lists cross PCIe and the host does no per-read work.
+#include <hipcub/hipcub.hpp>
+
+__global__ void pg_gather_runs_kernel(const pg_run *pool, const uint32_t *off, const uint32_t *cnt,
+                                      const uint32_t *csr, pg_run *out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = cnt[i];
+    const u32 *src = (const u32 *)(pool + off[i]);
+    u32 *dst = (u32 *)(out + csr[i]);
+    for (uint32_t k = 0; k < 3u * c; k++) dst[k] = src[k];
+}
+
+// csr[0..n] = exclusive prefix sums of cnt[0..n) (cnt[n] must be readable; it is ignored: the scan
+// runs over n + 1 items so that csr[n] = total).  tmp / tmp_bytes: scratch from pg_scan_tmp_bytes.
+extern "C" size_t pg_scan_tmp_bytes(uint32_t n)
+{
+    size_t bytes = 0;
+    hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)(n + 1));
+    return bytes;
+}
+
+extern "C" int pg_compact_runs(const pg_run *pool, const uint32_t *off, const uint32_t *cnt, uint32_t *csr,
+                               pg_run *out, uint32_t n, void *tmp, size_t tmp_bytes, int gather, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (!gather) {
+        hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, cnt, csr, (int)(n + 1), st);
+        return (int)e;
+    }
+    if (n) pg_gather_runs_kernel<<<(n + 255u) / 256u, 256, 0, st>>>(pool, off, cnt, csr, out, n);
+    return (int)hipGetLastError();
+}
+
 // Diagnostics: streams n dwords with the staging access pattern (one dword per lane, coalesced) so the
 // FETCH_SIZE counter can be calibrated against a known byte count (MI355X_MICROARCH.md, HBM section).
 __global__ void pg_calib_stream(const u32 *src, size_t n, u32 *sink)
