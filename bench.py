@@ -65,6 +65,26 @@ def measured_traffic(args):
     return per_read * args.reads, f"profiles/r01/{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per read x reads per launch)"
 
 
+def valu_issue(args, kernel_ms):
+    """The kernel is VALU-issue bound, not HBM bound: VALU instructions per read from
+    the committed PMC pass x 4 cycles per wave64 instruction over 1024 SIMDs at 2.4 GHz, against the kernel
+    time measured in this run.  None for workloads the PMC pass was not taken on."""
+    path = os.path.join(ROOT, "profiles", "r01", "v5_pmc_per_read.txt")
+    if args.read_len != 100 or args.max_range_index != 2 or not os.path.exists(path) or kernel_ms <= 0:
+        return None
+    valu = None
+    with open(path) as fh:
+        for line in fh:
+            f = line.split()
+            if f and f[0] == "SQ_INSTS_VALU":
+                valu = float(f[1])
+    if valu is None:
+        return None
+    issue_ms = valu * args.reads * 4.0 / (1024 * 2.4e9) * 1e3
+    return {"valu_insts_per_read": valu, "valu_issue_ms": issue_ms, "valu_busy_frac": issue_ms / kernel_ms,
+            "source": "profiles/r01/v5_pmc_per_read.txt (SQ_INSTS_VALU), 256 CUs x 4 SIMDs, 4 cycles per wave64 VALU instruction, 2.4 GHz"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,6 +182,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "pg_search_kernel", "kernel_ms": avg_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
+                "actual_bound": "valu-issue", "valu": valu_issue(args, avg_ms),
             },
         }
         if world == 1 and not args.no_cpu_baseline:
