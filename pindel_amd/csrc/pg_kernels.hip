@@ -1218,9 +1218,12 @@ extern "C" int pg_launch_search(const PgDevRef *ref, const PgDevParams *prm, con
     hipStream_t st = (hipStream_t)stream;
     // experiment knob: extra dynamic LDS per workgroup (lowers occupancy), bytes
     static const unsigned lds_pad = getenv("PG_LDS_PAD") ? (unsigned)atoi(getenv("PG_LDS_PAD")) : 0u;
+    // 64-base blocks per read: 1/2/3/4/8 with 32-bit cells (the common case), 2/4/8 with 64-bit cells
     const int nb = max_len <= 128 ? 2 : (max_len <= 256 ? 4 : 8);
     if (small_cells) {
-        if (nb == 2) launch<2, u32>(ref, prm, batch, mode, max_len, levels, st, lds_pad);
+        if (max_len <= 64) launch<1, u32>(ref, prm, batch, mode, max_len, levels, st, lds_pad);
+        else if (nb == 2) launch<2, u32>(ref, prm, batch, mode, max_len, levels, st, lds_pad);
+        else if (max_len <= 192) launch<3, u32>(ref, prm, batch, mode, max_len, levels, st, lds_pad);
         else if (nb == 4) launch<4, u32>(ref, prm, batch, mode, max_len, levels, st, lds_pad);
         else launch<8, u32>(ref, prm, batch, mode, max_len, levels, st, lds_pad);
     } else {

@@ -32,6 +32,18 @@ def test_mixed_lengths(engine_factory, small_ref):
     compare_result(gpu, orc, batch.n)
 
 
+@pytest.mark.parametrize("read_len", [40, 64, 150, 192])
+def test_kernel_block_count_variants(engine_factory, small_ref, read_len):
+    """One launch per 64-base block count the kernel is instantiated for (1 and 3 besides 2/4/8)."""
+    eng = engine_factory()
+    eng.load_reference(small_ref)
+    batch = synth.make_reads(small_ref[0][1], 3000, seed=60 + read_len, read_len=read_len)
+    gpu = eng.search_batch(batch)
+    orc = run_oracle({}, small_ref, batch)
+    assert (orc["close_cnt"] > 0).sum() > 1000
+    compare_result(gpu, orc, batch.n)
+
+
 def test_close_then_far_seams(engine_factory, small_ref):
     """pg_close_end_batch + pg_far_end_batch (the two reference seams) == fused search."""
     eng = engine_factory()
