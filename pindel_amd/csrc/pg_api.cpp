@@ -530,9 +530,11 @@ int pg_create(const pg_params *p, pg_ctx **out)
         delete ctx;
         return PG_E_DEVICE;
     }
-    // the kernel evaluates g_maxMismatch[L] from breakpoints: the table must be monotone and <= 16
+    // the kernel evaluates g_maxMismatch[L] from breakpoints: the table must be monotone (it is for every
+    // -e/-E tried).  Whether a batch fits the 16 mismatch levels depends on its longest read and is checked
+    // per batch (validate_and_measure).
     for (int i = 1; i < 500; i++)
-        if (ctx->mm[i] < ctx->mm[i - 1] || ctx->mm[i] > 16) {
+        if (ctx->mm[i] < ctx->mm[i - 1]) {
             pg_destroy(ctx);
             return PG_E_UNSUPPORTED;
         }

@@ -1,0 +1,124 @@
+"""Randomised parity hunt: HIP path (C ABI) vs the CPU oracle, bit-exact, over random parameters, read
+lengths and deliberately nasty references (segmental duplications, tandem repeats, homopolymers, N runs).
+
+    python scripts/fuzz_parity.py [iterations] [first_seed]
+
+Prints one line per iteration and stops at the first mismatch (exit code 1) after saving the failing
+configuration under gpurun_out/fuzz_fail_<seed>.npz.  tests/test_gpu_fuzz.py runs a few fixed seeds of it.
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from pindel_amd import binding, synth
+from tests.parity import compare_result, run_oracle
+
+SPACER = 100000
+
+
+def nasty_reference(rng, length):
+    """Spacer-padded chromosome: random ACGT with copied segments (exact and mutated), tandem repeats with
+    periods 1-6, and a few N runs."""
+    seq = rng.integers(0, 4, length).astype(np.uint8)
+    for _ in range(int(rng.integers(20, 80))):           # segmental duplications
+        ln = int(rng.integers(30, 400))
+        src = int(rng.integers(0, length - ln))
+        seg = seq[src:src + ln].copy()
+        for _ in range(int(rng.integers(1, 5))):
+            dst = int(rng.integers(0, length - ln))
+            cp = seg.copy()
+            nmut = int(rng.integers(0, 4))
+            if nmut:
+                cp[rng.integers(0, ln, nmut)] = rng.integers(0, 4, nmut)
+            if rng.random() < 0.3:                        # inverted copy
+                cp = (3 - cp)[::-1]
+            seq[dst:dst + ln] = cp
+    for _ in range(int(rng.integers(10, 40))):           # tandem repeats / homopolymers
+        period = int(rng.integers(1, 7))
+        ln = int(rng.integers(20, 300))
+        dst = int(rng.integers(0, length - ln))
+        unit = rng.integers(0, 4, period).astype(np.uint8)
+        seq[dst:dst + ln] = np.resize(unit, ln)
+    asc = np.frombuffer(b"ACGT", dtype=np.uint8)[seq]
+    for _ in range(int(rng.integers(0, 4))):
+        ln = int(rng.integers(1, 2000))
+        dst = int(rng.integers(0, length - ln))
+        asc[dst:dst + ln] = ord("N")
+    pad = np.full(SPACER, ord("N"), dtype=np.uint8)
+    return np.concatenate([pad, asc, pad]).tobytes()
+
+
+def random_params(rng):
+    kw = {}
+    if rng.random() < 0.7:
+        kw["max_range_index"] = int(rng.integers(1, 5))
+    if rng.random() < 0.5:
+        kw["additional_mismatch"] = int(rng.integers(1, 4))
+    if rng.random() < 0.5:
+        kw["min_perfect_match"] = int(rng.integers(1, 8))
+    if rng.random() < 0.4:
+        kw["max_mismatch_rate"] = float(rng.choice([0.0, 0.01, 0.02, 0.05, 0.1]))
+    if rng.random() < 0.4:
+        kw["seq_error_rate"] = float(rng.choice([0.001, 0.01, 0.03, 0.05]))
+    if rng.random() < 0.3:
+        kw["sensitivity"] = float(rng.choice([0.8, 0.95, 0.99]))
+    if rng.random() < 0.3:
+        kw["min_close"] = int(rng.integers(6, 15))
+    return kw
+
+
+def one_iteration(seed, n_reads=1500, verbose=True):
+    rng = np.random.default_rng(seed)
+    length = int(rng.integers(150_000, 400_000))
+    ref = nasty_reference(rng, length)
+    chroms = [("f", ref)]
+    kw = random_params(rng)
+    lens = sorted(set(int(x) for x in rng.choice([24, 36, 50, 64, 76, 100, 101, 128, 129, 150, 192, 200, 250, 300],
+                                                 size=int(rng.integers(1, 4)))))
+    isz = int(rng.choice([200, 350, 500, 800]))
+    batch = synth.make_reads(ref, n_reads, seed=seed + 1, read_lens=lens, insert_size=isz,
+                             error_rate=float(rng.choice([0.0, 0.01, 0.03])),
+                             n_rate=float(rng.choice([0.0, 0.001, 0.02])),
+                             max_del=int(rng.choice([50, 2000, 20000])))
+    # a third of the reads are re-anchored at random places of the nasty reference: their windows are
+    # full of repeats and most of them have no close end at all
+    k = n_reads // 3
+    batch.anchor_pos[:k] = rng.integers(2 * isz + 10, length - 2 * isz - 10, k).astype(np.int32)
+    try:
+        eng = binding.Engine(**kw)
+    except binding.PgError as e:          # e.g. a parameter set the library rejects (> 16 levels)
+        if verbose:
+            print(f"seed {seed}: parameters rejected ({e}); skipped")
+        return True
+    try:
+        eng.load_reference(chroms)
+        gpu = eng.search_batch(batch)
+        orc = run_oracle(kw, chroms, batch)
+        compare_result(gpu, orc, batch.n)
+    except binding.PgError as e:
+        if verbose:
+            print(f"seed {seed}: rejected by the library ({e}); skipped")
+        return True
+    except AssertionError as e:
+        os.makedirs("gpurun_out", exist_ok=True)
+        np.savez(f"gpurun_out/fuzz_fail_{seed}.npz", seed=seed, kw=str(kw), lens=lens, isz=isz)
+        print(f"seed {seed}: MISMATCH params={kw} lens={lens} isz={isz}: {e}")
+        return False
+    finally:
+        eng.close()
+    if verbose:
+        nc = int((orc["close_cnt"] > 0).sum())
+        nf = int((orc["far_cnt"] > 0).sum())
+        print(f"seed {seed}: ok  params={kw} lens={lens} isz={isz} close {nc} far {nf}")
+    return True
+
+
+if __name__ == "__main__":
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    for s in range(first, first + iters):
+        if not one_iteration(s):
+            sys.exit(1)
+    print("all", iters, "iterations bit-exact")

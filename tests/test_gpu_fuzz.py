@@ -1,0 +1,12 @@
+"""-m gpu: a few fixed seeds of the randomised parity hunt (scripts/fuzz_parity.py): random parameters,
+read lengths and repeat-ridden references, HIP path vs CPU oracle, bit-exact."""
+import pytest
+
+from scripts.fuzz_parity import one_iteration
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [1000, 1006, 1011, 1015, 1020, 1029, 1038, 2024])
+def test_fuzz_seed(seed):
+    assert one_iteration(seed, verbose=False)
