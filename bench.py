@@ -26,7 +26,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 TRAFFIC_FILE = "v5_hbm_traffic.json"
 
 
-def cpu_baseline(chroms, batch, params_kw, budget_s=15.0):
+def cpu_baseline(chroms, batch, params_kw, budget_s=15.0, bd=None, bd_off=None):
     """Time the CPU restatement (oracle, OpenMP over reads) on a bounded sample of the same reads."""
     from oracle import pyoracle
     cores = os.cpu_count() or 1
@@ -35,9 +35,10 @@ def cpu_baseline(chroms, batch, params_kw, budget_s=15.0):
 
     def run(n):
         b = batch.slice(0, n)
+        w, woff = (bd[:int(bd_off[n])], bd_off[:n + 1]) if bd is not None else (None, None)
         t0 = time.perf_counter()
         pyoracle.search_batch(p, seqs, b.seq, b.seq_off, b.anchor_strand, b.anchor_pos,
-                              b.insert_size, b.chr_id, n_threads=cores, keep_points=False)
+                              b.insert_size, b.chr_id, bd=w, bd_off=woff, n_threads=cores, keep_points=False)
         return time.perf_counter() - t0
 
     n0 = min(batch.n, 20000)
@@ -57,7 +58,7 @@ def measured_traffic(args):
     process, so the per-read figure measured with rocprofv3 on this same workload is scaled by the reads
     of one launch; null for any other workload."""
     path = os.path.join(ROOT, "profiles", "r01", TRAFFIC_FILE)
-    if args.read_len != 100 or args.max_range_index != 2 or not os.path.exists(path):
+    if args.read_len != 100 or args.max_range_index != 2 or args.workload != "sv10m" or not os.path.exists(path):
         return None, None
     with open(path) as fh:
         t = json.load(fh)
@@ -70,7 +71,8 @@ def valu_issue(args, kernel_ms):
     the committed PMC pass x 4 cycles per wave64 instruction over 1024 SIMDs at 2.4 GHz, against the kernel
     time measured in this run.  None for workloads the PMC pass was not taken on."""
     path = os.path.join(ROOT, "profiles", "r01", "v5_pmc_per_read.txt")
-    if args.read_len != 100 or args.max_range_index != 2 or not os.path.exists(path) or kernel_ms <= 0:
+    if (args.read_len != 100 or args.max_range_index != 2 or args.workload != "sv10m" or not os.path.exists(path)
+            or kernel_ms <= 0):
         return None
     valu = None
     with open(path) as fh:
@@ -96,6 +98,9 @@ def main():
     ap.add_argument("--max-range-index", type=int, default=2, help="Pindel -x")
     ap.add_argument("--seed", type=int, default=20260927)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["sv10m", "colo-bd"], default="sv10m",
+                    help="sv10m = BASELINE configs[2] (default); colo-bd = configs[1]-shaped: deletions only, "
+                         "1 M reads unless --reads is given, per-read BreakDancer window hints (synthetic)")
     args = ap.parse_args()
 
     import torch
@@ -118,11 +123,33 @@ def main():
     # ---- synthetic inputs: reference identical on every rank, reads sharded by rank
     ref = synth.make_reference(args.chr_len, seed=args.seed, device=dev)
     chroms = [("20", ref)]
-    batch = synth.make_reads(ref, args.reads, read_len=args.read_len, seed=args.seed + 1 + rank,
-                             device=dev)
+    bd = bd_off = None
+    if args.workload == "colo-bd":
+        # configs[1]-shaped (SURVEY.md 8d cfg 2): deletions only + BreakDancer hints.  The COLO-829 inputs are
+        # not in the image, so the hints are synthetic: 0-2 windows of 600 bases per read within 20 kb
+        # downstream/upstream of the anchor (where a deletion's far end lies).
+        import numpy as np
+        if args.reads == 10_000_000:
+            args.reads = 1_000_000
+        batch = synth.make_reads(ref, args.reads, read_len=args.read_len, seed=args.seed + 1 + rank,
+                                 device=dev, mix=(1.0, 0.0, 0.0, 0.0, 0.0))
+        rng = np.random.default_rng(args.seed + 77 + rank)
+        k = rng.integers(0, 3, batch.n)
+        bd_off = np.concatenate([[0], np.cumsum(k)]).astype(np.uint64)
+        owner = np.repeat(np.arange(batch.n), k)
+        sign = np.where(batch.anchor_strand[owner] == ord("+"), 1, -1)
+        centre = batch.anchor_pos[owner].astype(np.int64) + 100000 + sign * rng.integers(300, 20000, len(owner))
+        centre = np.clip(centre, 100400, len(ref) - 100400)
+        bd = np.zeros(len(owner), dtype=binding.WINDOW_DTYPE)
+        bd["chr_id"], bd["start"], bd["end"] = 0, centre - 300, centre + 300
+    else:
+        batch = synth.make_reads(ref, args.reads, read_len=args.read_len, seed=args.seed + 1 + rank,
+                                 device=dev)
     eng = binding.Engine(device=local_rank, **params_kw)
     eng.load_reference(chroms)
     dbatch = eng.upload(batch)           # inputs resident in HBM before the timed region
+    if bd is not None:
+        eng.set_windows(dbatch, bd, bd_off)
 
     def barrier():
         torch.cuda.synchronize()
@@ -169,9 +196,14 @@ def main():
             "dtype": "u64",
             "data": "synthetic",
             "config": {
-                "workload": (f"BASELINE configs[2]: synthetic {args.reads} x {args.read_len} bp "
+                "workload": ((f"BASELINE configs[2]: synthetic {args.reads} x {args.read_len} bp "
+                              if args.workload == "sv10m" else
+                              f"BASELINE configs[1]-shaped (deletions only, synthetic BreakDancer window hints): "
+                              f"{args.reads} x {args.read_len} bp ") +
                              f"one-end-anchored reads per GPU on a chr20-shaped reference "
-                             f"({args.chr_len} bp), all SV types (D/SI/TD/INV/none), Pindel defaults "
+                             f"({args.chr_len} bp), " +
+                             ("all SV types (D/SI/TD/INV/none)" if args.workload == "sv10m" else "deletions") +
+                             f", Pindel defaults "
                              f"-x {args.max_range_index} -a 1 -m 3 -u 0.02 -e 0.01 -E 0.95 -H 8"),
                 "reads_per_gpu": args.reads, "read_len": args.read_len, "insert_size": 500,
                 "parallelism": f"reads sharded over {world} GPU(s), reference replicated, no collective",
@@ -186,7 +218,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(chroms, batch, params_kw)
+            out["cpu_baseline"] = cpu_baseline(chroms, batch, params_kw, bd=bd, bd_off=bd_off)
         print(json.dumps(out), flush=True)
     eng.free_device_batch(dbatch)
     eng.close()

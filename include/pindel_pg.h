@@ -171,6 +171,11 @@ uint64_t pg_expand_runs(const pg_run *runs, uint64_t n_runs, pg_point *out);
 
 /* ---- the path, device-resident (what bench.py times) ------------------- */
 int  pg_device_batch_upload(pg_ctx *ctx, const pg_read_batch *reads, pg_device_batch **out);
+/* Attaches per-read BreakDancer/RP window clusters (the SearchWindowCluster of
+ * g_bdData.getCorrespondingSearchWindowCluster(read), src/bddata.cpp:949-979, searched before the
+ * ranges, src/pindel.cpp:1006-1018) to a device-resident batch; NULL detaches them.  Same limits as
+ * pg_far_end_batch. */
+int  pg_device_batch_set_windows(pg_ctx *ctx, pg_device_batch *b, const pg_windows *bd_hints);
 /* Close end + far end for every read of the batch; results stay on the GPU.
  * Synchronous: returns when the kernels have finished. */
 int  pg_device_batch_search(pg_ctx *ctx, pg_device_batch *b);

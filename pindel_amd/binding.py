@@ -65,7 +65,7 @@ EXPORTS = [
     "pg_load_reference", "pg_load_fasta", "pg_reference_n_chr", "pg_reference_name",
     "pg_reference_comp_size", "pg_reference_fetch", "pg_close_end_batch", "pg_far_end_batch",
     "pg_search_batch", "pg_result_view_get", "pg_result_free", "pg_expand_runs",
-    "pg_device_batch_upload", "pg_device_batch_search", "pg_device_batch_download",
+    "pg_device_batch_upload", "pg_device_batch_set_windows", "pg_device_batch_search", "pg_device_batch_download",
     "pg_device_batch_free", "pg_last_search_stats", "pg_device_batch_algorithmic_bytes"]
 
 
@@ -126,6 +126,7 @@ def lib():
     L.pg_expand_runs.argtypes = [vp, u64, vp]
     L.pg_expand_runs.restype = u64
     L.pg_device_batch_upload.argtypes = [vp, C.POINTER(PgReadBatch), C.POINTER(vp)]
+    L.pg_device_batch_set_windows.argtypes = [vp, vp, C.POINTER(PgWindows)]
     L.pg_device_batch_search.argtypes = [vp, vp]
     L.pg_device_batch_download.argtypes = [vp, vp, C.POINTER(vp)]
     L.pg_device_batch_free.argtypes = [vp, vp]
@@ -303,6 +304,15 @@ class Engine:
         h = C.c_void_p()
         self._check(self._L.pg_device_batch_upload(self._h, C.byref(s), C.byref(h)))
         return h
+
+    def set_windows(self, dbatch, bd=None, bd_off=None):
+        """Per-read BreakDancer window clusters for a device-resident batch (None detaches them)."""
+        w = None
+        if bd is not None:
+            bd = np.ascontiguousarray(bd, dtype=WINDOW_DTYPE)
+            bd_off = np.ascontiguousarray(bd_off, dtype=np.uint64)
+            w = PgWindows(bd_off.ctypes.data, bd.ctypes.data)
+        self._check(self._L.pg_device_batch_set_windows(self._h, dbatch, C.byref(w) if w is not None else None))
 
     def search_device(self, dbatch):
         self._check(self._L.pg_device_batch_search(self._h, dbatch))

@@ -709,6 +709,14 @@ int pg_device_batch_upload(pg_ctx *ctx, const pg_read_batch *reads, pg_device_ba
     return upload_batch(ctx, reads, out);
 }
 
+static int attach_windows(pg_ctx *ctx, pg_device_batch *b, const pg_windows *bd_hints);
+
+int pg_device_batch_set_windows(pg_ctx *ctx, pg_device_batch *b, const pg_windows *bd_hints)
+{
+    if (!ctx || !b) return PG_E_INVALID;
+    return attach_windows(ctx, b, bd_hints);
+}
+
 int pg_device_batch_search(pg_ctx *ctx, pg_device_batch *b)
 {
     if (!ctx || !b) return PG_E_INVALID;
@@ -858,6 +866,34 @@ int pg_search_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_result **out)
     return search_host(ctx, reads, PG_MODE_BOTH, out);
 }
 
+// Validates per-read window clusters and uploads them to the batch (replacing earlier ones).
+static int attach_windows(pg_ctx *ctx, pg_device_batch *b, const pg_windows *bd_hints)
+{
+    const size_t n = b->n;
+    if (b->bd_off) { (void)hipFree(b->bd_off); b->bd_off = nullptr; }
+    if (b->bd) { (void)hipFree(b->bd); b->bd = nullptr; }
+    if (!(bd_hints && bd_hints->offset && n)) return PG_OK;
+    const uint64_t nw = bd_hints->offset[n];
+    for (size_t i = 0; i < n; i++) {
+        if (bd_hints->offset[i + 1] < bd_hints->offset[i] ||
+            bd_hints->offset[i + 1] - bd_hints->offset[i] > PG_MAX_BD_WINDOWS)
+            return fail(ctx, PG_E_UNSUPPORTED, "more than 127 windows in a BreakDancer cluster");
+    }
+    for (uint64_t k = 0; k < nw; k++) {
+        const pg_window &w = bd_hints->windows[k];
+        if (w.chr_id < 0 || w.chr_id >= (int)ctx->names.size())
+            return fail(ctx, PG_E_INVALID, "BreakDancer window on unknown chromosome");
+        long long st = w.start < 0 ? (long long)w.end - 1 : w.start;
+        if ((long long)w.end - st >= (1ll << PG_REL_BITS))
+            return fail(ctx, PG_E_UNSUPPORTED, "BreakDancer window larger than 2^26 bases");
+    }
+    int rc;
+    if ((rc = dev_upload(ctx, &b->bd_off, bd_hints->offset, n + 1)) ||
+        (rc = dev_upload(ctx, &b->bd, bd_hints->windows, (size_t)nw)))
+        return rc;
+    return PG_OK;
+}
+
 int pg_far_end_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_result *close, const pg_windows *bd_hints)
 {
     if (!ctx || !reads || !close) return PG_E_INVALID;
@@ -877,25 +913,7 @@ int pg_far_end_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_result *close, 
             hipMemcpy(b->close_max, close->close_max.data(), n * 2, hipMemcpyHostToDevice) != hipSuccess)
             return bail(fail(ctx, PG_E_DEVICE, "upload of close-end summary failed"));
     }
-    if (bd_hints && bd_hints->offset && n) {
-        const uint64_t nw = bd_hints->offset[n];
-        for (size_t i = 0; i < n; i++) {
-            if (bd_hints->offset[i + 1] < bd_hints->offset[i] ||
-                bd_hints->offset[i + 1] - bd_hints->offset[i] > PG_MAX_BD_WINDOWS)
-                return bail(fail(ctx, PG_E_UNSUPPORTED, "more than 127 windows in a BreakDancer cluster"));
-        }
-        for (uint64_t k = 0; k < nw; k++) {
-            const pg_window &w = bd_hints->windows[k];
-            if (w.chr_id < 0 || w.chr_id >= (int)ctx->names.size())
-                return bail(fail(ctx, PG_E_INVALID, "BreakDancer window on unknown chromosome"));
-            long long st = w.start < 0 ? (long long)w.end - 1 : w.start;
-            if ((long long)w.end - st >= (1ll << PG_REL_BITS))
-                return bail(fail(ctx, PG_E_UNSUPPORTED, "BreakDancer window larger than 2^26 bases"));
-        }
-        if ((rc = dev_upload(ctx, &b->bd_off, bd_hints->offset, n + 1)) ||
-            (rc = dev_upload(ctx, &b->bd, bd_hints->windows, (size_t)nw)))
-            return bail(rc);
-    }
+    if ((rc = attach_windows(ctx, b, bd_hints))) return bail(rc);
     rc = run_search(ctx, b, PG_MODE_FAR);
     if (rc) return bail(rc);
     pg_result tmp;

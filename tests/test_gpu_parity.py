@@ -163,6 +163,15 @@ def test_multi_chromosome_and_breakdancer_hints(engine_factory):
     orc = run_oracle({}, chroms, batch, bd=bd, bd_off=bd_off)
     assert (orc["far_cnt"] > 0).sum() > 500
     compare_result(both, orc, batch.n)
+    # the same through the device-resident path: windows attached to the uploaded batch, one fused launch
+    db = eng.upload(batch)
+    eng.set_windows(db, bd, bd_off)
+    eng.search_device(db)
+    compare_result(eng.download(db), orc, batch.n)
+    eng.set_windows(db)                      # detached again: plain range search
+    eng.search_device(db)
+    compare_result(eng.download(db), run_oracle({}, chroms, batch), batch.n)
+    eng.free_device_batch(db)
 
 
 def test_empty_and_tiny_inputs(engine_factory, small_ref):
