@@ -23,7 +23,7 @@ if ROOT not in sys.path:
 
 CHR20_LEN = 62_435_964       # demo/hs_ref_chr20.fa.fai:1
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TRAFFIC_FILE = "v5_hbm_traffic.json"
+TRAFFIC_FILE = "v6_hbm_traffic.json"
 
 
 def cpu_baseline(chroms, batch, params_kw, budget_s=15.0, bd=None, bd_off=None):

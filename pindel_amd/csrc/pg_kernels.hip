@@ -61,6 +61,9 @@ typedef unsigned int u32;
 #define PT_DECL
 #define PT_MARK(k)
 #endif
+#ifndef PG_N_XCD
+#define PG_N_XCD 8u        // MI355X: 8 accelerator complex dies, 32 CUs and one L2 each
+#endif
 #ifndef PG_WAVES_PER_EU
 #define PG_WAVES_PER_EU 5   // register budget the kernel is compiled for (waves per SIMD): 96 VGPRs
 #endif
@@ -783,8 +786,17 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
-    const uint32_t rid = B.first_read + blockIdx.x;
     if (blockIdx.x >= B.n_reads) return;
+    // XCD-aware read order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so
+    // workgroup b runs on XCD b % 8.  Give every XCD a CONTIGUOUS eighth of the reads: the per-read input
+    // and output fields of neighbouring reads share cache lines, which then live in one L2 instead of
+    // being fetched and written back by up to eight.
+    uint32_t local = blockIdx.x;
+    {
+        const uint32_t per = B.n_reads / PG_N_XCD;
+        if (local < per * PG_N_XCD) local = (local % PG_N_XCD) * per + local / PG_N_XCD;
+    }
+    const uint32_t rid = B.first_read + local;
 
     const PgLdsLayout lay = pg_lds_layout(max_len, levels, NB, (uint32_t)sizeof(Cell));
     Search<Cell> S;
