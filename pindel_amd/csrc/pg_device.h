@@ -83,7 +83,7 @@ struct PgDevBatch {
 
 // Dynamic LDS layout (bytes), computed identically on host and device.
 struct PgLdsLayout {
-    uint32_t hist_off, carry_off, pref_off, queue_off, win_off, eq_off, qp_off, runs_off, total;
+    uint32_t hist_off, carry_off, queue_off, win_off, eq_off, qp_off, runs_off, total;
     uint32_t lh;        // histogram row length (max read length in the launch + 1)
     uint32_t levels;    // max TOTAL_SNP_ERROR_CHECKED in the launch
     uint32_t win_words; // LDS window capacity in 32-base words
@@ -106,8 +106,7 @@ PgLdsLayout pg_lds_layout(uint32_t max_len, uint32_t levels, uint32_t nb, uint32
     l.levels = levels;
     l.hist_off = 0;
     l.carry_off = (l.hist_off + l.levels * l.lh * cell + 15u) & ~15u;        // ginit[16] + carry[16]
-    l.pref_off = l.carry_off + 2u * PG_MAX_LEVELS * cell;           // pref[levels][64]
-    l.queue_off = l.pref_off + (cell == 8u ? l.levels * 64u * cell : 0u);   // (64-bit cells only); queue[192]
+    l.queue_off = l.carry_off + 2u * PG_MAX_LEVELS * cell;          // queue[192]
     l.win_off = (l.queue_off + 192u * 4u + 15u) & ~15u;              // window (stays valid during evaluate)
     // chunk + overhang of nb 64-base blocks on both sides + alignment slack
     l.win_words = PG_WIN_WORDS(nb);

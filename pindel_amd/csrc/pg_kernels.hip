@@ -121,6 +121,24 @@ __device__ __forceinline__ u32 wave_scan(u32 v)
     return v;
 }
 
+__device__ __forceinline__ u64 wave_scan(u64 v)
+{
+    v += row_shr<1>(v);
+    v += row_shr<2>(v);
+    v += row_shr<4>(v);
+    v += row_shr<8>(v);
+    v += (u64)(u32)__builtin_amdgcn_update_dpp(0, (int)(u32)v, 0x142, 0xa, 0xf, false) |
+         ((u64)(u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(v >> 32), 0x142, 0xa, 0xf, false) << 32);
+    v += (u64)(u32)__builtin_amdgcn_update_dpp(0, (int)(u32)v, 0x143, 0xc, 0xf, false) |
+         ((u64)(u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(v >> 32), 0x143, 0xc, 0xf, false) << 32);
+    return v;
+}
+__device__ __forceinline__ u32 read_lane(u32 v, int l) { return (u32)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ u64 read_lane(u64 v, int l)
+{
+    return (u64)read_lane((u32)v, l) | ((u64)read_lane((u32)(v >> 32), l) << 32);
+}
+
 // tells the compiler a value is wave-uniform (keeps it in SGPRs)
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // An opaque copy of a per-lane value: expressions built on it cannot be hoisted out of the enclosing
@@ -192,7 +210,6 @@ struct Search {
     Cell *hist;    // G difference histogram [T][lh]
     Cell *ginit;   // [PG_MAX_LEVELS] candidates entering at level k (at L = bps)
     Cell *carry;   // [PG_MAX_LEVELS] running prefix per level during evaluate
-    Cell *pref;    // [T][64] absolute G of the current 64-length round (aliases win/queue)
     u32 *queue;    // [192] compacted survivors of the prefilter
     uint4 *win;    // staged window: code planes (lo, hi, N)
     u32 *eq;       // staged window: one-hot planes [5][eq_stride]
@@ -571,16 +588,9 @@ __device__ __forceinline__ int evaluate(const PgDevRef &ref, const PgDevParams &
         if (lane < S.T) S.carry[lane] = g;
     }
     __syncthreads();
-    // 32-bit cells: lanes own L and one DPP wave scan per level turns the differences into G[k](L);
-    // lane k of cv carries G[k] at the end of the previous 64-length round.
-    // 64-bit cells: lanes as (level, chunk) for the prefix over L: 8 chunks of 8 cells per level
-    // (T <= 8), else 4 chunks of 16 cells; a level's lanes sit inside one 16-lane row (DPP row scans)
-    constexpr bool SCAN32 = sizeof(Cell) == 4;
-    const int CPL = S.T <= 8 ? 8 : 4;            // chunks per level
-    const int pk = lane / CPL, pc = lane & (CPL - 1);
-    const bool pact = pk < S.T;
-    u32 cv = 0u;
-    if (SCAN32) cv = lane < S.T ? (u32)S.carry[lane] : 0u;
+    // Lanes own L and one DPP wave scan per level turns the differences into G[k](L); lane k of cv
+    // carries G[k] at the end of the previous 64-length round.
+    Cell cv = lane < S.T ? S.carry[lane] : (Cell)0;
     bool aborted = false;
     for (int r0 = S.bps; r0 <= S.len - 1 && !aborted; r0 += WAVE) {
         const int L = r0 + lane;
@@ -588,53 +598,26 @@ __device__ __forceinline__ int evaluate(const PgDevRef &ref, const PgDevParams &
         int lo = -1;
         u32 cnt_lo = 0, sumw = 0;
         u64 id_lo = 0;
-        if (SCAN32) {
-            u32 zc = 0u, n1 = 0u, idr = 0u;
+        {
+            u32 zc = 0u, n1 = 0u;
+            Cell gid = 0;
             for (int k = 0; k < S.T; k++) {
-                const u32 d = valid ? (u32)S.hist[k * S.lh + L] : 0u;
-                const u32 ck = (u32)__builtin_amdgcn_readlane((int)cv, k);
-                const u32 g = wave_scan(d) + ck;
-                const u32 g63 = (u32)__builtin_amdgcn_readlane((int)g, 63);
+                const Cell d = valid ? S.hist[k * S.lh + L] : (Cell)0;
+                const Cell g = wave_scan(d) + read_lane(cv, k);
+                const Cell g63 = read_lane(g, 63);
                 cv = lane == k ? g63 : cv;
                 // G[k](L) is non-decreasing in k, so three counters say everything the rules need:
                 // zc = levels <= M with G = 0 (= the lowest non-empty level, M+1 if none), n1 = levels
                 // with G = 1 (a block starting at zc when G[zc] = 1, hence G[zc] = G[zc+ADD] = 1 <=>
                 // n1 > ADD) and the candidate id of any level with G = 1 (the same single candidate)
-                const u32 cnt = g & ((1u << F::CB) - 1u);
+                const u32 cnt = (u32)(g & (Cell)((1ull << F::CB) - 1ull));
                 zc += (k <= S.M && cnt == 0u) ? 1u : 0u;
                 n1 += cnt == 1u ? 1u : 0u;
-                idr = cnt == 1u ? (g >> F::CB) : idr;
+                gid = cnt == 1u ? g : gid;
             }
             lo = (int)zc <= S.M ? (int)zc : -1;
             cnt_lo = sumw = n1 > (u32)S.add_mm ? 1u : 0u;
-            id_lo = (u64)idr;
-        } else {
-            // ---- phase 1: absolute G[k](L) for L in [r0, r0+64) into pref[k][L-r0]
-            const int nvalid = S.len - r0 < WAVE ? S.len - r0 : WAVE;   // lengths r0 .. len-1
-            const int CS = (nvalid + CPL - 1) / CPL;                     // cells per chunk
-            const int j0 = pc * CS, j1 = (j0 + CS < WAVE) ? j0 + CS : WAVE;
-            const Cell *row = S.hist + pk * S.lh + r0;
-            Cell tot = 0;
-            if (pact)
-                for (int j = j0; j < j1; j++)
-                    if (r0 + j <= S.len - 1) tot += row[j];
-            const Cell inc = group_scan<Cell>(tot, pc, CPL);
-            Cell acc = pact ? (Cell)(S.carry[pk] + inc - tot) : (Cell)0;
-            if (pact)
-                for (int j = j0; j < j1; j++) {
-                    if (r0 + j <= S.len - 1) acc += row[j];
-                    S.pref[pk * WAVE + j] = acc;
-                }
-            __syncthreads();
-            if (pact && pc == CPL - 1) S.carry[pk] = acc;
-            __syncthreads();
-            // ---- phase 2: lanes own L
-            for (int i = 0; i < S.T; i++) {
-                Cell c = valid ? S.pref[i * WAVE + lane] : (Cell)0;
-                u32 cnt = (u32)(c & (Cell)((1ull << F::CB) - 1ull));
-                if (lo < 0 && i <= S.M && cnt > 0) { lo = i; cnt_lo = cnt; }
-                if (lo >= 0 && i == lo + S.add_mm) { sumw = cnt; id_lo = (u64)(c >> F::CB); }
-            }
+            id_lo = (u64)(gid >> F::CB);
         }
         int mmL = 0;                                  // g_maxMismatch[L] (<= M for L <= len)
         for (int k = 0; k < S.M; k++) mmL += (valid && (u32)L >= prm.mm_bp[k]) ? 1 : 0;
@@ -803,7 +786,6 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
     S.hist = (Cell *)(smem + lay.hist_off);
     S.ginit = (Cell *)(smem + lay.carry_off);
     S.carry = S.ginit + PG_MAX_LEVELS;
-    S.pref = (Cell *)(smem + lay.pref_off);
     S.queue = (u32 *)(smem + lay.queue_off);
     S.win = (uint4 *)(smem + lay.win_off);
     S.eq = (u32 *)(smem + lay.eq_off);
