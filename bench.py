@@ -70,7 +70,7 @@ def valu_issue(args, kernel_ms):
     """The kernel is VALU-issue bound, not HBM bound: VALU instructions per read from
     the committed PMC pass x 4 cycles per wave64 instruction over 1024 SIMDs at 2.4 GHz, against the kernel
     time measured in this run.  None for workloads the PMC pass was not taken on."""
-    path = os.path.join(ROOT, "profiles", "r01", "v5_pmc_per_read.txt")
+    path = os.path.join(ROOT, "profiles", "r01", "v6_pmc_per_read.txt")
     if (args.read_len != 100 or args.max_range_index != 2 or args.workload != "sv10m" or not os.path.exists(path)
             or kernel_ms <= 0):
         return None
@@ -84,7 +84,7 @@ def valu_issue(args, kernel_ms):
         return None
     issue_ms = valu * args.reads * 4.0 / (1024 * 2.4e9) * 1e3
     return {"valu_insts_per_read": valu, "valu_issue_ms": issue_ms, "valu_busy_frac": issue_ms / kernel_ms,
-            "source": "profiles/r01/v5_pmc_per_read.txt (SQ_INSTS_VALU), 256 CUs x 4 SIMDs, 4 cycles per wave64 VALU instruction, 2.4 GHz"}
+            "source": "profiles/r01/v6_pmc_per_read.txt (SQ_INSTS_VALU), 256 CUs x 4 SIMDs, 4 cycles per wave64 VALU instruction, 2.4 GHz"}
 
 
 def main():
