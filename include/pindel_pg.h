@@ -150,6 +150,12 @@ int  pg_load_reference(pg_ctx *ctx, int32_t n_chr, const char *const *names,
                        const uint8_t *const *seq_padded, const uint64_t *len_padded);
 /* FASTA loader with Genome::loadChromosome's semantics (pindel.cpp:272-312). */
 int  pg_load_fasta(pg_ctx *ctx, const char *path);
+/* Packed reference cache: writes / reads the loaded reference as the bit planes it
+ * occupies in HBM, so that a genome is packed from FASTA once (Genome::loadChromosome semantics,
+ * src/pindel.cpp:272-312, via pg_load_fasta) instead of being parsed character by character on every
+ * run.  The file records the spacer it was packed with; loading it into a ctx with another spacer fails. */
+int  pg_reference_save_packed(const pg_ctx *ctx, const char *path);
+int  pg_reference_load_packed(pg_ctx *ctx, const char *path);
 int  pg_reference_n_chr(const pg_ctx *ctx);
 const char *pg_reference_name(const pg_ctx *ctx, int32_t chr_id);
 uint64_t pg_reference_comp_size(const pg_ctx *ctx, int32_t chr_id);   /* getCompSize() */

@@ -62,7 +62,7 @@ assert RUN_DTYPE.itemsize == 12 and POINT_DTYPE.itemsize == 12 and WINDOW_DTYPE.
 # every symbol include/pindel_pg.h declares
 EXPORTS = [
     "pg_default_params", "pg_create", "pg_destroy", "pg_last_error", "pg_get_max_mismatch",
-    "pg_load_reference", "pg_load_fasta", "pg_reference_n_chr", "pg_reference_name",
+    "pg_load_reference", "pg_load_fasta", "pg_reference_save_packed", "pg_reference_load_packed", "pg_reference_n_chr", "pg_reference_name",
     "pg_reference_comp_size", "pg_reference_fetch", "pg_close_end_batch", "pg_far_end_batch",
     "pg_search_batch", "pg_result_view_get", "pg_result_free", "pg_expand_runs",
     "pg_device_batch_upload", "pg_device_batch_set_windows", "pg_device_batch_search", "pg_device_batch_download",
@@ -111,6 +111,8 @@ def lib():
     L.pg_get_max_mismatch.argtypes = [vp, vp]
     L.pg_load_reference.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(vp), C.POINTER(u64)]
     L.pg_load_fasta.argtypes = [vp, C.c_char_p]
+    L.pg_reference_save_packed.argtypes = [vp, C.c_char_p]
+    L.pg_reference_load_packed.argtypes = [vp, C.c_char_p]
     L.pg_reference_n_chr.argtypes = [vp]
     L.pg_reference_name.argtypes = [vp, i32]
     L.pg_reference_name.restype = C.c_char_p
@@ -262,6 +264,12 @@ class Engine:
 
     def load_fasta(self, path):
         self._check(self._L.pg_load_fasta(self._h, str(path).encode()))
+
+    def save_packed(self, path):
+        self._check(self._L.pg_reference_save_packed(self._h, str(path).encode()))
+
+    def load_packed(self, path):
+        self._check(self._L.pg_reference_load_packed(self._h, str(path).encode()))
 
     def reference_info(self):
         n = self._L.pg_reference_n_chr(self._h)

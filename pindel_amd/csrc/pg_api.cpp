@@ -480,6 +480,23 @@ int download(pg_ctx *ctx, pg_device_batch *b, pg_result *r)
     return cleanup(PG_OK);
 }
 
+// Copies the packed planes and the chromosome tables of the ctx to the device.
+int upload_reference(pg_ctx *ctx)
+{
+    std::vector<uint32_t> sizes(ctx->comp_size.size());
+    for (size_t c = 0; c < sizes.size(); c++) sizes[c] = (uint32_t)ctx->comp_size[c];
+    int rc;
+    if ((rc = dev_upload(ctx, &ctx->d_lo, ctx->h_lo.data(), ctx->h_lo.size())) ||
+        (rc = dev_upload(ctx, &ctx->d_hi, ctx->h_hi.data(), ctx->h_hi.size())) ||
+        (rc = dev_upload(ctx, &ctx->d_nn, ctx->h_nn.data(), ctx->h_nn.size())) ||
+        (rc = dev_upload(ctx, &ctx->d_word_off, ctx->word_off.data(), ctx->word_off.size())) ||
+        (rc = dev_upload(ctx, &ctx->d_chr_size, sizes.data(), sizes.size()))) {
+        free_reference(ctx);
+        return rc;
+    }
+    return PG_OK;
+}
+
 }  // namespace
 
 // ============================================================================== C ABI
@@ -614,18 +631,87 @@ int pg_load_reference(pg_ctx *ctx, int32_t n_chr, const char *const *names,
             lo[w] = l; hi[w] = h; nn[w] = n;
         }
     }
-    std::vector<uint32_t> sizes(n_chr);
-    for (int c = 0; c < n_chr; c++) sizes[c] = (uint32_t)len_padded[c];
-    int rc;
-    if ((rc = dev_upload(ctx, &ctx->d_lo, ctx->h_lo.data(), ctx->h_lo.size())) ||
-        (rc = dev_upload(ctx, &ctx->d_hi, ctx->h_hi.data(), ctx->h_hi.size())) ||
-        (rc = dev_upload(ctx, &ctx->d_nn, ctx->h_nn.data(), ctx->h_nn.size())) ||
-        (rc = dev_upload(ctx, &ctx->d_word_off, ctx->word_off.data(), ctx->word_off.size())) ||
-        (rc = dev_upload(ctx, &ctx->d_chr_size, sizes.data(), sizes.size()))) {
-        free_reference(ctx);
-        return rc;
+    return upload_reference(ctx);
+}
+
+// ---- packed reference on disk: the bit planes exactly as they sit in HBM, so a
+// genome is packed from FASTA once (Genome::loadChromosome semantics, pg_load_fasta) and mapped back
+// in seconds.  Layout: magic, spacer, n_chr, per chromosome {name length, name, padded size, word
+// offset}, number of words, then the lo / hi / N planes.
+static const char PG_REF_MAGIC[8] = { 'P', 'G', 'R', 'E', 'F', '0', '1', 0 };
+
+int pg_reference_save_packed(const pg_ctx *ctx, const char *path)
+{
+    if (!ctx || !path) return PG_E_INVALID;
+    if (ctx->names.empty()) return PG_E_NO_REFERENCE;
+    FILE *f = fopen(path, "wb");
+    if (!f) return PG_E_INVALID;
+    bool ok = fwrite(PG_REF_MAGIC, 1, 8, f) == 8;
+    const uint32_t spacer = ctx->prm.spacer, n_chr = (uint32_t)ctx->names.size();
+    ok = ok && fwrite(&spacer, 4, 1, f) == 1 && fwrite(&n_chr, 4, 1, f) == 1;
+    for (uint32_t c = 0; c < n_chr && ok; c++) {
+        const uint32_t nl = (uint32_t)ctx->names[c].size();
+        ok = fwrite(&nl, 4, 1, f) == 1 && (nl == 0 || fwrite(ctx->names[c].data(), 1, nl, f) == nl) &&
+             fwrite(&ctx->comp_size[c], 8, 1, f) == 1 && fwrite(&ctx->word_off[c], 8, 1, f) == 1;
     }
-    return PG_OK;
+    const uint64_t nw = ctx->h_lo.size();
+    ok = ok && fwrite(&nw, 8, 1, f) == 1 && fwrite(ctx->h_lo.data(), 4, nw, f) == nw &&
+         fwrite(ctx->h_hi.data(), 4, nw, f) == nw && fwrite(ctx->h_nn.data(), 4, nw, f) == nw;
+    ok = (fclose(f) == 0) && ok;
+    return ok ? PG_OK : PG_E_INVALID;
+}
+
+int pg_reference_load_packed(pg_ctx *ctx, const char *path)
+{
+    if (!ctx || !path) return fail(ctx, PG_E_INVALID, "bad packed-reference arguments");
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(ctx, PG_E_INVALID, std::string("cannot open ") + path);
+    auto bad = [&](const char *why) {
+        fclose(f);
+        free_reference(ctx);
+        return fail(ctx, PG_E_INVALID, std::string(path) + ": " + why);
+    };
+    free_reference(ctx);
+    char magic[8];
+    uint32_t spacer = 0, n_chr = 0;
+    if (fread(magic, 1, 8, f) != 8 || memcmp(magic, PG_REF_MAGIC, 8) != 0) return bad("not a packed reference");
+    if (fread(&spacer, 4, 1, f) != 1 || fread(&n_chr, 4, 1, f) != 1) return bad("truncated header");
+    if (spacer != ctx->prm.spacer) return bad("packed with a different spacer");
+    if (n_chr == 0 || n_chr > 32767) return bad("bad chromosome count");
+    for (uint32_t c = 0; c < n_chr; c++) {
+        uint32_t nl = 0;
+        uint64_t size = 0, woff = 0;
+        if (fread(&nl, 4, 1, f) != 1 || nl > 4096) return bad("bad chromosome name");
+        std::string name(nl, ' ');
+        if ((nl && fread(&name[0], 1, nl, f) != nl) || fread(&size, 8, 1, f) != 1 || fread(&woff, 8, 1, f) != 1)
+            return bad("truncated chromosome table");
+        if (size >= 0xffffffffull || size < 2ull * spacer) return bad("bad chromosome size");
+        ctx->names.push_back(name);
+        ctx->comp_size.push_back(size);
+        ctx->word_off.push_back(woff);
+    }
+    uint64_t nw = 0, expect = 0;
+    for (uint32_t c = 0; c < n_chr; c++) {
+        expect += PG_GUARD_WORDS;
+        if (ctx->word_off[c] != expect) return bad("inconsistent word offsets");
+        expect += (ctx->comp_size[c] + 31) / 32 + PG_GUARD_WORDS;
+    }
+    expect += 8;
+    if (fread(&nw, 8, 1, f) != 1 || nw != expect) return bad("inconsistent plane size");
+    try {
+        ctx->h_lo.resize(nw);
+        ctx->h_hi.resize(nw);
+        ctx->h_nn.resize(nw);
+    } catch (...) {
+        fclose(f);
+        free_reference(ctx);
+        return fail(ctx, PG_E_NOMEM, "host memory for the packed reference");
+    }
+    if (fread(ctx->h_lo.data(), 4, nw, f) != nw || fread(ctx->h_hi.data(), 4, nw, f) != nw ||
+        fread(ctx->h_nn.data(), 4, nw, f) != nw)
+        return bad("truncated planes");
+    fclose(f);
+    return upload_reference(ctx);
 }
 
 int pg_load_fasta(pg_ctx *ctx, const char *path)

@@ -269,3 +269,31 @@ print("ok", multi)
 """
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert res.returncode == 0 and "ok" in res.stdout, res.stdout + res.stderr
+
+
+def test_packed_reference_cache_roundtrip(engine_factory, small_ref, tmp_path):
+    """pg_reference_save_packed / pg_reference_load_packed: the planes written by one context, loaded by
+    another, give the same bases back and the same search results; wrong files are rejected."""
+    from pindel_amd.binding import PgError
+    chroms = [small_ref[0], ("second", synth.make_reference(300_000, seed=77))]
+    a = engine_factory()
+    a.load_reference(chroms)
+    path = tmp_path / "ref.pgref"
+    a.save_packed(path)
+    b = engine_factory()
+    b.load_packed(path)
+    assert b.reference_info() == a.reference_info()
+    for c, (_, seq) in enumerate(chroms):
+        for start in (0, 99_990, len(seq) - 4000):
+            assert b.reference_fetch(c, start, 3000) == bytes(seq[start:start + 3000])
+    batch = synth.make_reads(chroms[0][1], 1500, seed=78)
+    ra, rb = a.search_batch(batch), b.search_batch(batch)
+    assert ra.close_runs.tobytes() == rb.close_runs.tobytes() and ra.far_runs.tobytes() == rb.far_runs.tobytes()
+    assert np.array_equal(ra.close_off, rb.close_off) and np.array_equal(ra.far_off, rb.far_off)
+    compare_result(rb, run_oracle({}, chroms, batch), batch.n)
+    bad = tmp_path / "bad.pgref"
+    bad.write_bytes(path.read_bytes()[:1000])
+    with pytest.raises(PgError):
+        engine_factory().load_packed(bad)
+    with pytest.raises(PgError):
+        engine_factory(spacer=50000).load_packed(path)
