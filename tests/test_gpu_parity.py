@@ -297,3 +297,37 @@ def test_packed_reference_cache_roundtrip(engine_factory, small_ref, tmp_path):
         engine_factory().load_packed(bad)
     with pytest.raises(PgError):
         engine_factory(spacer=50000).load_packed(path)
+
+
+def test_many_chromosomes_150bp(engine_factory):
+    """BASELINE configs[3]-shaped at small scale: 24 chromosomes, 150 bp reads spread over all of them
+    (chr_id selects the reference planes, results carry the chromosome of every run)."""
+    from pindel_amd.hostio import ReadBatch
+    chroms = [(f"chr{c + 1}", synth.make_reference(250_000 + 10_000 * c, seed=500 + c, n_gaps=1, gap_len=5000))
+              for c in range(24)]
+    eng = engine_factory()
+    eng.load_reference(chroms)
+    parts = [synth.make_reads(chroms[c][1], 250, seed=600 + c, read_len=150, chr_id=c, max_del=3000) for c in range(24)]
+    off = [np.zeros(1, dtype=np.uint64)]
+    base = 0
+    for p_ in parts:
+        off.append(p_.seq_off[1:] + np.uint64(base))
+        base += int(p_.seq_off[-1])
+    batch = ReadBatch(seq=np.concatenate([p_.seq for p_ in parts]), seq_off=np.concatenate(off),
+                      anchor_strand=np.concatenate([p_.anchor_strand for p_ in parts]),
+                      anchor_pos=np.concatenate([p_.anchor_pos for p_ in parts]),
+                      insert_size=np.concatenate([p_.insert_size for p_ in parts]),
+                      chr_id=np.concatenate([p_.chr_id for p_ in parts]))
+    # interleave the chromosomes so that neighbouring reads use different reference planes
+    perm = np.random.default_rng(3).permutation(batch.n)
+    lens = batch.lengths()
+    o = batch.seq_off.astype(np.int64)
+    seq = np.concatenate([batch.seq[o[i]:o[i + 1]] for i in perm])
+    batch = ReadBatch(seq=seq, seq_off=np.concatenate([[0], np.cumsum(lens[perm])]).astype(np.uint64),
+                      anchor_strand=batch.anchor_strand[perm], anchor_pos=batch.anchor_pos[perm],
+                      insert_size=batch.insert_size[perm], chr_id=batch.chr_id[perm])
+    gpu = eng.search_batch(batch)
+    orc = run_oracle({}, chroms, batch)
+    assert (orc["close_cnt"] > 0).sum() > 3000 and (orc["far_cnt"] > 0).sum() > 2000
+    assert len(set(gpu.close_runs["chr_id"].tolist())) == 24
+    compare_result(gpu, orc, batch.n)
