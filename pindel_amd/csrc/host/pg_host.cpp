@@ -1,6 +1,9 @@
 // pg_host.cpp -- loaders, SV classifiers and text reporters (see pg_host.hpp).
 #include "pg_host_priv.hpp"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cctype>
 #include <cmath>
@@ -637,17 +640,34 @@ void Caller::process_window(const Chromosome &chrom, std::vector<SplitRead> &rea
             r.MatchedFarD = r.UP_Far[0].Strand;
         }
     }
+    // PGH_TIMING=1: wall-clock seconds per classifier on stderr (diagnostics)
+    static const bool timing = getenv("PGH_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t = now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const double t1 = now();
+        fprintf(stderr, "pgh timing: %-18s %.3f s (%zu reads)\n", what, t1 - t, reads.size());
+        t = t1;
+    };
     search_variant(c, 0);
+    lap("deletions");
     search_indels(c);
+    lap("indels (DI)");
     if (S.Analyze_TD) {
         search_tandem_dup(c);
+        lap("tandem dup");
         search_tandem_dup_nt(c);
+        lap("tandem dup NT");
     }
     if (S.Analyze_INV) {
         search_inversions(c);
+        lap("inversions");
         search_inversions_nt(c);
+        lap("inversions NT");
     }
     search_variant(c, 1);
+    lap("short insertions");
 }
 
 }  // namespace pgh

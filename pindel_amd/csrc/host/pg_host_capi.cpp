@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "pg_host.hpp"
+#include "pg_host_priv.hpp"
 #include "pg_pipeline.hpp"
 #include "pindel_pg.h"
 
@@ -83,6 +84,21 @@ int pgh_call_from_points(const char *fasta_path, const char *reads_path, const c
         return 0;
     };
     return run_pipeline(genome, fai, all, S, out_prefix, attach, g_err);
+}
+
+// Test hook (tests/test_cpu_suite.py): sorts indices 0..n-1 by keys[] with the reference's O(n^2)
+// exchange sort and with its fast equivalent; the two outputs must be identical.
+void pgh_test_exchange_sort(const int32_t *keys, uint32_t n, uint32_t *out_reference, uint32_t *out_fast)
+{
+    std::vector<unsigned> a(n), b(n);
+    for (uint32_t i = 0; i < n; i++) a[i] = b[i] = i;
+    auto less = [&](unsigned x, unsigned y) { return keys[x] < keys[y]; };
+    pgh::detail::exchange_sort_reference(a, less);
+    pgh::detail::exchange_sort_fast(b, less);
+    for (uint32_t i = 0; i < n; i++) {
+        out_reference[i] = a[i];
+        out_fast[i] = b[i];
+    }
 }
 
 }  // extern "C"

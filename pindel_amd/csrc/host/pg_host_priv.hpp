@@ -4,6 +4,9 @@
 
 #include <sstream>
 #include <string>
+#include <algorithm>
+#include <functional>
+#include <unordered_set>
 #include <vector>
 
 #include "pg_host.hpp"
@@ -115,27 +118,55 @@ inline bool smaller(const SplitRead &a, const SplitRead &b)
     return false;
 }
 
-// bubblesortReads, src/reporter.cpp:932-942: an exchange sort that also swaps equal elements.
-// Reproduced as is, because the (unstable) order of equal reads is visible in the report.
-inline void exchange_sort(const std::vector<SplitRead> &reads, std::vector<unsigned> &idx)
+// bubblesortReads, src/reporter.cpp:932-942: an exchange sort that also swaps EQUAL elements,
+//     for a < b: if (!smaller(x[a], x[b])) swap(x[a], x[b])
+// Its (unstable-looking) order of equal reads is visible in the reports, so it has to be reproduced
+// exactly -- but not in O(n^2): that loop leaves the elements sorted by key with equal elements in the
+// REVERSE of their original order, i.e. it equals a stable sort of the reversed sequence.  (Each pass
+// moves the last of the minimal elements to the front and shifts the others of its class one place
+// down the chain; tests/test_cpu_suite.py checks the two against each other on random inputs.)
+template <class Less>
+inline void exchange_sort_reference(std::vector<unsigned> &idx, Less less)      // the O(n^2) original
 {
     const size_t n = idx.size();
     for (size_t a = 0; a + 1 < n; a++)
         for (size_t b = a + 1; b < n; b++)
-            if (!smaller(reads[idx[a]], reads[idx[b]])) std::swap(idx[a], idx[b]);
+            if (!less(idx[a], idx[b])) std::swap(idx[a], idx[b]);
+}
+template <class Less>
+inline void exchange_sort_fast(std::vector<unsigned> &idx, Less less)
+{
+    std::reverse(idx.begin(), idx.end());
+    std::stable_sort(idx.begin(), idx.end(), less);
+}
+inline void exchange_sort(const std::vector<SplitRead> &reads, std::vector<unsigned> &idx)
+{
+    exchange_sort_fast(idx, [&](unsigned a, unsigned b) { return smaller(reads[a], reads[b]); });
 }
 
-// markDuplicates, src/reporter.cpp:946-972
+// markDuplicates, src/reporter.cpp:946-972: walking the sorted box, a read that is still unique makes
+// every LATER read with the same (Left, Right, Name) non-unique.  So within a (Left, Right, Name)
+// class everything behind its first unique member is cleared: one hash lookup per read.
 inline void mark_duplicates(std::vector<SplitRead> &reads, const std::vector<unsigned> &idx)
 {
-    const size_t n = idx.size();
-    for (size_t a = 0; a + 1 < n; a++) {
-        SplitRead &x = reads[idx[a]];
-        if (!x.UniqueRead) continue;
-        for (size_t b = a + 1; b < n; b++) {
-            SplitRead &y = reads[idx[b]];
-            if (x.Left == y.Left && x.Right == y.Right && x.Name == y.Name) y.UniqueRead = false;
+    struct Key {
+        unsigned left, right;
+        const std::string *name;
+        bool operator==(const Key &o) const { return left == o.left && right == o.right && *name == *o.name; }
+    };
+    struct Hash {
+        size_t operator()(const Key &k) const
+        {
+            return std::hash<std::string>()(*k.name) ^ ((size_t)k.left * 0x9e3779b97f4a7c15ull) ^ ((size_t)k.right << 21);
         }
+    };
+    std::unordered_set<Key, Hash> seen_unique;
+    seen_unique.reserve(idx.size() * 2);
+    for (unsigned i : idx) {
+        SplitRead &x = reads[i];
+        const Key k = { x.Left, x.Right, &x.Name };
+        if (seen_unique.count(k)) x.UniqueRead = false;
+        else if (x.UniqueRead) seen_unique.insert(k);
     }
 }
 

@@ -185,18 +185,8 @@ void Caller::sort_output_td(Ctx &c, std::vector<std::vector<unsigned>> &boxes, b
     for (unsigned b = 0; b < c.NumBoxes; b++) {
         std::vector<unsigned> &box = boxes[b];
         if (box.empty() || box.size() < S.NumRead2ReportCutOff) continue;
-        const size_t n = box.size();
-        for (size_t a = 0; a + 1 < n; a++)               // bubblesortReads
-            for (size_t d = a + 1; d < n; d++)
-                if (!smaller(reads[box[a]], reads[box[d]])) std::swap(box[a], box[d]);
-        for (size_t a = 0; a + 1 < n; a++) {             // markDuplicates
-            SplitRead &x = reads[box[a]];
-            if (!x.UniqueRead) continue;
-            for (size_t d = a + 1; d < n; d++) {
-                SplitRead &y = reads[box[d]];
-                if (x.Left == y.Left && x.Right == y.Right && x.Name == y.Name) y.UniqueRead = false;
-            }
-        }
+        exchange_sort(reads, box);                       // bubblesortReads
+        mark_duplicates(reads, box);                     // markDuplicates
         std::vector<SplitRead> good;
         for (unsigned i : box)
             if (reads[i].UniqueRead) good.push_back(reads[i]);

@@ -7,6 +7,7 @@
 // not built here.
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -18,8 +19,15 @@
 
 using namespace pgh;
 
+static double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 int main(int argc, char **argv)
 {
+    const double t_start = now_s();
+    double t_search = 0.0;
     std::string fasta, reads_path, prefix;
     pg_params prm;
     pg_default_params(&prm);
@@ -88,6 +96,7 @@ int main(int argc, char **argv)
     S.spacer = prm.spacer;
     pg_get_max_mismatch(ctx, S.max_mismatch);
     std::vector<unsigned> fai = read_fai(fasta, genome);
+    const double t_loaded = now_s();
     auto chr_of = [](const SplitRead &r) { return r.chr_id; };
     auto make_point = [](const pg_point &p) {
         UniquePoint u;
@@ -101,6 +110,7 @@ int main(int argc, char **argv)
     };
     size_t n_close = 0, n_far = 0;
     auto search = [&](const Chromosome &, int, std::vector<SplitRead> &reads, const std::vector<uint32_t> &) {
+        const double t0 = now_s();
         pg_result *res = nullptr;
         int r = pg_adapter::CloseEndBatch(ctx, reads, chr_of, make_point, &res);      // ReadBuffer::flush
         if (r) return r;
@@ -110,11 +120,17 @@ int main(int argc, char **argv)
             n_close += !x.UP_Close.empty();
             n_far += !x.UP_Far.empty();
         }
+        t_search += now_s() - t0;
         return r;
     };
     rc = run_pipeline(genome, fai, all, S, prefix, search, err);
     if (rc) fprintf(stderr, "pindel_pg: %s (%s)\n", err.c_str(), pg_last_error(ctx));
-    else printf("pindel_pg: %zu reads, close end %zu, far end %zu\n", all.size(), n_close, n_far);
+    else {
+        printf("pindel_pg: %zu reads, close end %zu, far end %zu\n", all.size(), n_close, n_far);
+        // the phases the reference's Timer reports (pindel.cpp:1990-1996), wall-clock seconds
+        printf("pindel_pg: loading %.2f s, split-read search (GPU, incl. adapters) %.2f s, classification + reports %.2f s\n",
+               t_loaded - t_start, t_search, now_s() - t_loaded - t_search);
+    }
     pg_destroy(ctx);
     return rc ? 1 : 0;
 }

@@ -93,3 +93,23 @@ def test_oracle_edge_cases():
     rt = pyoracle.search_batch(p, [ref[0][1]], tiny.seq, tiny.seq_off, tiny.anchor_strand, tiny.anchor_pos,
                                tiny.insert_size, tiny.chr_id)
     assert rt["close_cnt"][0] == 0 and rt["far_cnt"][0] == 0
+
+
+def test_fast_exchange_sort_equals_the_reference_loop():
+    """The reporters' order of equal reads comes from the reference's O(n^2) exchange sort that also
+    swaps equal elements (reporter.cpp:932-942); the host library replaces it by a stable sort of the
+    reversed sequence -- identical permutation on random inputs with many ties."""
+    import ctypes as C
+    from pindel_amd import hostlib
+    L = hostlib.lib()
+    L.pgh_test_exchange_sort.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.pgh_test_exchange_sort.restype = None
+    rng = np.random.default_rng(11)
+    for trial in range(400):
+        n = int(rng.integers(0, 200))
+        keys = rng.integers(0, int(rng.integers(1, 12)), n).astype(np.int32)
+        a = np.zeros(n, dtype=np.uint32)
+        b = np.zeros(n, dtype=np.uint32)
+        L.pgh_test_exchange_sort(keys.ctypes.data, n, a.ctypes.data, b.ctypes.data)
+        assert np.array_equal(a, b), (trial, keys.tolist())
+        assert np.all(np.diff(keys[a]) >= 0)
