@@ -25,7 +25,7 @@ raw = np.zeros(n, dtype=np.uint32)
 L.pg_debug_read_alg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
 assert L.pg_debug_read_alg(eng._h, db, raw.ctypes.data, n) == 0
 d = raw[n - 65536 * 16:].reshape(65536, 16).astype(np.float64)
-names = ["load planes", "scan (stage+filter+dense)", "evaluate", "publish/clean", "zero hist", "configure", "first_base_ok + tail", "next step + loop top"]
+names = ["load planes", "scan (stage+filter+dense)", "evaluate", "publish/clean", "zero hist", "configure", "tail", "-"]
 for k, kern in ((0, "close kernel"), (8, "far kernel")):
     tot = d[:, k:k + 8].sum(axis=1)
     print(kern, "mean cycles per read", round(tot.mean()))
