@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 
+#include "pg_bdhints.hpp"
 #include "pg_host.hpp"
 #include "pg_host_priv.hpp"
 #include "pg_pipeline.hpp"
@@ -84,6 +85,36 @@ int pgh_call_from_points(const char *fasta_path, const char *reads_path, const c
         return 0;
     };
     return run_pipeline(genome, fai, all, S, out_prefix, attach, g_err);
+}
+
+// BreakDancer hints (pg_bdhints.hpp) for one bin: clusters of the reads whose last close-end point is at
+// q[i].  out_off has n_q + 1 entries, out_win 3 ints (chr id, start, end) per window; returns the status
+// of load_file (0 / 1 = ignored), -1 = cannot open, -2 = unknown chromosome, -3 = out_win too small.
+int pgh_bd_query(const char *path, uint32_t spacer, int32_t n_chr, const char *const *names, int32_t chr_id,
+                 uint32_t start, uint32_t end, uint32_t n_q, const uint32_t *q, uint64_t *out_off,
+                 int32_t *out_win, uint64_t cap, uint64_t *n_events)
+{
+    pgh::BDHints h;
+    std::string note;
+    const int rc = h.load_file(path, spacer, note);
+    if (n_events) *n_events = h.n_events();
+    g_err = note;
+    if (rc < 0) return -1;
+    std::vector<std::string> nm(names, names + n_chr);
+    if (!h.load_region(nm, chr_id, start, end, g_err)) return -2;
+    uint64_t k = 0;
+    out_off[0] = 0;
+    for (uint32_t i = 0; i < n_q; i++) {
+        for (const pgh::BDWindow &w : h.cluster(q[i])) {
+            if (k >= cap) return -3;
+            out_win[3 * k] = w.chr_id;
+            out_win[3 * k + 1] = (int32_t)w.start;
+            out_win[3 * k + 2] = (int32_t)w.end;
+            k++;
+        }
+        out_off[i + 1] = k;
+    }
+    return rc;
 }
 
 // Test hook (tests/test_cpu_suite.py): sorts indices 0..n-1 by keys[] with the reference's O(n^2)

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "pg_adapter.hpp"
+#include "pg_bdhints.hpp"
 #include "pg_host.hpp"
 #include "pg_pipeline.hpp"
 #include "pindel_pg.h"
@@ -28,7 +29,8 @@ int main(int argc, char **argv)
 {
     const double t_start = now_s();
     double t_search = 0.0;
-    std::string fasta, reads_path, prefix;
+    std::string fasta, reads_path, prefix, bd_path;
+    bool use_bd = false;
     pg_params prm;
     pg_default_params(&prm);
     Settings S;
@@ -52,6 +54,8 @@ int main(int argc, char **argv)
         else if (f == "-w") S.window_mbp = atof(v);
         else if (f == "-G") prm.device = atoi(v);
         else if (f == "-T") { /* thread count: the search runs on the GPU */ }
+        else if (f == "-b") bd_path = v;                                     // --breakdancer
+        else if (f == "--bd-hints") use_bd = std::string(v) == "on";         // see below: off = what 0.2.5b9 does
         else {
             fprintf(stderr, "pindel_pg: unknown flag %s\n", f.c_str());
             return 2;
@@ -108,13 +112,60 @@ int main(int argc, char **argv)
         u.Mismatches = p.mismatches;
         return u;
     };
+    // -b: Pindel 0.2.5b9 loads the file but, for Pindel-text input, never hands its events to the far-end
+    // search.  That is the default here too.  "--bd-hints on" searches the windows of
+    // the file's events before the ranges, the way the BAM path of the reference does (pg_bdhints.hpp).
+    BDHints bd;
+    std::vector<std::string> chr_names;
+    for (const Chromosome &c : genome) chr_names.push_back(c.name);
+    if (!bd_path.empty()) {
+        std::string note;
+        const int brc = bd.load_file(bd_path, prm.spacer, note);
+        if (brc < 0) {
+            fprintf(stderr, "pindel_pg: %s\n", note.c_str());
+            return 1;
+        }
+        if (brc > 0) printf("pindel_pg: %s\n", note.c_str());
+        printf("pindel_pg: BD events: %zu%s\n", bd.n_events(), use_bd ? "" : " (not used for Pindel-text input; --bd-hints on to use them)");
+    }
     size_t n_close = 0, n_far = 0;
     auto search = [&](const Chromosome &, int, std::vector<SplitRead> &reads, const std::vector<uint32_t> &) {
         const double t0 = now_s();
         pg_result *res = nullptr;
         int r = pg_adapter::CloseEndBatch(ctx, reads, chr_of, make_point, &res);      // ReadBuffer::flush
         if (r) return r;
-        r = pg_adapter::SearchFarEnds(ctx, reads, chr_of, make_point, res, nullptr);    // SearchFarEnds
+        std::vector<uint64_t> hoff;
+        std::vector<pg_window> hwin;
+        pg_windows hints = { nullptr, nullptr };
+        if (use_bd && bd.n_events() && !reads.empty()) {
+            // the bin of these reads, as main() hands it to g_bdData.loadRegion (pindel.cpp:1828, 1853)
+            unsigned lo = reads[0].MatchedRelPos, hi = reads[0].MatchedRelPos;
+            for (const SplitRead &x : reads) {
+                lo = std::min(lo, x.MatchedRelPos);
+                hi = std::max(hi, x.MatchedRelPos);
+            }
+            const unsigned W = (unsigned)(S.window_mbp * 1000000);
+            const unsigned ws = lo / W * W, we = ws + W;
+            (void)hi;
+            std::string berr;
+            if (!bd.load_region(chr_names, reads[0].chr_id, ws + prm.spacer, we + prm.spacer, berr)) {
+                fprintf(stderr, "pindel_pg: %s\n", berr.c_str());
+                pg_result_free(res);
+                return (int)PG_E_INVALID;
+            }
+            hoff.push_back(0);
+            for (const SplitRead &x : reads) {
+                if (!x.UP_Close.empty())
+                    for (const BDWindow &w : bd.cluster(x.UP_Close.back().AbsLoc)) {
+                        pg_window pw = { w.chr_id, (int32_t)w.start, (int32_t)w.end };
+                        hwin.push_back(pw);
+                    }
+                hoff.push_back(hwin.size());
+            }
+            hints.offset = hoff.data();
+            hints.windows = hwin.empty() ? nullptr : hwin.data();
+        }
+        r = pg_adapter::SearchFarEnds(ctx, reads, chr_of, make_point, res, hints.offset ? &hints : nullptr);   // SearchFarEnds
         pg_result_free(res);
         for (const SplitRead &x : reads) {
             n_close += !x.UP_Close.empty();

@@ -113,3 +113,123 @@ def test_fast_exchange_sort_equals_the_reference_loop():
         L.pgh_test_exchange_sort(keys.ctypes.data, n, a.ctypes.data, b.ctypes.data)
         assert np.array_equal(a, b), (trial, keys.tolist())
         assert np.all(np.diff(keys[a]) >= 0)
+
+
+# ---- BreakDancer window hints (pindel_amd/csrc/host/pg_bdhints.hpp) against an independent restatement
+def _bd_restatement(lines, spacer, chr_names, chr_id, start, end, queries):
+    """bddata.cpp:91-136, 814-979 and control_state.cpp:71-131 restated in Python (PARITY UNPINNED: the
+    reference never uses -b events on the text-input path, so there is no reference output to compare with)."""
+    SPAN = 200
+    ev = []
+    for ln in lines:
+        if ln.startswith("#") or not ln.strip():
+            continue
+        f = ln.split()
+        c1, p1, c2, p2 = f[0], int(f[1]) + spacer, f[3], int(f[4]) + spacer
+        if c1 == c2 and abs(p1 - p2) < 500:
+            continue
+        ev.append((c1, p1, c2, p2))
+        ev.append((c2, p2, c1, p1))
+    ev.sort()
+    sow = lambda p: p - SPAN if p >= SPAN else 0
+    eow = lambda p: p + SPAN
+    ws = start - 3000 if start >= 3000 else 0
+    we = end + 3000
+    chr_ = chr_names[chr_id]
+    import bisect
+    first = bisect.bisect_left(ev, (chr_, ws, "", 0))
+    # upper_bound with key (chr, we, "", 0): every event whose first coordinate is (chr, we) sorts after the key
+    last = bisect.bisect_left(ev, (chr_, we, "", 0))
+    while last < len(ev) and ev[last][:2] == (chr_, we) and ev[last][2:] <= ("", 0):
+        last += 1
+    mask = [0] * (we - ws + 1)
+    clusters = [[]]
+    b = e = first
+    index = 0
+    for pos in range(ws, we):
+        changed = False
+        k = b
+        while k < e and pos > eow(ev[k][1]):
+            b += 1
+            k += 1
+            changed = True
+        for k in range(e, last):
+            s_ = sow(ev[k][1])
+            if pos < s_:
+                break
+            if pos == s_:
+                e += 1
+                changed = True
+        if b != e:
+            if changed:
+                index += 1
+                sub = sorted(ev[b:e], key=lambda t: (t[2], t[3], t[0], t[1]))
+                cl, i = [], 0
+                while i < len(sub):
+                    cid = chr_names.index(sub[i][2])
+                    w = [cid, sow(sub[i][3]), eow(sub[i][3])]
+                    while i + 1 < len(sub) and sub[i + 1][2] == sub[i][2] and sow(sub[i + 1][3]) <= eow(sub[i][3]) + 1:
+                        i += 1
+                        w[2] = eow(sub[i][3])
+                    cl.append(tuple(w))
+                    i += 1
+                clusters.append(cl)
+            mask[pos - ws] = index
+    out = []
+    size = 1 + we - ws
+    for q in queries:
+        rel = (q - ws) & 0xFFFFFFFF
+        if rel > size:
+            out.append([])
+        elif q > ws and rel < size - 1:
+            out.append(clusters[mask[rel]])
+        else:
+            out.append([])
+    return out, len(ev) // 2
+
+
+def test_breakdancer_hints_match_the_restatement(tmp_path):
+    import ctypes as C
+    from pindel_amd import hostlib
+    L = hostlib.lib()
+    L.pgh_bd_query.argtypes = [C.c_char_p, C.c_uint32, C.c_int32, C.POINTER(C.c_char_p), C.c_int32, C.c_uint32,
+                               C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    rng = np.random.default_rng(5)
+    names = ["chrA", "chrB", "chr10"]
+    spacer = 100000
+    for trial in range(6):
+        lines = ["#Chr1\tPos1\tOrientation1\tChr2\tPos2\tOrientation2\tType\tSize"]
+        for _ in range(int(rng.integers(5, 400))):
+            c1 = names[int(rng.integers(0, 3))]
+            c2 = c1 if rng.random() < 0.8 else names[int(rng.integers(0, 3))]
+            p1 = int(rng.integers(1, 60000))
+            p2 = p1 + int(rng.integers(-300, 30000)) if rng.random() < 0.9 else int(rng.integers(1, 60000))
+            p2 = max(p2, 1)
+            lines.append(f"{c1}\t{p1}\t10+0-\t{c2}\t{p2}\t0+10-\tDEL\t{abs(p2 - p1)}\t99\t10")
+            if rng.random() < 0.1:                       # clustered events: overlapping windows
+                lines.append(f"{c1}\t{p1 + int(rng.integers(0, 150))}\t3+0-\t{c2}\t{p2 + int(rng.integers(0, 350))}\t0+3-\tDEL\t1\t50\t3")
+        path = tmp_path / f"bd{trial}.txt"
+        path.write_text("\n".join(lines) + "\n")
+        chr_id = int(rng.integers(0, 3))
+        start = spacer + int(rng.integers(0, 20000))
+        end = start + int(rng.integers(5000, 50000))
+        q = np.concatenate([rng.integers(start - 4000, end + 4000, 3000),
+                            [start - 3000, start - 2999, end + 2999, end + 3000, end + 3001, 0]]).astype(np.uint32)
+        want, n_ev = _bd_restatement(lines, spacer, names, chr_id, start, end, [int(x) for x in q])
+        arr = (C.c_char_p * 3)(*[n.encode() for n in names])
+        off = np.zeros(len(q) + 1, dtype=np.uint64)
+        cap = 40 * len(q)
+        win = np.zeros(3 * cap, dtype=np.int32)
+        nev = C.c_uint64()
+        rc = L.pgh_bd_query(str(path).encode(), spacer, 3, arr, chr_id, start, end, len(q), q.ctypes.data,
+                            off.ctypes.data, win.ctypes.data, cap, C.byref(nev))
+        assert rc == 0 and nev.value == n_ev
+        got = [[tuple(int(v) for v in win[3 * k:3 * k + 3]) for k in range(int(off[i]), int(off[i + 1]))]
+               for i in range(len(q))]
+        assert got == want
+        assert sum(len(g) for g in got) > 0
+    bad = tmp_path / "bad.txt"
+    bad.write_text("chrA\t10\t+\tchrA\tnotanumber\t-\n")
+    rc = L.pgh_bd_query(str(bad).encode(), spacer, 3, arr, 0, spacer, spacer + 1000, 0, None, off.ctypes.data,
+                        win.ctypes.data, cap, C.byref(nev))
+    assert rc == 1 and nev.value == 0                    # ignored, like CheckBreakDancerFileFormat

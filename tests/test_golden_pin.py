@@ -78,3 +78,78 @@ def test_command_line_reproduces_gold_reports(tmp_path):
     assert out.returncode == 0, out.stderr
     assert "close end 14862, far end 10968" in out.stdout
     gu.assert_reports_match_gold(prefix)
+
+
+@pytest.mark.gpu
+def test_command_line_breakdancer_hints(tmp_path):
+    """`-b file` alone changes nothing (what 0.2.5b9 does for Pindel-text input); with `--bd-hints on` the
+    command line searches the events' windows before the ranges: same reports as the CPU oracle given the
+    same per-read window clusters (pgh_bd_query) and the C++ reporters."""
+    import ctypes as C
+    import filecmp
+    import os
+    import subprocess
+    from pindel_amd import binding
+    fa, reads_txt, chroms, batch = _load(tmp_path)
+    exe = os.path.join(os.path.dirname(binding.LIB_PATH), "pindel_pg")
+    # events between random places of the 200 kb chromosome and places 1-40 kb away
+    rng = np.random.default_rng(9)
+    lines = ["#Chr1\tPos1\tOri1\tChr2\tPos2\tOri2\tType\tSize\tScore\tReads"]
+    for _ in range(300):
+        p1 = int(rng.integers(1000, 190000))
+        p2 = min(p1 + int(rng.integers(600, 40000)), 199000)
+        lines.append(f"1\t{p1}\t5+0-\t1\t{p2}\t0+5-\tDEL\t{p2 - p1}\t99\t5")
+    bd_path = tmp_path / "bd.txt"
+    bd_path.write_text("\n".join(lines) + "\n")
+
+    def run(prefix, *extra):
+        out = subprocess.run([exe, "-f", fa, "-p", reads_txt, "-o", str(tmp_path / prefix), *extra],
+                             capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        return out.stdout
+
+    run("plain")
+    so = run("ignored", "-b", str(bd_path))
+    assert "BD events: 300" in so
+    for sfx in ("_D", "_SI", "_TD", "_INV"):
+        assert filecmp.cmp(tmp_path / ("plain" + sfx), tmp_path / ("ignored" + sfx), shallow=False)
+    run("hinted", "-b", str(bd_path), "--bd-hints", "on")
+
+    # the same with the oracle: close end, clusters of the last close-end point, far end with the windows
+    p = pyoracle.make_params()
+    seqs = [s for _, s in chroms]
+    args = (batch.seq, batch.seq_off, batch.anchor_strand, batch.anchor_pos, batch.insert_size, batch.chr_id)
+    close = pyoracle.search_batch(p, seqs, *args, do_far=False)
+    last = np.array([int(close["close_pts"][i][close["close_cnt"][i] - 1]["abs_loc"]) if close["close_cnt"][i] else 0
+                     for i in range(batch.n)], dtype=np.uint32)
+    L = hostlib.lib()
+    L.pgh_bd_query.argtypes = [C.c_char_p, C.c_uint32, C.c_int32, C.POINTER(C.c_char_p), C.c_int32, C.c_uint32,
+                               C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    names = (C.c_char_p * 1)(b"1")
+    off = np.zeros(batch.n + 1, dtype=np.uint64)
+    cap = 64 * batch.n
+    win = np.zeros(3 * cap, dtype=np.int32)
+    nev = C.c_uint64()
+    rc = L.pgh_bd_query(str(bd_path).encode(), 100000, 1, names, 0, 100000, 100000 + 5_000_000, batch.n,
+                        last.ctypes.data, off.ctypes.data, win.ctypes.data, cap, C.byref(nev))
+    assert rc == 0 and nev.value == 300
+    has_close = close["close_cnt"] > 0
+    cnt = np.diff(off.astype(np.int64))
+    cnt[~has_close] = 0
+    keep = np.repeat(has_close, np.diff(off.astype(np.int64)))
+    bd = np.zeros(int(cnt.sum()), dtype=pyoracle.WINDOW_DTYPE)
+    w3 = win[:3 * int(off[-1])].reshape(-1, 3)[keep]
+    bd["chr_id"], bd["start"], bd["end"] = w3[:, 0], w3[:, 1], w3[:, 2]
+    bd_off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint64)
+    assert len(bd) > 1000
+    r = pyoracle.search_batch(p, seqs, *args, bd=bd, bd_off=bd_off)
+    co, cp = gu.csr_from_strided(r["close_cnt"], r["close_pts"])
+    fo, fp = gu.csr_from_strided(r["far_cnt"], r["far_pts"])
+    st = hostlib.default_settings(pyoracle.max_mismatch_table())
+    hostlib.call_from_points(fa, reads_txt, str(tmp_path / "oracle_hinted"), st, co, cp, fo, fp, r["rc_flag"])
+    differs_from_plain = False
+    for sfx in ("_D", "_SI", "_TD", "_INV"):
+        assert filecmp.cmp(tmp_path / ("hinted" + sfx), tmp_path / ("oracle_hinted" + sfx), shallow=False), sfx
+        differs_from_plain |= not filecmp.cmp(tmp_path / ("hinted" + sfx), tmp_path / ("plain" + sfx), shallow=False)
+    # (whether the hints change a report depends on the data; they must at least have been searched)
+    assert differs_from_plain or int((r["far_cnt"] > 0).sum()) >= 10968
