@@ -152,11 +152,11 @@ void make_tables(pg_ctx *ctx)
 
 void free_reference(pg_ctx *ctx)
 {
-    if (ctx->d_lo) hipFree(ctx->d_lo);
-    if (ctx->d_hi) hipFree(ctx->d_hi);
-    if (ctx->d_nn) hipFree(ctx->d_nn);
-    if (ctx->d_word_off) hipFree(ctx->d_word_off);
-    if (ctx->d_chr_size) hipFree(ctx->d_chr_size);
+    if (ctx->d_lo) (void)hipFree(ctx->d_lo);
+    if (ctx->d_hi) (void)hipFree(ctx->d_hi);
+    if (ctx->d_nn) (void)hipFree(ctx->d_nn);
+    if (ctx->d_word_off) (void)hipFree(ctx->d_word_off);
+    if (ctx->d_chr_size) (void)hipFree(ctx->d_chr_size);
     ctx->d_lo = ctx->d_hi = ctx->d_nn = nullptr;
     ctx->d_word_off = nullptr;
     ctx->d_chr_size = nullptr;
@@ -207,7 +207,7 @@ void free_batch_buffers(pg_device_batch *b)
                      b->close_last, b->close_max, b->bd_off, b->bd, b->close_off, b->close_cnt,
                      b->far_off, b->far_cnt, b->alg, b->pool, b->pool_used };
     for (void *p : ptrs)
-        if (p) hipFree(p);
+        if (p) (void)hipFree(p);
 }
 
 int validate_and_measure(pg_ctx *ctx, const pg_read_batch *reads, uint32_t *max_len, uint32_t *levels)
@@ -284,13 +284,13 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, std::vector<
     if (getenv("PG_TEST_TINY_POOL")) b->pool_shard_cap = 1;      // tests: force the overflow/regrow path
     AL(pool, (size_t)b->pool_shard_cap * PG_POOL_SHARDS);
 #undef AL
-    hipMemset(b->close_cnt, 0, (n + 1) * sizeof(uint32_t));
-    hipMemset(b->far_cnt, 0, (n + 1) * sizeof(uint32_t));
-    hipMemset(b->close_off, 0, std::max<size_t>(n, 1) * sizeof(uint32_t));
-    hipMemset(b->far_off, 0, std::max<size_t>(n, 1) * sizeof(uint32_t));
-    hipMemset(b->rc_flag, 0, std::max<size_t>(n, 1));
-    hipMemset(b->close_max, 0, std::max<size_t>(n, 1) * sizeof(uint16_t));
-    hipMemset(b->alg, 0, std::max<size_t>(n, 1) * sizeof(uint32_t));
+    (void)hipMemset(b->close_cnt, 0, (n + 1) * sizeof(uint32_t));
+    (void)hipMemset(b->far_cnt, 0, (n + 1) * sizeof(uint32_t));
+    (void)hipMemset(b->close_off, 0, std::max<size_t>(n, 1) * sizeof(uint32_t));
+    (void)hipMemset(b->far_off, 0, std::max<size_t>(n, 1) * sizeof(uint32_t));
+    (void)hipMemset(b->rc_flag, 0, std::max<size_t>(n, 1));
+    (void)hipMemset(b->close_max, 0, std::max<size_t>(n, 1) * sizeof(uint16_t));
+    (void)hipMemset(b->alg, 0, std::max<size_t>(n, 1) * sizeof(uint32_t));
     if (copy && n) {
         hipError_t e = hipSuccess;
         if (nseq) e = hipMemcpy(b->seq, reads->seq + base0, (size_t)nseq, hipMemcpyHostToDevice);
@@ -567,11 +567,11 @@ void pg_destroy(pg_ctx *ctx)
 {
     if (!ctx) return;
     free_reference(ctx);
-    if (ctx->d_thr) hipFree(ctx->d_thr);
-    if (ctx->ev0) hipEventDestroy(ctx->ev0);
-    if (ctx->ev1) hipEventDestroy(ctx->ev1);
-    if (ctx->stream) hipStreamDestroy(ctx->stream);
-    if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
+    if (ctx->d_thr) (void)hipFree(ctx->d_thr);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     delete ctx;
 }
 

@@ -1155,7 +1155,7 @@ __global__ void pg_gather_runs_kernel(const pg_run *pool, const uint32_t *off, c
 extern "C" size_t pg_scan_tmp_bytes(uint32_t n)
 {
     size_t bytes = 0;
-    hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)(n + 1));
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)(n + 1));
     return bytes;
 }
 
