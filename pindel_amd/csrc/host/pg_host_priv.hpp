@@ -150,14 +150,14 @@ inline void exchange_sort(const std::vector<SplitRead> &reads, std::vector<unsig
 inline void mark_duplicates(std::vector<SplitRead> &reads, const std::vector<unsigned> &idx)
 {
     struct Key {
-        unsigned left, right;
+        int left, right;
         const std::string *name;
         bool operator==(const Key &o) const { return left == o.left && right == o.right && *name == *o.name; }
     };
     struct Hash {
         size_t operator()(const Key &k) const
         {
-            return std::hash<std::string>()(*k.name) ^ ((size_t)k.left * 0x9e3779b97f4a7c15ull) ^ ((size_t)k.right << 21);
+            return std::hash<std::string>()(*k.name) ^ ((size_t)(unsigned)k.left * 0x9e3779b97f4a7c15ull) ^ ((size_t)(unsigned)k.right << 21);
         }
     };
     std::unordered_set<Key, Hash> seen_unique;
