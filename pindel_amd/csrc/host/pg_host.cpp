@@ -490,13 +490,16 @@ void Caller::search_variant(Ctx &c, int kind)
         if (r.Used || r.UP_Far.empty()) continue;
         const bool plus = r.MatchedD == '+';
         if (!plus && r.MatchedD != '-') continue;
+        const FarByLength by_len(r);
         for (short budget = 0; budget <= r.MAX_SNP_ERROR && !r.Used; budget++) {
             const int nc = (int)r.UP_Close.size();
             for (int k = 0; k < nc && !r.Used; k++) {
                 const int ci = plus ? k : nc - 1 - k;
                 const UniquePoint &cp = r.UP_Close[ci];
                 if (cp.Mismatches > budget) continue;
-                for (int fi = (int)r.UP_Far.size() - 1; fi >= 0 && !r.Used; fi--) {
+                int fi_first = (int)r.UP_Far.size() - 1, fi_last = 0;
+                if (kind == 0) by_len.range_desc(r.getReadLength(), cp.LengthStr, (int)r.UP_Far.size(), fi_first, fi_last);
+                for (int fi = fi_first; fi >= fi_last && !r.Used; fi--) {
                     const UniquePoint &fp = r.UP_Far[fi];
                     if (fp.Mismatches > budget) continue;
                     if (fp.Mismatches + cp.Mismatches > budget) continue;

@@ -118,6 +118,46 @@ inline bool smaller(const SplitRead &a, const SplitRead &b)
     return false;
 }
 
+// The classifiers pair every close-end point with every far-end point (budget x |UP_Close| x |UP_Far|
+// iterations per read, search_variant.cpp:104-240 and friends) although most of them test
+// "LengthStr(close) + LengthStr(far) == ReadLength" first.  UP_Far holds at most one point per length, in
+// increasing length (it is one evaluation of the pattern growth), so the only far point that can pass
+// that test is found by length; the loop body then runs for that index alone -- same first hit, same
+// outcome.  If a caller hands in a list that is not strictly increasing the full loop is used.
+struct FarByLength {
+    short idx[512];
+    bool usable;
+    explicit FarByLength(const SplitRead &r) : usable(true)
+    {
+        for (int i = 0; i < 512; i++) idx[i] = -1;
+        int prev = -1;
+        const int nf = (int)r.UP_Far.size();
+        for (int j = 0; j < nf; j++) {
+            const int L = r.UP_Far[j].LengthStr;
+            if (L <= prev || L < 0 || L >= 512 || nf > 32000) {
+                usable = false;
+                return;
+            }
+            idx[L] = (short)j;
+            prev = L;
+        }
+    }
+    // [first, last] = the far indices (descending walk first >= last) that can pair with a close point of
+    // length close_len in a read of length read_len; empty when first < last
+    void range_desc(int read_len, int close_len, int nf, int &first, int &last) const
+    {
+        if (!usable) {
+            first = nf - 1;
+            last = 0;
+            return;
+        }
+        const int L = read_len - close_len;
+        const int j = (L >= 0 && L < 512) ? idx[L] : -1;
+        first = j;
+        last = j < 0 ? 0 : j;
+    }
+};
+
 // bubblesortReads, src/reporter.cpp:932-942: an exchange sort that also swaps EQUAL elements,
 //     for a < b: if (!smaller(x[a], x[b])) swap(x[a], x[b])
 // Its (unstable-looking) order of equal reads is visible in the reports, so it has to be reproduced

@@ -64,12 +64,21 @@ void Caller::search_tandem_dup(Ctx &c)
         const bool plus = r.MatchedD == '+';
         if (!plus && r.MatchedD != '-') continue;
         const int nc = (int)r.UP_Close.size(), nf = (int)r.UP_Far.size();
+        const FarByLength by_len(r);
         for (short budget = 0; budget <= r.MAX_SNP_ERROR; budget++) {
             for (int k = 0; k < nc; k++) {
                 if (r.Used) break;
                 const UniquePoint &cp = r.UP_Close[plus ? k : nc - 1 - k];
                 if (cp.Mismatches > budget) continue;
-                for (int j = 0; j < nf; j++) {
+                // only the far point of length ReadLength - LengthStr(close) can pass the tests below
+                int fi_first, fi_last;
+                by_len.range_desc(r.getReadLength(), cp.LengthStr, nf, fi_first, fi_last);
+                int j_first = 0, j_last = nf - 1;
+                if (by_len.usable) {
+                    if (fi_first < 0) continue;
+                    j_first = j_last = plus ? nf - 1 - fi_first : fi_first;
+                }
+                for (int j = j_first; j <= j_last; j++) {
                     if (r.Used) break;
                     const UniquePoint &fp = r.UP_Far[plus ? nf - 1 - j : j];
                     if (fp.Mismatches > budget) continue;
