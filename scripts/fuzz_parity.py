@@ -86,6 +86,27 @@ def one_iteration(seed, n_reads=1500, verbose=True):
     # full of repeats and most of them have no close end at all
     k = n_reads // 3
     batch.anchor_pos[:k] = rng.integers(2 * isz + 10, length - 2 * isz - 10, k).astype(np.int32)
+    # a third of the iterations: a second chromosome and per-read BreakDancer window clusters (0-4 windows,
+    # some on the other chromosome, some with start < 0, some overlapping), searched before the ranges
+    bd = bd_off = None
+    if rng.random() < 0.34:
+        chroms.append(("g", nasty_reference(rng, int(rng.integers(60_000, 150_000)))))
+        cnt = rng.integers(0, 5, n_reads)
+        cnt[rng.random(n_reads) < 0.3] = 0
+        bd_off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint64)
+        owner = np.repeat(np.arange(n_reads), cnt)
+        bd = np.zeros(len(owner), dtype=binding.WINDOW_DTYPE)
+        other = rng.random(len(owner)) < 0.2
+        bd["chr_id"] = np.where(other, 1, 0)
+        size = np.where(other, len(chroms[1][1]), len(ref))
+        centre = np.where(other, rng.integers(SPACER + 300, 1 << 30, len(owner)) % (size - 2 * SPACER - 600) + SPACER + 300,
+                          batch.anchor_pos[owner].astype(np.int64) + SPACER + rng.integers(-30000, 30000, len(owner)))
+        centre = np.clip(centre, SPACER + 300, size - SPACER - 300)
+        half = rng.integers(20, 1500, len(owner))
+        bd["start"] = np.maximum(centre - half, 1)
+        bd["end"] = np.minimum(centre + half, size - 1)
+        neg = rng.random(len(owner)) < 0.03
+        bd["start"][neg] = -1
     try:
         eng = binding.Engine(**kw)
     except binding.PgError as e:          # e.g. a parameter set the library rejects (> 16 levels)
@@ -94,8 +115,18 @@ def one_iteration(seed, n_reads=1500, verbose=True):
         return True
     try:
         eng.load_reference(chroms)
-        gpu = eng.search_batch(batch)
-        orc = run_oracle(kw, chroms, batch)
+        if bd is None:
+            gpu = eng.search_batch(batch)
+            orc = run_oracle(kw, chroms, batch)
+        else:
+            close = eng.close_end_batch(batch)
+            gpu = eng.far_end_batch(batch, close, bd=bd, bd_off=bd_off)
+            orc = run_oracle(kw, chroms, batch, bd=bd, bd_off=bd_off)
+            db = eng.upload(batch)                    # and the fused device-resident launch with windows
+            eng.set_windows(db, bd, bd_off)
+            eng.search_device(db)
+            compare_result(eng.download(db), orc, batch.n)
+            eng.free_device_batch(db)
         compare_result(gpu, orc, batch.n)
     except binding.PgError as e:
         if verbose:
@@ -111,7 +142,8 @@ def one_iteration(seed, n_reads=1500, verbose=True):
     if verbose:
         nc = int((orc["close_cnt"] > 0).sum())
         nf = int((orc["far_cnt"] > 0).sum())
-        print(f"seed {seed}: ok  params={kw} lens={lens} isz={isz} close {nc} far {nf}")
+        print(f"seed {seed}: ok  params={kw} lens={lens} isz={isz} close {nc} far {nf}" +
+              (f" bd windows {len(bd)}" if bd is not None else ""))
     return True
 
 
