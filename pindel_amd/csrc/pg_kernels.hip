@@ -485,10 +485,12 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, const PgDevParams
         const int ne = e < cs + (int)PG_CHUNK ? e : cs + (int)PG_CHUNK;
         if (ns >= xs && ne <= xe) continue;                 // nothing new in this chunk
         const int wb = cs - 64 * NB;
-        if (!(wo == S.win_wo && S.wbase == wb && ne + 64 * NB <= S.win_hi)) {
-            const int se = e_max < cs + (int)PG_CHUNK ? e_max : cs + (int)PG_CHUNK;
+        // The chunk must be resident up to e_max, not just up to this call's end: the filter masks of the
+        // innermost far-end chunk are computed once for all nested ranges, and an earlier fill with the same
+        // base (a close-end window that happens to start where this chunk starts) may be shorter.
+        const int se = e_max < cs + (int)PG_CHUNK ? e_max : cs + (int)PG_CHUNK;
+        if (!(wo == S.win_wo && S.wbase == wb && se + 64 * NB <= S.win_hi))
             stage_window<NB, Cell>(ref, S, wo, wb, se + 64 * NB, lane);
-        }
         const int pbase = cs + 32 * lane;
         const u32 rmask = bits32(ns - pbase, ne - pbase) & ~bits32(xs - pbase, xe - pbase);
         const bool cached = use_cache && k == 0 && cache_valid;
