@@ -331,3 +331,43 @@ def test_many_chromosomes_150bp(engine_factory):
     assert (orc["close_cnt"] > 0).sum() > 3000 and (orc["far_cnt"] > 0).sum() > 2000
     assert len(set(gpu.close_runs["chr_id"].tolist())) == 24
     compare_result(gpu, orc, batch.n)
+
+
+def test_anchor_sweep_window_coincidences(engine_factory, small_ref):
+    """Split reads with deletions of 150-1000 bases, each anchored at every offset of a +-700 base sweep for
+    insert sizes 350 and 480: every alignment between the close-end windows (R = 0 and R = 1) and the innermost
+    far-end chunk occurs -- including a R = 1 close-end window that starts exactly where the far-end chunk
+    starts while the far end lies beyond what that window staged (fuzz seed 61026)."""
+    from pindel_amd.hostio import ReadBatch
+    eng = engine_factory()
+    eng.load_reference(small_ref)
+    ref = np.frombuffer(small_ref[0][1], dtype=np.uint8)
+    comp = np.zeros(256, dtype=np.uint8)
+    for a_, b_ in zip(b"ACGTN", b"TGCAN"):
+        comp[a_] = b_
+    rng = np.random.default_rng(17)
+    seqs, strand, pos, isz = [], [], [], []
+    for i in range(10):
+        while True:                                           # a place clear of the N gaps
+            bp = int(rng.integers(400_000, 1_000_000))
+            dsize = int(rng.integers(150, 1000))
+            sp = int(rng.integers(25, 60))
+            bases = np.concatenate([ref[bp - sp:bp], ref[bp + dsize:bp + dsize + 100 - sp]])
+            if not np.any(ref[bp - 2000:bp + 3000] == ord("N")):
+                break
+        read = comp[bases[::-1]]                               # mate of a '+' anchor: reverse strand
+        for ins in (350, 480):
+            for d in range(-700, 701):
+                seqs.append(read)
+                strand.append(ord("+"))
+                pos.append(bp - sp - 100000 + d)
+                isz.append(ins)
+    n = len(seqs)
+    perm = rng.permutation(n)        # neighbours in the batch (= on the same CU) are unrelated reads
+    batch = ReadBatch(seq=np.concatenate([seqs[i] for i in perm]), seq_off=(np.arange(n + 1, dtype=np.uint64) * 100),
+                      anchor_strand=np.array(strand, dtype=np.uint8)[perm], anchor_pos=np.array(pos, dtype=np.int32)[perm],
+                      insert_size=np.array(isz, dtype=np.int16)[perm], chr_id=np.zeros(n, dtype=np.int32))
+    gpu = eng.search_batch(batch)
+    orc = run_oracle({}, small_ref, batch)
+    assert (orc["close_cnt"] > 0).sum() > n // 3 and (orc["far_cnt"] > 0).sum() > n // 4
+    compare_result(gpu, orc, batch.n)
