@@ -491,15 +491,30 @@ void Caller::search_variant(Ctx &c, int kind)
         const bool plus = r.MatchedD == '+';
         if (!plus && r.MatchedD != '-') continue;
         const FarByLength by_len(r);
+        const FarByLoc by_loc(r);
         for (short budget = 0; budget <= r.MAX_SNP_ERROR && !r.Used; budget++) {
             const int nc = (int)r.UP_Close.size();
             for (int k = 0; k < nc && !r.Used; k++) {
                 const int ci = plus ? k : nc - 1 - k;
                 const UniquePoint &cp = r.UP_Close[ci];
                 if (cp.Mismatches > budget) continue;
+                // candidates among the far points, visited from the highest index down like the full loop:
+                // deletions: the one of length ReadLength - LengthStr(close); short insertions: the ones
+                // at AbsLoc(close) + 1 ('+' anchor) / AbsLoc(close) - 1 ('-' anchor)
                 int fi_first = (int)r.UP_Far.size() - 1, fi_last = 0;
+                size_t lb = 0, le = 0;
                 if (kind == 0) by_len.range_desc(r.getReadLength(), cp.LengthStr, (int)r.UP_Far.size(), fi_first, fi_last);
-                for (int fi = fi_first; fi >= fi_last && !r.Used; fi--) {
+                else by_loc.range(plus ? cp.AbsLoc + 1 : cp.AbsLoc - 1, lb, le);
+                for (size_t step_ = 0;; step_++) {
+                    int fi;
+                    if (kind == 0) {
+                        fi = fi_first - (int)step_;
+                        if (fi < fi_last) break;
+                    } else {
+                        if (lb + step_ >= le) break;
+                        fi = -by_loc.v[lb + step_].second;
+                    }
+                    if (r.Used) break;
                     const UniquePoint &fp = r.UP_Far[fi];
                     if (fp.Mismatches > budget) continue;
                     if (fp.Mismatches + cp.Mismatches > budget) continue;

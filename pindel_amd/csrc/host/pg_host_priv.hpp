@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <functional>
 #include <unordered_set>
+#include <utility>
 #include <vector>
 
 #include "pg_host.hpp"
@@ -155,6 +156,26 @@ struct FarByLength {
         const int j = (L >= 0 && L < 512) ? idx[L] : -1;
         first = j;
         last = j < 0 ? 0 : j;
+    }
+};
+
+// The same idea for the tests on positions (short insertions: "far AbsLoc == close AbsLoc + 1"): the far
+// points sorted by (AbsLoc ascending, index descending); the entries of one AbsLoc are then exactly the
+// points the descending loop over all far points would have tested successfully, in the same order.
+struct FarByLoc {
+    std::vector<std::pair<unsigned, int>> v;
+    explicit FarByLoc(const SplitRead &r)
+    {
+        v.reserve(r.UP_Far.size());
+        for (int j = 0; j < (int)r.UP_Far.size(); j++) v.push_back(std::make_pair(r.UP_Far[j].AbsLoc, -j));
+        std::sort(v.begin(), v.end());
+    }
+    // [b, e): entries with the given AbsLoc; far index = -v[k].second, descending as k grows
+    void range(unsigned loc, size_t &b, size_t &e) const
+    {
+        b = std::lower_bound(v.begin(), v.end(), std::make_pair(loc, -0x7fffffff)) - v.begin();
+        e = b;
+        while (e < v.size() && v[e].first == loc) e++;
     }
 };
 
