@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <fstream>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "pg_host.hpp"
@@ -67,7 +68,7 @@ int run_pipeline(const std::vector<Chromosome> &genome, const std::vector<unsign
                 for (SplitRead &r : reads)
                     if (!r.UP_Close.empty()) {
                         caller.note_close_mapped(r);
-                        kept.push_back(r);
+                        kept.push_back(std::move(r));      // `reads` is not used after this loop
                     }
                 if (!kept.empty()) caller.process_window(chrom, kept, ws, we, bed_start, bed_end);
             }
