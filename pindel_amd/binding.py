@@ -77,8 +77,10 @@ def build(force: bool = False) -> str:
         os.path.join(_HERE, "..", "include", "pindel_pg.h")]
     if force or not os.path.exists(LIB_PATH) or any(
             os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
-        subprocess.check_call(["make", "-C", src_dir, "-B", "all"], stdout=subprocess.DEVNULL,
-                              stderr=subprocess.DEVNULL)
+        r = subprocess.run(["make", "-C", src_dir, "-B", "all"], stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"building {LIB_PATH} failed (make exit {r.returncode}):\n{r.stdout[-8000:]}")
     return LIB_PATH
 
 

@@ -34,30 +34,101 @@ int main(int argc, char **argv)
     pg_params prm;
     pg_default_params(&prm);
     Settings S;
-    for (int i = 1; i + 1 < argc; i += 2) {
+    // Flags as src/fn_parameters.cpp defines them: value flags need an argument that does not start with
+    // '-'; unary switches take an optional true/false word (readParameters, fn_parameters.cpp:366-406).
+    // Switches of report families this program does not write are accepted and ignored, like the reference
+    // accepts them; anything else is an error, and so is a value that is not a number.
+    struct Flag { const char *sh, *lg; char kind; };      // kind: i int, f float, s string, u unary
+    static const Flag flags[] = {
+        { "-f", "--fasta", 's' }, { "-p", "--pindel-file", 's' }, { "-o", "--output-prefix", 's' },
+        { "-x", "--max_range_index", 'i' }, { "-a", "--additional_mismatch", 'i' },
+        { "-m", "--min_perfect_match_around_BP", 'i' }, { "-u", "--maximum_allowed_mismatch_rate", 'f' },
+        { "-e", "--sequencing_error_rate", 'f' }, { "-E", "--sensitivity", 'f' }, { "-H", "--min_close", 'i' },
+        { "-M", "--minimum_support_for_event", 'i' }, { "-B", "--balance_cutoff", 'i' },
+        { "-d", "--min_num_matched_bases", 'i' }, { "-v", "--min_inversion_size", 'i' },
+        { "-w", "--window_size", 'f' }, { "-T", "--number_of_threads", 'i' }, { "-b", "--breakdancer", 's' },
+        { "-G", "--gpus", 's' }, { "", "--bd-hints", 's' }, { "-c", "--chromosome", 's' },
+        { "-n", "--min_NT_size", 'i' }, { "-A", "--anchor_quality", 'i' }, { "-L", "--logfilename", 's' },
+        { "-r", "--report_inversions", 'u' }, { "-t", "--report_duplications", 'u' },
+        { "-l", "--report_long_insertions", 'u' }, { "-k", "--report_breakpoints", 'u' },
+        { "-s", "--report_close_mapped_reads", 'u' }, { "-S", "--report_only_close_mapped_reads", 'u' },
+        { "-I", "--report_interchromosomal_events", 'u' }, { "-C", "--IndelCorrection", 'u' },
+        { "-N", "--NormalSamples", 'u' }, { "-R", "--RP", 'u' }, { "-q", "--detect_DD", 'u' },
+    };
+    std::string gpu_list;
+    for (int i = 1; i < argc; i++) {
         const std::string f = argv[i];
-        const char *v = argv[i + 1];
-        if (f == "-f") fasta = v;
-        else if (f == "-p") reads_path = v;
-        else if (f == "-o") prefix = v;
-        else if (f == "-x") prm.max_range_index = atoi(v);
-        else if (f == "-a") prm.additional_mismatch = atoi(v);
-        else if (f == "-m") prm.min_perfect_match_around_bp = atoi(v);
-        else if (f == "-u") prm.max_allowed_mismatch_rate = atof(v);
-        else if (f == "-e") prm.seq_error_rate = S.Seq_Error_Rate = atof(v);
-        else if (f == "-E") prm.sensitivity = atof(v);
-        else if (f == "-H") prm.min_close = atoi(v);
-        else if (f == "-M") S.NumRead2ReportCutOff = (unsigned)atoi(v);
-        else if (f == "-B") S.BalanceCutoff = (unsigned)atoi(v);
-        else if (f == "-d") S.Min_Num_Matched_Bases = atoi(v);
-        else if (f == "-v") S.MIN_IndelSize_Inversion = atoi(v);
-        else if (f == "-w") S.window_mbp = atof(v);
-        else if (f == "-G") prm.device = atoi(v);
-        else if (f == "-T") { /* thread count: the search runs on the GPU */ }
-        else if (f == "-b") bd_path = v;                                     // --breakdancer
-        else if (f == "--bd-hints") use_bd = std::string(v) == "on";         // see below: off = what 0.2.5b9 does
-        else {
-            fprintf(stderr, "pindel_pg: unknown flag %s\n", f.c_str());
+        const Flag *fl = nullptr;
+        for (const Flag &x : flags)
+            if ((x.sh[0] && f == x.sh) || f == x.lg) fl = &x;
+        if (!fl) {
+            fprintf(stderr, "pindel_pg: unknown argument: %s\n", f.c_str());
+            return 2;
+        }
+        const std::string key = fl->sh[0] ? fl->sh : fl->lg;
+        if (fl->kind == 'u') {
+            bool on = true;
+            if (i + 1 < argc && argv[i + 1][0] != '-') {
+                const char c0 = (char)tolower((unsigned char)argv[i + 1][0]);
+                on = !(c0 == 'f' || c0 == '0');
+                i++;
+            }
+            if (key == "-r") S.Analyze_INV = on;
+            else if (key == "-t") S.Analyze_TD = on;
+            // the other switches select reports (LI, BP, CloseEndMapped, INT ...) outside this program's scope
+            continue;
+        }
+        if (i + 1 >= argc) {
+            fprintf(stderr, "pindel_pg: argument of %s lacking.\n", f.c_str());
+            return 2;
+        }
+        const char *v = argv[++i];
+        if (v[0] == '-' && fl->kind != 's') {
+            fprintf(stderr, "pindel_pg: argument of %s seems erroneous.\n", f.c_str());
+            return 2;
+        }
+        long iv = 0;
+        double fv = 0.0;
+        if (fl->kind == 'i' || fl->kind == 'f') {
+            char *endp = nullptr;
+            if (fl->kind == 'i') iv = strtol(v, &endp, 10);
+            else fv = strtod(v, &endp);
+            if (endp == v || *endp != 0) {
+                fprintf(stderr, "pindel_pg: argument of %s is not a number: %s\n", f.c_str(), v);
+                return 2;
+            }
+        }
+        if (key == "-f") fasta = v;
+        else if (key == "-p") reads_path = v;
+        else if (key == "-o") prefix = v;
+        else if (key == "-x") prm.max_range_index = (int)iv;
+        else if (key == "-a") prm.additional_mismatch = (int)iv;
+        else if (key == "-m") prm.min_perfect_match_around_bp = (int)iv;
+        else if (key == "-u") prm.max_allowed_mismatch_rate = fv;
+        else if (key == "-e") prm.seq_error_rate = S.Seq_Error_Rate = fv;
+        else if (key == "-E") prm.sensitivity = fv;
+        else if (key == "-H") prm.min_close = (int)iv;
+        else if (key == "-M") S.NumRead2ReportCutOff = (unsigned)iv;
+        else if (key == "-B") S.BalanceCutoff = (unsigned)iv;
+        else if (key == "-d") S.Min_Num_Matched_Bases = (int)iv;
+        else if (key == "-v") S.MIN_IndelSize_Inversion = (int)iv;
+        else if (key == "-w") S.window_mbp = fv;
+        else if (key == "-G") gpu_list = v;
+        else if (key == "-b") bd_path = v;                                     // --breakdancer
+        else if (key == "--bd-hints") use_bd = std::string(v) == "on";         // see below: off = what 0.2.5b9 does
+        else if (key == "-c") {
+            if (std::string(v) != "ALL") {
+                fprintf(stderr, "pindel_pg: only -c ALL is supported\n");
+                return 2;
+            }
+        }
+        // -T (threads: the search runs on the GPU), -n, -A, -L: accepted, no effect on this path
+    }
+    if (!gpu_list.empty()) {
+        char *endp = nullptr;
+        prm.device = (int)strtol(gpu_list.c_str(), &endp, 10);
+        if (endp == gpu_list.c_str()) {
+            fprintf(stderr, "pindel_pg: bad device list %s\n", gpu_list.c_str());
             return 2;
         }
     }

@@ -26,6 +26,11 @@ struct DevBuf {
 
 }  // namespace
 
+// The kernel keeps window bounds, anchor positions and candidate positions in signed 32-bit integers
+// (pg_window, anchor_pos, `center`, `p`): a padded chromosome must stay below 2^31 with headroom for the
+// guard/overhang arithmetic around a window end.
+static const uint64_t PG_MAX_CHR_PADDED = 0x7fffffffull - 65536ull;
+
 struct pg_ctx {
     pg_params prm{};
     uint32_t mm[512]{};
@@ -215,6 +220,8 @@ int validate_and_measure(pg_ctx *ctx, const pg_read_batch *reads, uint32_t *max_
     if (!reads || (reads->n_reads && (!reads->seq_off || !reads->anchor_strand || !reads->anchor_pos ||
                                       !reads->insert_size || !reads->chr_id)))
         return fail(ctx, PG_E_INVALID, "null array in pg_read_batch");
+    if (reads->n_reads && !reads->seq && reads->seq_off[reads->n_reads] > reads->seq_off[0])
+        return fail(ctx, PG_E_INVALID, "null seq in pg_read_batch");
     if (ctx->names.empty()) return fail(ctx, PG_E_NO_REFERENCE, "no reference loaded");
     uint32_t ml = 1;
     const int n_chr = (int)ctx->names.size();
@@ -284,13 +291,21 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, std::vector<
     if (getenv("PG_TEST_TINY_POOL")) b->pool_shard_cap = 1;      // tests: force the overflow/regrow path
     AL(pool, (size_t)b->pool_shard_cap * PG_POOL_SHARDS);
 #undef AL
-    (void)hipMemset(b->close_cnt, 0, (n + 1) * sizeof(uint32_t));
-    (void)hipMemset(b->far_cnt, 0, (n + 1) * sizeof(uint32_t));
-    (void)hipMemset(b->close_off, 0, std::max<size_t>(n, 1) * sizeof(uint32_t));
-    (void)hipMemset(b->far_off, 0, std::max<size_t>(n, 1) * sizeof(uint32_t));
-    (void)hipMemset(b->rc_flag, 0, std::max<size_t>(n, 1));
-    (void)hipMemset(b->close_max, 0, std::max<size_t>(n, 1) * sizeof(uint16_t));
-    (void)hipMemset(b->alg, 0, std::max<size_t>(n, 1) * sizeof(uint32_t));
+    {
+        // the device-side CSR scan / gather trusts these counts: a failed memset must not go unnoticed
+        hipError_t e = hipMemset(b->close_cnt, 0, (n + 1) * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemset(b->far_cnt, 0, (n + 1) * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemset(b->close_off, 0, std::max<size_t>(n, 1) * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemset(b->far_off, 0, std::max<size_t>(n, 1) * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemset(b->rc_flag, 0, std::max<size_t>(n, 1));
+        if (e == hipSuccess) e = hipMemset(b->close_max, 0, std::max<size_t>(n, 1) * sizeof(uint16_t));
+        if (e == hipSuccess) e = hipMemset(b->alg, 0, std::max<size_t>(n, 1) * sizeof(uint32_t));
+        if (e != hipSuccess) {
+            free_batch_buffers(b);
+            delete b;
+            return fail(ctx, PG_E_DEVICE, std::string("clearing the batch outputs: ") + hipGetErrorString(e));
+        }
+    }
     if (copy && n) {
         hipError_t e = hipSuccess;
         if (nseq) e = hipMemcpy(b->seq, reads->seq + base0, (size_t)nseq, hipMemcpyHostToDevice);
@@ -592,7 +607,7 @@ int pg_load_reference(pg_ctx *ctx, int32_t n_chr, const char *const *names,
     free_reference(ctx);
     uint64_t total_words = 0;
     for (int c = 0; c < n_chr; c++) {
-        if (len_padded[c] >= 0xffffffffull) return fail(ctx, PG_E_UNSUPPORTED, "chromosome longer than 2^32 bases");
+        if (len_padded[c] > PG_MAX_CHR_PADDED) return fail(ctx, PG_E_UNSUPPORTED, "chromosome of 2^31 bases or more (positions are signed 32-bit on the device)");
         if (len_padded[c] < 2ull * ctx->prm.spacer) return fail(ctx, PG_E_INVALID, "chromosome shorter than its spacers");
         total_words += PG_GUARD_WORDS;
         ctx->word_off.push_back(total_words);
@@ -685,7 +700,7 @@ int pg_reference_load_packed(pg_ctx *ctx, const char *path)
         std::string name(nl, ' ');
         if ((nl && fread(&name[0], 1, nl, f) != nl) || fread(&size, 8, 1, f) != 1 || fread(&woff, 8, 1, f) != 1)
             return bad("truncated chromosome table");
-        if (size >= 0xffffffffull || size < 2ull * spacer) return bad("bad chromosome size");
+        if (size > PG_MAX_CHR_PADDED || size < 2ull * spacer) return bad("bad chromosome size (2^31 bases or more are not supported)");
         ctx->names.push_back(name);
         ctx->comp_size.push_back(size);
         ctx->word_off.push_back(woff);

@@ -279,7 +279,7 @@ __device__ __forceinline__ void fetch_global(const PgDevRef &ref, long long wo, 
 // and the per-lane selects / bit reversals disappear.
 template <int NB, typename Cell, bool MIXED>
 __device__ __forceinline__ void dense_pass(const Search<Cell> &S, const Query<NB> &Q, int wbase,
-                                           int origin, u32 region, int n, int lane)
+                                           int origin, u32 region, int n, int lane, bool undo = false)
 {
     bool alive = lane < n;
     int p = 0;
@@ -290,7 +290,12 @@ __device__ __forceinline__ void dense_pass(const Search<Cell> &S, const Query<NB
         p = wbase + (int)(e >> 1);
     }
     const bool comp = isB ? Q.cB : Q.cF;
+#ifdef PG_DUP
+    const Cell val0 = cell_pack<Cell>((u64)(u32)(p - origin), isB, region);
+    const Cell val = undo ? (Cell)0 - val0 : val0;      // diagnostics: the second pass takes the first one back
+#else
     const Cell val = cell_pack<Cell>((u64)(u32)(p - origin), isB, region);
+#endif
     const Cell neg = (Cell)0 - val;
     int cell = 0;            // level * lh
     const int cell_end = S.T * S.lh;
@@ -490,7 +495,12 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, const PgDevParams
         // base (a close-end window that happens to start where this chunk starts) may be shorter.
         const int se = e_max < cs + (int)PG_CHUNK ? e_max : cs + (int)PG_CHUNK;
         if (!(wo == S.win_wo && S.wbase == wb && se + 64 * NB <= S.win_hi))
+        {
             stage_window<NB, Cell>(ref, S, wo, wb, se + 64 * NB, lane);
+#if defined(PG_DUP) && PG_DUP == 2
+            stage_window<NB, Cell>(ref, S, wo, wb, se + 64 * NB, opaque(lane));
+#endif
+        }
         const int pbase = cs + 32 * lane;
         const u32 rmask = bits32(ns - pbase, ne - pbase) & ~bits32(xs - pbase, xe - pbase);
         const bool cached = use_cache && k == 0 && cache_valid;
@@ -503,6 +513,9 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, const PgDevParams
                 if (cached) m = kb ? cacheB : cacheF;
                 else {
                     m = seed_filter<NB, Cell>(prm, S, Q, kb != 0, lane);
+#if defined(PG_DUP) && PG_DUP == 3
+                    m &= seed_filter<NB, Cell>(prm, S, Q, kb != 0, opaque(lane)) | (u32)opaque(0);
+#endif
                     if (use_cache && k == 0) { if (kb) cacheB = m; else cacheF = m; }
                 }
                 pm = m & rmask;
@@ -527,6 +540,12 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, const PgDevParams
                     __syncthreads();
 #ifndef PG_ABL_NODENSE
                     dense_pass<NB, Cell, MIXED>(S, Q, wb, origin, region, n, lane);
+#if defined(PG_DUP) && PG_DUP == 4
+                    __syncthreads();
+                    dense_pass<NB, Cell, MIXED>(S, Q, wb, origin, region, n, opaque(lane), true);
+                    __syncthreads();
+                    dense_pass<NB, Cell, MIXED>(S, Q, wb, origin, region, n, opaque(lane));
+#endif
 #endif
                     __syncthreads();
                     // move the remainder (< 128 entries) to the front
@@ -814,6 +833,9 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
     PT_DECL
     u64 *qplanes = (u64 *)(smem + lay.qp_off);   // [0]: forward, [1]: reversed consumption order
     load_planes<NB>(seq, len, lane, qplanes);
+#if defined(PG_DUP) && PG_DUP == 1
+    load_planes<NB>(seq, len, opaque(lane), qplanes);
+#endif
     PT_MARK(0)
 #if defined(PG_STOP_AFTER) && PG_STOP_AFTER == 0
     if (lane == 0) B.rc_flag[rid] = (uint8_t)(qplanes[0] ^ qplanes[4 * NB + NB]);
@@ -940,6 +962,9 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
         if (!is_close && !Q.first_ok) break;         // far end: first base N (or not ACGT): nothing to find
         PT_MARK(5)
         if (zero) { zero_hist(S, opaque(lane)); S.nsurv = 0; nsurv_eval = -1; }
+#if defined(PG_DUP) && PG_DUP == 6
+        if (zero) zero_hist(S, opaque(lane));
+#endif
         PT_MARK(4)
         // ---------------- scan
 #ifdef PG_ABL_NOSCAN
@@ -997,6 +1022,9 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
                     int nn = 0; mm = 0;
 #else
                     int nn = evaluate<NB, Cell>(ref, prm, S, Q, R, runs_tmp, skip, PG_RUN_TMP, mm, opaque(lane));
+#if defined(PG_DUP) && PG_DUP == 5
+                    { int mm2; nn = evaluate<NB, Cell>(ref, prm, S, Q, R, runs_tmp, skip, PG_RUN_TMP, mm2, opaque(lane)); mm = mm2; }
+#endif
 #endif
                     if (pass == 0) { n = uni(nn); mx = uni(mm); }
                     PT_MARK(2)
