@@ -4,16 +4,23 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path (pg_device_batch_search: close-end + far-end kernel)
-over one batch of synthetic reads already resident in HBM.  Workload at N=1 = BASELINE.json
-configs[2]: 10 M x 100 bp one-end-anchored reads on a chr20-shaped reference, all SV types,
-Pindel defaults (-x 2 ...).  Reads shard across ranks (each rank generates its own 10 M reads,
-reference replicated per GPU, no collective on the data path) -> weak scaling.
+A "step" is one pass of the hot path (pg_device_batch_search: close-end + far-end kernel) over one batch
+of synthetic reads already resident in HBM.  Workload at N=1 = BASELINE.json configs[2]: 10 M x 100 bp
+one-end-anchored reads on a chr20-shaped reference, all SV types, Pindel defaults (-x 2 ...).
+
+Multi-GPU: reads shard by index, reference replicated per GPU, no collective on the data
+path (torch.distributed only for the barrier and the max-over-ranks time).
+  --scaling weak    (default) every rank generates its own --reads reads
+  --scaling strong  ONE seeded batch of --reads reads, rank r searches shard.shard_bounds(...)[r]; rank 0
+                    gathers the per-read digests in rank order: config.result_sha256 must equal the N=1 value
+`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run with N ranks.
 Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,68 +30,160 @@ if ROOT not in sys.path:
 
 CHR20_LEN = 62_435_964       # demo/hs_ref_chr20.fa.fai:1
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TRAFFIC_FILE = "v6_hbm_traffic.json"
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
+TRAFFIC_FILE = "hbm_traffic.json"
+PMC_FILE = "pmc_sq.txt"
 
 
-def cpu_baseline(chroms, batch, params_kw, budget_s=15.0, bd=None, bd_off=None):
-    """Time the CPU restatement (oracle, OpenMP over reads) on a bounded sample of the same reads."""
+def cpu_baseline(chroms, batch, params_kw, budget_s=12.0, bd=None, bd_off=None, thread_points=True):
+    """Time the CPU restatement (oracle, OpenMP over reads) on a bounded sample of the same reads, at all host
+    cores and -- on a smaller sample -- at 1/32/128 threads (the restatement is a faithful list-per-level
+    port, slower per core than the reference binary: SURVEY.md section 6 has the reference's own numbers)."""
     from oracle import pyoracle
     cores = os.cpu_count() or 1
     p = pyoracle.make_params(**params_kw)
     seqs = [s for _, s in chroms]
 
-    def run(n):
+    def run(n, threads):
         b = batch.slice(0, n)
         w, woff = (bd[:int(bd_off[n])], bd_off[:n + 1]) if bd is not None else (None, None)
         t0 = time.perf_counter()
         pyoracle.search_batch(p, seqs, b.seq, b.seq_off, b.anchor_strand, b.anchor_pos,
-                              b.insert_size, b.chr_id, bd=w, bd_off=woff, n_threads=cores, keep_points=False)
+                              b.insert_size, b.chr_id, bd=w, bd_off=woff, n_threads=threads, keep_points=False)
         return time.perf_counter() - t0
 
     n0 = min(batch.n, 20000)
-    run(n0)                              # warms the pages and the OpenMP pool
+    run(n0, cores)                       # warms the pages and the OpenMP pool
     n1 = min(batch.n, 200000)
-    t1 = run(n1)                         # calibrates the rate at a size where all threads are busy
+    t1 = run(n1, cores)                  # calibrates the rate at a size where all threads are busy
     n2 = int(min(batch.n, max(n1, n1 / max(t1, 1e-6) * budget_s)))
     if n2 > n1:
-        n1, t1 = n2, run(n2)
-    return {"value": n1 / t1, "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": f"first {n1} reads of the rank-0 batch, close+far end, OpenMP {cores} threads, {t1:.1f} s"}
+        n1, t1 = n2, run(n2, cores)
+    out = {"value": n1 / t1, "unit": "reads/s", "cores": cores, "kind": "port",
+           "sample": f"first {n1} reads of the rank-0 batch, close+far end, OpenMP {cores} threads, {t1:.1f} s"}
+    if thread_points:
+        pts = {}
+        for th in (1, 32, 128):
+            if th >= cores:
+                continue
+            n = int(min(batch.n, max(2000, out["value"] * th / cores * 2.0)))     # ~2 s each
+            pts[str(th)] = n / run(n, th)
+        pts[str(cores)] = out["value"]
+        out["reads_per_s_by_threads"] = pts
+    return out
 
 
-def measured_traffic(args):
-    """HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE with the gfx950
-    x2 correction + WRITE_SIZE, MI355X_MICROARCH.md).  PMC counters cannot be read from inside this
-    process, so the per-read figure measured with rocprofv3 on this same workload is scaled by the reads
-    of one launch; null for any other workload."""
-    path = os.path.join(ROOT, "profiles", "r01", TRAFFIC_FILE)
-    if args.read_len != 100 or args.max_range_index != 2 or args.workload != "sv10m" or not os.path.exists(path):
+def default_workload(args):
+    return args.read_len == 100 and args.max_range_index == 2 and args.workload == "sv10m"
+
+
+def measured_traffic(args, reads_per_launch):
+    """HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE with the gfx950 x2
+    correction + WRITE_SIZE, MI355X_MICROARCH.md).  PMC counters cannot be read from inside this process,
+    so the per-read figure measured with rocprofv3 on this same workload (scripts/profile_round.sh) is
+    scaled by the reads of one launch; null for any other workload."""
+    path = os.path.join(PROFILE_DIR, TRAFFIC_FILE)
+    if not default_workload(args) or not os.path.exists(path):
         return None, None
     with open(path) as fh:
         t = json.load(fh)
     per_read = t["fetch_bytes_per_read"] + t["write_bytes_per_read_uncalibrated"]
-    return per_read * args.reads, f"profiles/r01/{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per read x reads per launch)"
+    return per_read * reads_per_launch, (f"profiles/r02/{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                          "separate passes, per read x reads per launch)")
 
 
-def valu_issue(args, kernel_ms):
-    """The kernel is VALU-issue bound, not HBM bound: VALU instructions per read from
-    the committed PMC pass x 4 cycles per wave64 instruction over 1024 SIMDs at 2.4 GHz, against the kernel
-    time measured in this run.  None for workloads the PMC pass was not taken on."""
-    path = os.path.join(ROOT, "profiles", "r01", "v6_pmc_per_read.txt")
-    if (args.read_len != 100 or args.max_range_index != 2 or args.workload != "sv10m" or not os.path.exists(path)
-            or kernel_ms <= 0):
+def issue_model(args, kernel_ms, reads_per_launch):
+    """The kernel is instruction-issue bound, not HBM bound.  Instructions per read from
+    the committed PMC pass; issue costs from profiles/r02/ubench_issue_rates.txt (measured on MI355X): a SIMD
+    issues a plain wave64 VALU op every 2 cycles and the CU's scalar unit ~1 op per cycle."""
+    path = os.path.join(PROFILE_DIR, PMC_FILE)
+    if not default_workload(args) or not os.path.exists(path) or kernel_ms <= 0:
         return None
-    valu = None
+    c = {}
     with open(path) as fh:
         for line in fh:
             f = line.split()
-            if f and f[0] == "SQ_INSTS_VALU":
-                valu = float(f[1])
-    if valu is None:
+            if len(f) >= 2 and f[0].startswith(("SQ_", "GRBM_")):
+                c[f[0]] = float(f[1])
+    if "SQ_INSTS_VALU" not in c:
         return None
-    issue_ms = valu * args.reads * 4.0 / (1024 * 2.4e9) * 1e3
-    return {"valu_insts_per_read": valu, "valu_issue_ms": issue_ms, "valu_busy_frac": issue_ms / kernel_ms,
-            "source": "profiles/r01/v6_pmc_per_read.txt (SQ_INSTS_VALU), 256 CUs x 4 SIMDs, 4 cycles per wave64 VALU instruction, 2.4 GHz"}
+    valu, salu = c["SQ_INSTS_VALU"], c.get("SQ_INSTS_SALU", 0.0)
+    valu_ms = valu * reads_per_launch * 2.0 / (1024 * 2.4e9) * 1e3
+    salu_ms = salu * reads_per_launch * 1.0 / (256 * 2.4e9) * 1e3
+    return {"valu_insts_per_read": valu, "salu_insts_per_read": salu,
+            "valu_issue_ms_at_2_cycles": valu_ms, "salu_issue_ms_at_1_per_cu_cycle": salu_ms,
+            "valu_busy_frac": valu_ms / kernel_ms, "salu_busy_frac": salu_ms / kernel_ms,
+            "source": f"profiles/r02/{PMC_FILE} + profiles/r02/ubench_issue_rates.txt, 256 CUs x 4 SIMDs, 2.4 GHz nominal"}
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` without a launcher: run N ranks under torch.distributed.run."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def build_workload(args, rank, world, dev):
+    """-> chroms [(name, padded bytes)], batch (this rank's reads), bd, bd_off, description, total reads."""
+    import numpy as np
+    from pindel_amd import binding, shard, synth
+    bd = bd_off = None
+    strong = args.scaling == "strong"
+    read_seed = args.seed + 1 + (0 if strong else rank)
+    if args.workload == "grch38-150":
+        # BASELINE configs[3]-shaped: 24 chromosomes, 3.1 Gbp, 150-bp reads; one rank's share of 100 M reads
+        if args.read_len == 100:
+            args.read_len = 150
+        if args.reads == 10_000_000:
+            args.reads = 12_500_000
+        scale = args.genome_scale
+        lens = [max(400_000, int(L * scale)) for L in synth.GRCH38_LENGTHS]
+        chroms = synth.make_genome(lens, synth.GRCH38_NAMES, seed=args.seed, device=dev)
+        batch = synth.make_reads_genome(chroms, args.reads, seed=read_seed, device=dev, read_len=args.read_len)
+        desc = (f"BASELINE configs[3]-shaped: {args.reads} x {args.read_len} bp reads per GPU on a GRCh38-shaped "
+                f"reference (24 chromosomes, {sum(lens)} bp, i.i.d. + repeats/gaps per chromosome), all SV types")
+    else:
+        rf = 0.45 if args.workload == "repeat-rich" else 0.0
+        ref = synth.make_reference(args.chr_len, seed=args.seed, device=dev, repeat_frac=rf)
+        chroms = [("20", ref)]
+        if args.workload == "colo-bd":
+            # configs[1]-shaped (SURVEY.md 8d cfg 2): deletions only + BreakDancer hints.  The COLO-829 BAM is not
+            # in the image, so the hints are synthetic: 0-2 windows of 600 bases per read within 20 kb
+            # downstream/upstream of the anchor (where a deletion's far end lies).
+            if args.reads == 10_000_000:
+                args.reads = 1_000_000
+            batch = synth.make_reads(ref, args.reads, read_len=args.read_len, seed=read_seed,
+                                     device=dev, mix=(1.0, 0.0, 0.0, 0.0, 0.0))
+            rng = np.random.default_rng(args.seed + 77 + (0 if strong else rank))
+            k = rng.integers(0, 3, batch.n)
+            bd_off = np.concatenate([[0], np.cumsum(k)]).astype(np.uint64)
+            owner = np.repeat(np.arange(batch.n), k)
+            sign = np.where(batch.anchor_strand[owner] == ord("+"), 1, -1)
+            centre = batch.anchor_pos[owner].astype(np.int64) + 100000 + sign * rng.integers(300, 20000, len(owner))
+            centre = np.clip(centre, 100400, len(ref) - 100400)
+            bd = np.zeros(len(owner), dtype=binding.WINDOW_DTYPE)
+            bd["chr_id"], bd["start"], bd["end"] = 0, centre - 300, centre + 300
+            desc = (f"BASELINE configs[1]-shaped (deletions only, synthetic BreakDancer window hints): {args.reads} x "
+                    f"{args.read_len} bp reads on a chr20-shaped reference ({args.chr_len} bp)")
+        else:
+            batch = synth.make_reads(ref, args.reads, read_len=args.read_len, seed=read_seed, device=dev)
+            kind = "BASELINE configs[2]" if args.workload == "sv10m" else "repeat-rich variant of configs[2] (45 % repeats)"
+            desc = (f"{kind}: synthetic {args.reads} x {args.read_len} bp one-end-anchored reads on a chr20-shaped "
+                    f"reference ({args.chr_len} bp), all SV types (D/SI/TD/INV/none)")
+    total = batch.n
+    if strong and world > 1:
+        lo, hi = shard.shard_bounds(batch.n, world)[rank]
+        if bd is not None:
+            b0, b1 = int(bd_off[lo]), int(bd_off[hi])
+            bd, bd_off = bd[b0:b1], (bd_off[lo:hi + 1] - bd_off[lo]).astype(np.uint64)
+        batch = batch.slice(lo, hi)
+    return chroms, batch, bd, bd_off, desc, total
 
 
 def main():
@@ -92,60 +191,52 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU (weak) / in total (strong)")
     ap.add_argument("--read-len", type=int, default=100)
     ap.add_argument("--chr-len", type=int, default=CHR20_LEN)
     ap.add_argument("--max-range-index", type=int, default=2, help="Pindel -x")
     ap.add_argument("--seed", type=int, default=20260927)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["sv10m", "colo-bd"], default="sv10m",
-                    help="sv10m = BASELINE configs[2] (default); colo-bd = configs[1]-shaped: deletions only, "
-                         "1 M reads unless --reads is given, per-read BreakDancer window hints (synthetic)")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive pg_search_batch sample")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--genome-scale", type=float, default=1.0, help="grch38-150: scale every chromosome (tests)")
+    ap.add_argument("--workload", choices=["sv10m", "colo-bd", "grch38-150", "repeat-rich"], default="sv10m",
+                    help="sv10m = BASELINE configs[2] (default); colo-bd = configs[1]-shaped; grch38-150 = configs[3]-shaped "
+                         "(one rank's 12.5 M x 150 bp on a 3.1 Gbp 24-chromosome reference); repeat-rich = configs[2] on a "
+                         "reference that is 45 % diverged repeat copies")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_spawn(args)
+
     import torch
-    from pindel_amd import binding, synth
+    from pindel_amd import binding, shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if world > torch.cuda.device_count() and not os.environ.get("PG_BENCH_SHARE_GPU"):
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible")
+    local_dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     dist = None
     if world > 1 or os.environ.get("PG_BENCH_FORCE_DIST"):     # the env knob exercises the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if os.environ.get("PG_BENCH_SHARE_GPU"):     # tests on a 1-GPU box: ranks share device 0, gloo instead of RCCL
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
 
     params_kw = dict(max_range_index=args.max_range_index)
-    # ---- synthetic inputs: reference identical on every rank, reads sharded by rank
-    ref = synth.make_reference(args.chr_len, seed=args.seed, device=dev)
-    chroms = [("20", ref)]
-    bd = bd_off = None
-    if args.workload == "colo-bd":
-        # configs[1]-shaped (SURVEY.md 8d cfg 2): deletions only + BreakDancer hints.  The COLO-829 inputs are
-        # not in the image, so the hints are synthetic: 0-2 windows of 600 bases per read within 20 kb
-        # downstream/upstream of the anchor (where a deletion's far end lies).
-        import numpy as np
-        if args.reads == 10_000_000:
-            args.reads = 1_000_000
-        batch = synth.make_reads(ref, args.reads, read_len=args.read_len, seed=args.seed + 1 + rank,
-                                 device=dev, mix=(1.0, 0.0, 0.0, 0.0, 0.0))
-        rng = np.random.default_rng(args.seed + 77 + rank)
-        k = rng.integers(0, 3, batch.n)
-        bd_off = np.concatenate([[0], np.cumsum(k)]).astype(np.uint64)
-        owner = np.repeat(np.arange(batch.n), k)
-        sign = np.where(batch.anchor_strand[owner] == ord("+"), 1, -1)
-        centre = batch.anchor_pos[owner].astype(np.int64) + 100000 + sign * rng.integers(300, 20000, len(owner))
-        centre = np.clip(centre, 100400, len(ref) - 100400)
-        bd = np.zeros(len(owner), dtype=binding.WINDOW_DTYPE)
-        bd["chr_id"], bd["start"], bd["end"] = 0, centre - 300, centre + 300
-    else:
-        batch = synth.make_reads(ref, args.reads, read_len=args.read_len, seed=args.seed + 1 + rank,
-                                 device=dev)
-    eng = binding.Engine(device=local_rank, **params_kw)
+    chroms, batch, bd, bd_off, desc, total_reads = build_workload(args, rank, world, dev)
+    eng = binding.Engine(device=local_dev, **params_kw)
     eng.load_reference(chroms)
     dbatch = eng.upload(batch)           # inputs resident in HBM before the timed region
     if bd is not None:
@@ -168,53 +259,67 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if os.environ.get("PG_BENCH_SHARE_GPU") else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    alg_bytes = eng.algorithmic_bytes(dbatch)     # per launch (outside the timed region)
+    # ---- outside the timed region: accounting, result digests, the host-buffer seam, the CPU baseline
+    alg_bytes = eng.algorithmic_bytes(dbatch)     # per launch
     n_runs = eng.last_stats()[1]
     res = eng.download(dbatch)
     n_close = int((res.close_off[1:] > res.close_off[:-1]).sum())
     n_far = int((res.far_off[1:] > res.far_off[:-1]).sum())
+    digests = shard.read_digests(res)
+    if dist is not None and args.scaling == "strong":
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(digests, gathered, dst=0)
+        if rank == 0:
+            import numpy as np
+            digests = np.concatenate(gathered)      # rank order == input order
+    units = total_reads if args.scaling == "strong" else world * args.reads
 
     if rank == 0:
         avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic, traffic_src = measured_traffic(args)
+        traffic, traffic_src = measured_traffic(args, batch.n)
+        host_path = None
+        if world == 1 and not args.no_host_path:
+            # the seam a Pindel maintainer calls: host buffers in, host CSR out (PCIe both ways) -- never `value`
+            nb = min(batch.n, 4_000_000)
+            sub = batch.slice(0, nb)
+            eng.search_batch(sub).free()
+            th = time.perf_counter()
+            r2 = eng.search_batch(sub)
+            host_path = nb / (time.perf_counter() - th)
+            r2.free()
         out = {
             "metric": "one-end-anchored reads/sec through split-read search (close end + far end)",
-            "value": world * args.reads * args.steps / elapsed,
+            "value": units * args.steps / elapsed,
             "unit": "reads/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
             "config": {
-                "workload": ((f"BASELINE configs[2]: synthetic {args.reads} x {args.read_len} bp "
-                              if args.workload == "sv10m" else
-                              f"BASELINE configs[1]-shaped (deletions only, synthetic BreakDancer window hints): "
-                              f"{args.reads} x {args.read_len} bp ") +
-                             f"one-end-anchored reads per GPU on a chr20-shaped reference "
-                             f"({args.chr_len} bp), " +
-                             ("all SV types (D/SI/TD/INV/none)" if args.workload == "sv10m" else "deletions") +
-                             f", Pindel defaults "
-                             f"-x {args.max_range_index} -a 1 -m 3 -u 0.02 -e 0.01 -E 0.95 -H 8"),
-                "reads_per_gpu": args.reads, "read_len": args.read_len, "insert_size": 500,
-                "parallelism": f"reads sharded over {world} GPU(s), reference replicated, no collective",
+                "workload": desc + f", Pindel defaults -x {args.max_range_index} -a 1 -m 3 -u 0.02 -e 0.01 -E 0.95 -H 8",
+                "reads_per_gpu": batch.n, "reads_total": units, "read_len": args.read_len, "insert_size": 500,
+                "parallelism": f"reads sharded over {world} GPU(s) ({args.scaling} scaling), reference replicated, no collective",
                 "reads_with_close_end": n_close, "reads_with_far_end": n_far, "runs_out": int(n_runs),
+                "result_sha256": shard.digest_hex(digests),
+                "host_path_reads_per_s": host_path,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "pg_search_kernel", "kernel_ms": avg_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "actual_bound": "valu-issue", "valu": valu_issue(args, avg_ms),
+                "actual_bound": "instruction issue (VALU + scalar), see DESIGN.md section 4",
+                "issue": issue_model(args, avg_ms, batch.n),
             },
         }
         if world == 1 and not args.no_cpu_baseline:

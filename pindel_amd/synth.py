@@ -26,14 +26,60 @@ def _gen(seed, device):
     return g
 
 
+# GRCh38 primary assembly, chr1..22, X, Y (lengths of the .fai; only the shape matters here)
+GRCH38_LENGTHS = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636,
+                  138394717, 133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345,
+                  83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895, 57227415]
+GRCH38_NAMES = [str(i) for i in range(1, 23)] + ["X", "Y"]
+
+
+def _plant_repeats(seq, g, device, repeat_frac, n_families=6, divergence=(0.03, 0.20), n_tracts_per_mb=20):
+    """Repeat-rich variant: `repeat_frac` of the sequence is overwritten by diverged copies
+    of a few repeat families (consensus 300 bp - 6 kb, per-copy divergence drawn from `divergence`), plus
+    low-complexity tracts (mono/di/tri-nucleotide runs of 30-300 bp).  A real genome is about half repeats;
+    the i.i.d. default has a survivor rate of the seed filter that is best-case."""
+    length = seq.numel()
+    acgt = _ACGT.to(device)
+    fam_len = [300, 300, 1200, 2500, 6000, 6000][:n_families]
+    share = [0.30, 0.15, 0.15, 0.15, 0.15, 0.10][:n_families]
+    for f in range(n_families):
+        Lf = fam_len[f]
+        cons = acgt[torch.randint(0, 4, (Lf,), generator=g, device=device)]
+        k = max(1, int(length * repeat_frac * share[f] / Lf))
+        done = 0
+        while done < k:
+            kk = min(k - done, max(1, (1 << 24) // Lf))
+            pos = torch.randint(0, max(length - Lf, 1), (kk,), generator=g, device=device)
+            div = divergence[0] + (divergence[1] - divergence[0]) * torch.rand(kk, generator=g, device=device)
+            idx = pos[:, None] + torch.arange(Lf, device=device)[None, :]
+            mut = torch.rand(kk, Lf, generator=g, device=device) < div[:, None]
+            rnd = acgt[torch.randint(0, 4, (kk, Lf), generator=g, device=device)]
+            seq[idx.reshape(-1)] = torch.where(mut, rnd, cons[None, :].expand(kk, Lf)).reshape(-1)
+            done += kk
+    n_tr = max(1, int(length / 1e6 * n_tracts_per_mb))
+    pos = torch.randint(0, max(length - 400, 1), (n_tr,), generator=g, device=device)
+    tl = torch.randint(30, 300, (n_tr,), generator=g, device=device)
+    unit = torch.randint(1, 4, (n_tr,), generator=g, device=device)
+    motif = acgt[torch.randint(0, 4, (n_tr, 3), generator=g, device=device)]
+    j = torch.arange(300, device=device)[None, :]
+    idx = pos[:, None] + j
+    val = torch.gather(motif, 1, (j % unit[:, None]).expand(n_tr, 300))
+    keep = (j < tl[:, None]).reshape(-1)
+    seq[idx.reshape(-1)[keep]] = val.reshape(-1)[keep]
+
+
 def make_reference(length: int, seed: int = 20260927, n_gaps: int = 3, gap_len: int = 50000,
                    repeat_len: int = 2000, n_repeat_copies: int = 4, microsat_len: int = 600,
-                   spacer: int = SPACER, device="cpu") -> bytes:
+                   spacer: int = SPACER, device="cpu", repeat_frac: float = 0.0) -> bytes:
     """i.i.d. ACGT with a few N gaps, one repeat family and an AC microsatellite,
-    returned spacer-padded like Chromosome::getSeq() (src/pindel.cpp:297-309)."""
+    returned spacer-padded like Chromosome::getSeq() (src/pindel.cpp:297-309).
+    repeat_frac > 0: additionally repeat-rich (see _plant_repeats)."""
     g = _gen(seed, device)
     code = torch.randint(0, 4, (length,), generator=g, device=device, dtype=torch.uint8)
     seq = _ACGT.to(device)[code.long()]
+    del code
+    if repeat_frac > 0:
+        _plant_repeats(seq, g, device, repeat_frac)
     if length > 20 * (gap_len + repeat_len + microsat_len):
         for k in range(n_gaps):
             s = int(length * (k + 1) / (n_gaps + 1.5))
@@ -47,6 +93,48 @@ def make_reference(length: int, seed: int = 20260927, n_gaps: int = 3, gap_len: 
         seq[s:s + microsat_len] = ac.repeat(microsat_len // 2 + 1)[:microsat_len]
     pad = torch.full((spacer,), ord("N"), dtype=torch.uint8, device=device)
     return torch.cat([pad, seq, pad]).cpu().numpy().tobytes()
+
+
+def make_genome(lengths, names=None, seed: int = 20260927, device="cpu", repeat_frac: float = 0.0, spacer: int = SPACER):
+    """A multi-chromosome reference: [(name, padded_bytes)] with one make_reference per chromosome."""
+    names = names or [f"chr{i + 1}" for i in range(len(lengths))]
+    return [(nm, make_reference(int(L), seed=seed + 101 * i, device=device, repeat_frac=repeat_frac, spacer=spacer))
+            for i, (nm, L) in enumerate(zip(names, lengths))]
+
+
+def make_reads_genome(chroms, n_reads: int, seed: int = 20260927, device="cpu", interleave: bool = True, **kw):
+    """Reads over every chromosome of `chroms`, proportional to its length.  interleave = False keeps the
+    reads grouped by chromosome (the order a coordinate-sorted BAM delivers them)."""
+    from .hostio import ReadBatch
+    sizes = np.array([len(s) for _, s in chroms], dtype=np.float64)
+    counts = np.floor(sizes / sizes.sum() * n_reads).astype(np.int64)
+    counts[0] += n_reads - counts.sum()
+    parts = []
+    for c, (_, s) in enumerate(chroms):
+        if counts[c] > 0:
+            parts.append(make_reads(s, int(counts[c]), seed=seed + 7 * c, chr_id=c, device=device, **kw))
+    off = np.concatenate([[0]] + [p.seq_off[1:].astype(np.uint64) + np.uint64(b) for p, b in
+                                   zip(parts, np.cumsum([0] + [len(p.seq) for p in parts[:-1]]))]).astype(np.uint64)
+    b = ReadBatch(seq=np.concatenate([p.seq for p in parts]), seq_off=off,
+                  anchor_strand=np.concatenate([p.anchor_strand for p in parts]),
+                  anchor_pos=np.concatenate([p.anchor_pos for p in parts]),
+                  insert_size=np.concatenate([p.insert_size for p in parts]),
+                  chr_id=np.concatenate([p.chr_id for p in parts]))
+    if interleave and b.n:
+        rng = np.random.default_rng(seed + 5)
+        perm = rng.permutation(b.n)
+        lens = b.lengths()
+        if (lens == lens[0]).all():
+            L = int(lens[0])
+            seq = b.seq.reshape(b.n, L)[perm].reshape(-1)
+            off = b.seq_off
+        else:
+            o = b.seq_off.astype(np.int64)
+            seq = np.concatenate([b.seq[o[i]:o[i + 1]] for i in perm])
+            off = np.concatenate([[0], np.cumsum(lens[perm])]).astype(np.uint64)
+        b = ReadBatch(seq=seq, seq_off=off, anchor_strand=b.anchor_strand[perm], anchor_pos=b.anchor_pos[perm],
+                      insert_size=b.insert_size[perm], chr_id=b.chr_id[perm])
+    return b
 
 
 def make_reads(chr_padded, n_reads: int, read_len: int = 100, seed: int = 20260927,

@@ -74,6 +74,16 @@ VKERNEL(k_salu, "s_add_u32 %8, %8, 3", "s_xor_b32 %9, %9, 5", "s_and_b32 %10, %1
 VKERNEL(k_mix, "v_xor_b32 %0, %0, %16", "s_add_u32 %8, %8, 3", "v_xor_b32 %1, %1, %16", "s_xor_b32 %9, %9, 5",
         "v_xor_b32 %2, %2, %16", "s_add_u32 %10, %10, 3", "v_xor_b32 %3, %3, %16", "s_xor_b32 %11, %11, 5")
 
+// 3 vector : 1 scalar and 1 : 3 -- does the scalar stream ride for free next to the vector stream (separate
+// issue ports) or do both share one issue slot per SIMD?
+VKERNEL(k_mix31, "v_xor_b32 %0, %0, %16", "v_xor_b32 %1, %1, %16", "v_xor_b32 %2, %2, %16", "s_add_u32 %8, %8, 3",
+        "v_xor_b32 %3, %3, %16", "v_xor_b32 %4, %4, %16", "v_xor_b32 %5, %5, %16", "s_xor_b32 %9, %9, 5")
+VKERNEL(k_mix13, "s_add_u32 %8, %8, 3", "s_xor_b32 %9, %9, 5", "s_add_u32 %10, %10, 3", "v_xor_b32 %0, %0, %16",
+        "s_add_u32 %11, %11, 3", "s_xor_b32 %12, %12, 5", "s_add_u32 %13, %13, 3", "v_xor_b32 %1, %1, %16")
+// complex vector op (3.2 cycles alone) next to scalar ops
+VKERNEL(k_mixc, "v_alignbit_b32 %0, %0, %16, %17", "s_add_u32 %8, %8, 3", "v_alignbit_b32 %1, %1, %16, %17", "s_xor_b32 %9, %9, 5",
+        "v_alignbit_b32 %2, %2, %16, %17", "s_add_u32 %10, %10, 3", "v_alignbit_b32 %3, %3, %16, %17", "s_xor_b32 %11, %11, 5")
+// LDS broadcast read + vector ops
 typedef void (*kern_t)(unsigned *, unsigned long long *, unsigned);
 struct Case { const char *name; kern_t k; int insts_per_iter; const char *what; };
 
@@ -93,7 +103,8 @@ int main()
         { "v_xor", k_xor, 64, "" }, { "v_alignbit", k_alignbit, 64, "" }, { "v_bfi", k_bfi, 64, "" },
         { "v_and_or", k_and_or, 64, "" }, { "v_add_u32", k_add, 64, "" }, { "v_fma_f32", k_fma, 64, "" },
         { "v_add_dpp", k_dpp_add, 64, "" }, { "v_readlane", k_readlane, 64, "" }, { "v_cmp", k_cmp, 64, "" },
-        { "v_bcnt", k_popc, 64, "" }, { "s_alu", k_salu, 64, "" }, { "v+s mix", k_mix, 64, "" },
+        { "v_bcnt", k_popc, 64, "" }, { "s_alu", k_salu, 64, "" }, { "v+s mix", k_mix, 64, "" }, { "3v+1s mix", k_mix31, 64, "" }, { "1v+3s mix", k_mix13, 64, "" },
+        { "valign+s", k_mixc, 64, "" },
     };
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
