@@ -57,6 +57,7 @@ struct pg_device_batch {
     uint32_t n = 0;
     uint32_t max_len = 0, levels = 0;
     int32_t max_isz = 0;
+    int64_t max_bd_window = 0;         // largest BreakDancer window attached (positions)
     uint8_t *seq = nullptr;
     uint64_t *seq_off = nullptr;
     uint8_t *strand = nullptr;
@@ -287,7 +288,7 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, std::vector<
     AL(far_off, n);
     AL(far_cnt, n + 1);
     AL(alg, n);
-    AL(pool_used, PG_POOL_SHARDS * 16);
+    AL(pool_used, PG_POOL_SHARDS * 16 + PG_WORK_CTRS * 16);     // run-pool cursors + the launch's read counters
     b->pool_shard_cap = (uint32_t)std::min<uint64_t>((3ull * n) / PG_POOL_SHARDS + 96ull, 0x7fffffffull / PG_POOL_SHARDS);
     if (getenv("PG_TEST_TINY_POOL")) b->pool_shard_cap = 1;      // tests: force the overflow/regrow path
     AL(pool, (size_t)b->pool_shard_cap * PG_POOL_SHARDS);
@@ -354,15 +355,16 @@ PgDevBatch dev_batch(const pg_device_batch *b)
     d.pool = b->pool;
     d.pool_shard_cap = b->pool_shard_cap;
     d.pool_used = b->pool_used;
+    d.work_ctr = b->pool_used + PG_POOL_SHARDS * 16;
     d.alg_bytes = b->alg;
     return d;
 }
 
-bool small_cells(const pg_ctx *ctx, const pg_device_batch *b)
+bool small_ids(const pg_ctx *ctx, const pg_device_batch *b)
 {
-    // 32-bit histogram cells when every window of this launch has <= 32768 positions
-    // (ranges 128*4^x, close windows 3*InsertSize) and there are no BreakDancer regions
-    return !b->bd_off && ctx->prm.max_range_index <= 4 && 3ll * b->max_isz <= PG_SMALL_MAX_WINDOW &&
+    // 32-bit candidate ids when every window of this launch has <= 2^24 positions: ranges 128 * 4^x
+    // (x <= 8), close windows 3 * InsertSize (a short), BreakDancer windows as attached
+    return ctx->prm.max_range_index <= 8 && (long long)b->max_bd_window <= PG_SMALL_MAX_WINDOW &&
            !getenv("PG_FORCE_WIDE_CELLS");
 }
 
@@ -374,7 +376,9 @@ int launch_range(pg_ctx *ctx, pg_device_batch *b, int mode, uint32_t lo, uint32_
     PgDevBatch d = dev_batch(b);
     d.first_read = lo;
     d.n_reads = cnt;
-    int lrc = pg_launch_search(&ref, &prm, &d, mode, b->max_len, b->levels, small_cells(ctx, b) ? 1 : 0, ctx->stream);
+    // the persistent launch claims its reads from these counters
+    HIP_TRY(ctx, hipMemsetAsync(d.work_ctr, 0, PG_WORK_CTRS * 16 * sizeof(uint32_t), ctx->stream));
+    int lrc = pg_launch_search(&ref, &prm, &d, mode, b->max_len, b->levels, small_ids(ctx, b) ? 1 : 0, ctx->stream);
     if (lrc != 0) return fail(ctx, PG_E_DEVICE, std::string("kernel launch: ") + hipGetErrorString((hipError_t)lrc));
     return PG_OK;
 }
@@ -987,6 +991,7 @@ static int attach_windows(pg_ctx *ctx, pg_device_batch *b, const pg_windows *bd_
     const size_t n = b->n;
     if (b->bd_off) { (void)hipFree(b->bd_off); b->bd_off = nullptr; }
     if (b->bd) { (void)hipFree(b->bd); b->bd = nullptr; }
+    b->max_bd_window = 0;
     if (!(bd_hints && bd_hints->offset && n)) return PG_OK;
     const uint64_t nw = bd_hints->offset[n];
     for (size_t i = 0; i < n; i++) {
@@ -1001,6 +1006,7 @@ static int attach_windows(pg_ctx *ctx, pg_device_batch *b, const pg_windows *bd_
         long long st = w.start < 0 ? (long long)w.end - 1 : w.start;
         if ((long long)w.end - st >= (1ll << PG_REL_BITS))
             return fail(ctx, PG_E_UNSUPPORTED, "BreakDancer window larger than 2^26 bases");
+        b->max_bd_window = std::max<int64_t>(b->max_bd_window, (long long)w.end - st);
     }
     int rc;
     if ((rc = dev_upload(ctx, &b->bd_off, bd_hints->offset, n + 1)) ||

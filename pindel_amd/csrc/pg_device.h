@@ -62,30 +62,24 @@ struct PgDevBatch {
     pg_run *pool;
     uint32_t pool_shard_cap;       // runs per shard
     uint32_t *pool_used;           // [PG_POOL_SHARDS * 16]; cursor > pool_shard_cap means overflow (retry bigger)
+    uint32_t *work_ctr;            // [PG_WORK_CTRS * 16] reads claimed per XCD part (zeroed before every launch)
     uint32_t *alg_bytes;           // [n] algorithmic bytes per read, nullable
 };
 
-// Histogram cell = count (low bits) | candidate id (high bits).
-//   64-bit cells: 28-bit count, id = rel(26) | strand(1) | region(7)   -- any window the ABI accepts
-//   32-bit cells: 16-bit count, id = rel(15) | strand(1)               -- every search window of the
-//                 launch has <= 32768 positions and there are no BreakDancer regions
-#define PG_CNT_BITS 28
+// Candidate id = position relative to the search origin | kind (F/B) | window index of a BreakDancer cluster.
+//   64-bit ids: rel(26) | kind(1) | region(7)   -- any window the ABI accepts
+//   32-bit ids: rel(24) | kind(1) | region(7)   -- every search window of the launch has <= 2^24 positions
 #define PG_REL_BITS 26
-#define PG_CNT_BITS_SMALL 16
-#define PG_REL_BITS_SMALL 15
-#define PG_SMALL_MAX_WINDOW 32768
+#define PG_REL_BITS_SMALL 24
+#define PG_SMALL_MAX_WINDOW (1 << 24)
 #define PG_MAX_LEVELS 16
 #define PG_MM_BREAKS 16
 #define PG_POOL_SHARDS 1024u
-#ifndef PG_RUN_TMP
-#define PG_RUN_TMP 24            // runs of one search kept in LDS; more -> evaluated again, chunk by chunk
-#endif
+#define PG_WORK_CTRS 8u           // per-XCD read counters of the persistent launch, 64 bytes apart
 
 // Dynamic LDS layout (bytes), computed identically on host and device.
 struct PgLdsLayout {
-    uint32_t hist_off, carry_off, queue_off, win_off, eq_off, qp_off, runs_off, total;
-    uint32_t lh;        // histogram row length (max read length in the launch + 1)
-    uint32_t levels;    // max TOTAL_SNP_ERROR_CHECKED in the launch
+    uint32_t queue_off, win_off, eq_off, qp_off, bufa_off, bufb_off, total;
     uint32_t win_words; // LDS window capacity in 32-base words
 };
 
@@ -99,33 +93,31 @@ static inline
 #ifdef __HIPCC__
 __host__ __device__
 #endif
-PgLdsLayout pg_lds_layout(uint32_t max_len, uint32_t levels, uint32_t nb, uint32_t cell)
+PgLdsLayout pg_lds_layout(uint32_t max_len, uint32_t levels, uint32_t nb)
 {
+    (void)max_len;
+    (void)levels;
     PgLdsLayout l;
-    l.lh = max_len + 1;
-    l.levels = levels;
-    l.hist_off = 0;
-    l.carry_off = (l.hist_off + l.levels * l.lh * cell + 15u) & ~15u;        // ginit[16] + carry[16]
-    l.queue_off = l.carry_off + 2u * PG_MAX_LEVELS * cell;          // queue[192]
-    l.win_off = (l.queue_off + 192u * 4u + 15u) & ~15u;              // window (stays valid during evaluate)
-    // chunk + overhang of nb 64-base blocks on both sides + alignment slack
+    l.queue_off = 0;                                                 // queue[64]: survivors of one candidate pass
+    l.win_off = l.queue_off + 64u * 4u;                              // window, code planes (uint4 per word)
     l.win_words = PG_WIN_WORDS(nb);
     // one-hot planes of the same window (rows A, C, G, T, not-N; win_words words each)
     l.eq_off = (l.win_off + l.win_words * 16u + 15u) & ~15u;
     // the read's bit planes: 2 orientations x (lo, hi, N, other) x nb 64-base blocks
     l.qp_off = (l.eq_off + PG_EQ_ROWS * l.win_words * 4u + 15u) & ~15u;
-    l.runs_off = l.qp_off + 2u * 4u * nb * 8u;
-    l.total = (l.runs_off + PG_RUN_TMP * 12u + 15u) & ~15u;
+    l.bufa_off = l.qp_off + 2u * 4u * nb * 8u;                       // tier A entries: 68 x 16 bytes
+    l.bufb_off = l.bufa_off + 68u * 16u;                             // tier B entries: 64 x (16 + 16 nb) bytes
+    l.total = (l.bufb_off + 64u * (16u + 16u * nb) + 15u) & ~15u;
     return l;
 }
 
 #ifdef __cplusplus
 extern "C" {
 #endif
-// Launches the search kernel for the reads of the batch on `stream`.  small_cells selects the
-// 32-bit histogram cells (see above for when that is valid).
+// Launches the search kernel for the reads of the batch on `stream`.  small_ids selects the
+// 32-bit candidate ids (see above for when that is valid).
 int pg_launch_search(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch *batch,
-                     int mode, uint32_t max_len, uint32_t levels, int small_cells, void *stream);
+                     int mode, uint32_t max_len, uint32_t levels, int small_ids, void *stream);
 // Device-side CSR of a result list: first the scan (gather = 0: csr[0..n] = exclusive sums of cnt, cnt has
 // n + 1 readable entries), then the gather (gather = 1: out[csr[i] + k] = pool[off[i] + k]).
 size_t pg_scan_tmp_bytes(uint32_t n);

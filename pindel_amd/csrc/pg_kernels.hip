@@ -7,42 +7,40 @@
 //              SearchFarEndAtPos                   src/farend_searcher.cpp:46-103
 //              CheckBoth / ExtendMatch             src/pindel.cpp:2823-2902, 2673-2725
 //   both       CategorizePositions, CheckMismatches src/searcher.cpp:48-63, 331-388
-// The reference grows per-mismatch-level position lists one base at a time.  This
-// kernel computes the same thing differently (DESIGN.md "kernel formulation"):
+// The reference grows per-mismatch-level position lists one base at a time.  This kernel computes
+// the same function differently (DESIGN.md "kernel formulation"):
 //
-//   * The chromosome lives in HBM as three bit planes (2-bit code planar + N plane).
-//     A window chunk (2048 positions + overhang) is staged into LDS with coalesced dword
-//     loads, as code planes and as one-hot planes (is-A/C/G/T/not-N).
-//   * SEED FILTER, bit sliced: each lane owns the 32 window positions of one LDS word.
-//     The match mask of consumed base j for all 32 positions is one v_alignbit of the
-//     one-hot plane of that read symbol; mismatch counts live in a 4-bit ripple counter
-//     of 32-bit slices.  It keeps exactly the seeds that can matter (DESIGN.md
-//     "relevance"); survivors (~2 % of positions) are enumerated into an LDS queue.
-//     At the far end one filter pass per strand serves all nested ranges.
-//   * DENSE PASS: 64 queued candidates at a time, one per lane.  The mismatch pattern
-//     of the read placed at p comes 64 bases per step (funnel shifts + XOR, no
-//     per-base loop).  A candidate's life is the short list "at length L it leaves
-//     mismatch level k".  Each such event is ONE LDS atomic add of -(1 | id<<CB) into
-//     the cumulative difference histogram G[k][L] (G[k](L) = number of candidates
-//     with level <= k at length L; count in the low CB bits, candidate id above).
-//     Candidates are order independent in the reference (a point is only emitted
-//     when a level holds exactly one position), so per-level COUNTS plus the identity
-//     of a singleton are all that is needed.
-//   * EVALUATE: lanes own lengths L; a DPP wave scan per level turns the differences
-//     into G[k](L); the reference's abort / emission rules are applied to 64 lengths at
-//     once, CheckMismatches is redone with the same plane arithmetic, and consecutive
-//     points are emitted as run-length-encoded runs.
-//   * Nested far-end ranges (128, 512, 2048 ... bases) only add the new flanks:
-//     the histogram is additive over disjoint position sets.
+//   * The chromosome lives in HBM as three bit planes (2-bit code planar + N plane).  A window chunk
+//     (2048 positions + overhang) is staged into LDS with coalesced dword loads, as code planes and as
+//     one-hot planes (is-A/C/G/T/not-N).
+//   * SEED FILTER, bit sliced: each lane owns the 32 window positions of one LDS word.  The match mask of
+//     consumed base j for all 32 positions is one v_alignbit of the one-hot plane of that read symbol;
+//     mismatch counts live in a 4-bit ripple counter of 32-bit slices.  It keeps exactly the seeds that
+//     can matter (DESIGN.md "relevance"); survivors (~2 % of positions) get queue slots from a wave prefix
+//     sum of the per-lane popcounts.
+//   * CANDIDATES, one per lane, 64 at a time: the mismatch pattern of the read placed at p comes 64 bases
+//     per step (funnel shifts + XOR).  A candidate is fully described by its mismatch bitmap `mis`
+//     (level after L bases = popcount(mis & lowbits(L))), its exact-inequality bitmap `sne` (for
+//     CheckMismatches' perfect-match window) and its whole-read Hamming count.
+//   * ACCUMULATE, lanes own lengths L: the reference's emission rule at length L only needs the lowest
+//     level, whether a second candidate lies within ADDITIONAL_MISMATCH of it, and the identity of the
+//     lowest one.  That is a running (min1, min2, argmin) reduction over candidates -- associative, so
+//     candidates stream through it in any order and nothing like a per-level position list or histogram
+//     is ever stored.  Two tiers: candidates that die within 16 bases of the first evaluated length
+//     (almost all of them) are folded four at a time by 16-lane quarters that cover only those 16
+//     lengths; the few long-lived ones are folded with all 64 lanes per 64-length round.
+//     CheckMismatches is evaluated for every (candidate, L) inside the fold (three bit operations) and
+//     travels with the argmin.
+//   * EVALUATE: abort rule, emission rule and run-length encoding of consecutive points with ballots;
+//     runs go straight to the pooled output.
+//   * Nested far-end ranges (128, 512, 2048 ... bases) only add the candidates of the new flanks: the
+//     reduction is additive over disjoint position sets.
+//   * PERSISTENT waves: a launch has a few workgroups per CU; each claims chunks of reads from per-XCD
+//     counters (every XCD works through a contiguous eighth of the batch: neighbouring reads share cache
+//     lines and reference windows in ONE L2).
 //
-// The kernel is VALU-issue bound: what counts is the number of
-// vector instructions per read and the resident waves per SIMD (LDS per workgroup and
-// VGPRs).  Histogram cells are 32-bit (16-bit count + 16-bit id) whenever every search
-// window of the launch has at most 32 768 positions (Pindel defaults), and 64-bit
-// otherwise (large -x, BreakDancer clusters).  The read's own bit planes live in LDS:
-// as SGPRs they get spilled to VGPR lanes and every use costs a v_readlane on the VALU.
-//
-// No MFMA: this is bit/byte comparison work, not a contraction.
+// The kernel is bound by instruction issue (vector + scalar), not by HBM (DESIGN.md section 4,
+// profiles/r02/ubench_issue_rates.txt).  No MFMA: this is bit/byte comparison work, not a contraction.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -53,20 +51,16 @@ typedef unsigned long long u64;
 typedef unsigned int u32;
 
 #define WAVE 64
-// Optional per-phase cycle accounting (compile with -DPG_PHASE_TIMING; diagnostics only).
-#ifdef PG_PHASE_TIMING
-#define PT_DECL long long pt_t0 = clock64(); long long pt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define PT_MARK(k) { long long t_ = clock64(); pt_acc[k] += t_ - pt_t0; pt_t0 = t_; }
-#else
-#define PT_DECL
-#define PT_MARK(k)
-#endif
 #ifndef PG_N_XCD
 #define PG_N_XCD 8u        // MI355X: 8 accelerator complex dies, 32 CUs and one L2 each
 #endif
 #ifndef PG_WAVES_PER_EU
 #define PG_WAVES_PER_EU 5   // register budget the kernel is compiled for (waves per SIMD): 96 VGPRs
 #endif
+#ifndef PG_CLAIM
+#define PG_CLAIM 8u         // reads claimed per atomic
+#endif
+#define PG_BIG 0xffffu      // "no candidate" level
 
 __device__ __forceinline__ u64 ballot64(bool p) { return __ballot(p); }
 // DPP lane shifts (no LDS round trip).  row_shr:n moves lane i-n -> i inside each 16-lane row and
@@ -80,34 +74,10 @@ __device__ __forceinline__ u32 wave_shr1(u32 v)
 {
     return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);
 }
-template <int N>
-__device__ __forceinline__ u64 row_shr(u64 v)
-{
-    return (u64)row_shr<N>((u32)v) | ((u64)row_shr<N>((u32)(v >> 32)) << 32);
-}
 __device__ __forceinline__ u64 wave_shr1(u64 v)
 {
     return (u64)wave_shr1((u32)v) | ((u64)wave_shr1((u32)(v >> 32)) << 32);
 }
-// inclusive prefix sum inside aligned groups of G lanes (G = 4, 8 or 16); c = lane % G
-template <typename C>
-__device__ __forceinline__ C group_scan(C v, int c, int G)
-{
-    C t = row_shr<1>(v);
-    if (c >= 1) v += t;
-    t = row_shr<2>(v);
-    if (c >= 2) v += t;
-    if (G > 4) {
-        t = row_shr<4>(v);
-        if (c >= 4) v += t;
-    }
-    if (G > 8) {
-        t = row_shr<8>(v);
-        if (c >= 8) v += t;
-    }
-    return v;
-}
-
 // inclusive prefix sum over the 64 lanes of the wave, all DPP: Hillis-Steele inside the 16-lane rows
 // (row_shr shifts zeros in), then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3
 __device__ __forceinline__ u32 wave_scan(u32 v)
@@ -118,19 +88,6 @@ __device__ __forceinline__ u32 wave_scan(u32 v)
     v += row_shr<8>(v);
     v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
     v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
-    return v;
-}
-
-__device__ __forceinline__ u64 wave_scan(u64 v)
-{
-    v += row_shr<1>(v);
-    v += row_shr<2>(v);
-    v += row_shr<4>(v);
-    v += row_shr<8>(v);
-    v += (u64)(u32)__builtin_amdgcn_update_dpp(0, (int)(u32)v, 0x142, 0xa, 0xf, false) |
-         ((u64)(u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(v >> 32), 0x142, 0xa, 0xf, false) << 32);
-    v += (u64)(u32)__builtin_amdgcn_update_dpp(0, (int)(u32)v, 0x143, 0xc, 0xf, false) |
-         ((u64)(u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(v >> 32), 0x143, 0xc, 0xf, false) << 32);
     return v;
 }
 __device__ __forceinline__ u32 read_lane(u32 v, int l) { return (u32)__builtin_amdgcn_readlane((int)v, l); }
@@ -149,15 +106,17 @@ __device__ __forceinline__ int opaque(int v)
     asm volatile("" : "+v"(v));
     return v;
 }
-__device__ __forceinline__ u64 low_bits(int n)            // n in [0,64]
+__device__ __forceinline__ u64 low_bits(int n)            // clamped to [0,64]
 {
-    return n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+    return n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1ull));
+}
+__device__ __forceinline__ u32 low32(int n)               // clamped to [0,32]
+{
+    return n >= 32 ? 0xffffffffu : (n <= 0 ? 0u : ((1u << n) - 1u));
 }
 __device__ __forceinline__ u64 bit_range(int lo, int hi)  // bits [lo,hi), clamped to [0,64]
 {
-    lo = lo < 0 ? 0 : (lo > 64 ? 64 : lo);
-    hi = hi < 0 ? 0 : (hi > 64 ? 64 : hi);
-    return hi > lo ? (low_bits(hi) & ~low_bits(lo)) : 0ull;
+    return low_bits(hi) & ~low_bits(lo);
 }
 __device__ __forceinline__ u64 funnel64(u32 w0, u32 w1, u32 w2, u32 s)
 {
@@ -165,28 +124,30 @@ __device__ __forceinline__ u64 funnel64(u32 w0, u32 w1, u32 w2, u32 s)
     u32 b = __builtin_amdgcn_alignbit(w2, w1, s);
     return (u64)a | ((u64)b << 32);
 }
-
-// Histogram cell formats.
-template <typename Cell> struct CellFmt;
-template <> struct CellFmt<u32> {
-    static constexpr int CB = PG_CNT_BITS_SMALL, RB = PG_REL_BITS_SMALL;
-};
-template <> struct CellFmt<u64> {
-    static constexpr int CB = PG_CNT_BITS, RB = PG_REL_BITS;
-};
-template <typename Cell>
-__device__ __forceinline__ Cell cell_pack(u64 rel, bool isB, u32 region)
+__device__ __forceinline__ u32 med3(u32 a, u32 b, u32 c)
 {
-    typedef CellFmt<Cell> F;
-    u64 id = rel | ((u64)isB << F::RB) | ((u64)region << (F::RB + 1));
-    return (Cell)(1ull | (id << F::CB));
+    u32 r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// Candidate ids: position relative to the search's origin, kind (F/B) and window index (BreakDancer cluster).
+//   32-bit: rel(24) | kind << 24 | region << 25   -- every window of the launch has <= 2^24 positions
+//   64-bit: rel(26) | kind << 26 | region << 27   -- anything the ABI accepts
+template <typename Id> struct IdFmt;
+template <> struct IdFmt<u32> { static constexpr int RB = PG_REL_BITS_SMALL; };
+template <> struct IdFmt<u64> { static constexpr int RB = PG_REL_BITS; };
+template <typename Id>
+__device__ __forceinline__ Id make_id(u32 rel, bool isB, u32 region)
+{
+    return (Id)rel | ((Id)(isB ? 1u : 0u) << IdFmt<Id>::RB) | ((Id)region << (IdFmt<Id>::RB + 1));
 }
 
 // The read's bit planes live in LDS (not in SGPRs: 32+ SGPRs of planes would be spilled to VGPR lanes and
-// come back through v_readlane, which issues on the VALU this kernel is bound by; an LDS broadcast
-// read does not).  Layout: u64 qp[2 orientations][4 planes][NB blocks]; orientation 0 = the read left
-// to right, 1 = reversed; planes in CONSUMPTION order (bit j of block b = base 64b+j the growth
-// consumes): code bit0, code bit1, is 'N', is other (never matches).
+// come back through v_readlane; an LDS broadcast read costs no vector issue slot).  Layout:
+// u64 qp[2 orientations][4 planes][NB blocks]; orientation 0 = the read left to right, 1 = reversed;
+// planes in CONSUMPTION order (bit j of block b = base 64b+j the growth consumes): code bit0, code bit1,
+// is 'N', is other (never matches).
 enum { QP_LO = 0, QP_HI = 1, QP_NN = 2, QP_OO = 3 };
 
 // Everything a search needs to know about the query.
@@ -203,23 +164,59 @@ template <int NB> __device__ __forceinline__ u64 q_hi(const Query<NB> &Q, int b)
 template <int NB> __device__ __forceinline__ u64 q_nn(const Query<NB> &Q, int b) { return Q.qp[QP_NN * NB + b]; }
 template <int NB> __device__ __forceinline__ u64 q_oo(const Query<NB> &Q, int b) { return Q.qp[QP_OO * NB + b]; }
 
-template <typename Cell>
 struct Search {
     int len, T, M, add_mm, bps, min_perfect, thr;
-    int lh;
-    Cell *hist;    // G difference histogram [T][lh]
-    Cell *ginit;   // [PG_MAX_LEVELS] candidates entering at level k (at L = bps)
-    Cell *carry;   // [PG_MAX_LEVELS] running prefix per level during evaluate
-    u32 *queue;    // [192] compacted survivors of the prefilter
-    uint4 *win;    // staged window: code planes (lo, hi, N)
-    u32 *eq;       // staged window: one-hot planes [5][eq_stride]
-    int eq_stride;
+    u32 *queue;          // [64] survivors of the prefilter for one candidate pass
+    uint4 *win;          // staged window: code planes (lo, hi, N)
+    u32 *eq;             // staged window: one-hot planes [5][win_words]
+    uint4 *bufA;         // [68] tier A entries {mis0 lo, sne0 lo, id lo, meta}; scratch for the quarter merge
+    unsigned char *bufB; // [64] tier B entries {id lo, meta, -, -} + NB x {mis lo, mis hi, sne lo, sne hi}
     // what the LDS window currently holds: bases [win_lo, win_hi) of the chromosome whose AbsLoc 0 is
     // at word index win_wo; the first staged base is wbase = win_lo (any alignment)
     long long win_wo;
     int win_lo, win_hi, wbase;
-    int nsurv;     // candidates added to the histogram since it was zeroed
+    int nsurv;           // candidates folded since the state was reset
+    bool tierA;          // bps + 16 <= 32: the short-lived tier is usable
+    bool len_check;      // Min_Perfect_Match_Around_BP >= bps: the "L > m" test of CheckMismatches can fail
 };
+
+// Running reduction of a search (registers).  Tier B: lane owns L = bps + 64 r + lane in round r.
+// Tier A: lane = 16 q + j owns L = bps + j; quarter q holds a partial reduction.
+template <int NB, typename Id>
+struct Acc {
+    u32 m1[NB], m2[NB], ok[NB];
+    Id id[NB];
+    u32 a1, a2, aok;
+    Id aid;
+    __device__ __forceinline__ void reset()
+    {
+#pragma unroll
+        for (int r = 0; r < NB; r++) { m1[r] = m2[r] = PG_BIG; ok[r] = 0u; id[r] = 0; }
+        a1 = a2 = PG_BIG; aok = 0u; aid = 0;
+    }
+};
+
+// fold one candidate (level k, id cid, CheckMismatches result okc) into (min1, min2, argmin)
+template <typename Id>
+__device__ __forceinline__ void fold(u32 &m1, u32 &m2, Id &id, u32 &ok, u32 k, Id cid, u32 okc)
+{
+    const bool lt = k < m1;
+    m2 = med3(m1, m2, k);           // second smallest of {m1 <= m2, k}
+    id = lt ? cid : id;
+    ok = lt ? okc : ok;
+    m1 = k < m1 ? k : m1;
+}
+// merge two partial reductions (a <- a + b)
+template <typename Id>
+__device__ __forceinline__ void merge(u32 &a1, u32 &a2, Id &aid, u32 &aok, u32 b1, u32 b2, Id bid, u32 bok)
+{
+    const bool lt = b1 < a1;
+    const u32 hi1 = a1 > b1 ? a1 : b1, lo2 = a2 < b2 ? a2 : b2;
+    a2 = hi1 < lo2 ? hi1 : lo2;
+    aid = lt ? bid : aid;
+    aok = lt ? bok : aok;
+    a1 = lt ? b1 : a1;
+}
 
 // g_maxMismatch[L] from its breakpoints (the table is monotone): #{k : L >= mm_bp[k]}
 __device__ __forceinline__ int max_mismatch_at(const PgDevParams &prm, int L)
@@ -260,93 +257,146 @@ __device__ __forceinline__ void fetch_lds(const uint4 *win, int wbase, int q, bo
     if (rev) { rlo = __brevll(rlo); rhi = __brevll(rhi); rnn = __brevll(rnn); }
 }
 
-// Same from HBM/L2 (used when re-checking a single candidate).  wo = word index of AbsLoc 0.
-__device__ __forceinline__ void fetch_global(const PgDevRef &ref, long long wo, int q, bool rev,
-                                             u64 &rlo, u64 &rhi, u64 &rnn)
-{
-    long long w = wo + (long long)(q >> 5);   // arithmetic shift = floor
-    u32 s = (u32)(q & 31);
-    rlo = funnel64(ref.lo[w], ref.lo[w + 1], ref.lo[w + 2], s);
-    rhi = funnel64(ref.hi[w], ref.hi[w + 1], ref.hi[w + 2], s);
-    rnn = funnel64(ref.nn[w], ref.nn[w + 1], ref.nn[w + 2], s);
-    if (rev) { rlo = __brevll(rlo); rhi = __brevll(rhi); rnn = __brevll(rnn); }
-}
-
 // ---------------------------------------------------------------------------------
-// Dense pass over n (<= 64) queued candidates, one per lane: full mismatch pattern, level at
-// L = bps, then one histogram update per later mismatch until the candidate dies.
+// One pass over n (<= 64) queued candidates.
+//  1. lanes = candidates: mismatch / inequality bitmaps of the read placed at the candidate, Hamming count;
+//     short-lived candidates (dead before L = bps + 16) write a 16-byte entry to bufA, the others a full
+//     entry to bufB.
+//  2. tier A, lanes = 4 candidates x 16 lengths: fold the short-lived ones.
+//  3. tier B, lanes = 64 lengths of a round: fold the long-lived ones that are still alive when the round
+//     starts.
 // MIXED = both candidate kinds in one search (far end); otherwise the kind is wave-uniform (close end)
 // and the per-lane selects / bit reversals disappear.
-template <int NB, typename Cell, bool MIXED>
-__device__ __forceinline__ void dense_pass(const Search<Cell> &S, const Query<NB> &Q, int wbase,
-                                           int origin, u32 region, int n, int lane, bool undo = false)
+template <int NB, typename Id, bool MIXED>
+__device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB> &Q, Acc<NB, Id> &A, int wbase,
+                                                int origin, u32 region, int n, int lane)
 {
-    bool alive = lane < n;
+    constexpr int EB = 16 + 16 * NB;
+    bool valid = lane < n;
     int p = 0;
     bool isB = MIXED ? false : Q.allowB;
-    if (alive) {
+    if (valid) {
         u32 e = S.queue[lane];
         if (MIXED) isB = e & 1u;
         p = wbase + (int)(e >> 1);
     }
     const bool comp = isB ? Q.cB : Q.cF;
-#ifdef PG_DUP
-    const Cell val0 = cell_pack<Cell>((u64)(u32)(p - origin), isB, region);
-    const Cell val = undo ? (Cell)0 - val0 : val0;      // diagnostics: the second pass takes the first one back
-#else
-    const Cell val = cell_pack<Cell>((u64)(u32)(p - origin), isB, region);
-#endif
-    const Cell neg = (Cell)0 - val;
-    int cell = 0;            // level * lh
-    const int cell_end = S.T * S.lh;
+    u64 mis[NB], sne[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) mis[b] = sne[b] = 0ull;
+    int cum = 0;
+    bool need = valid;
 #pragma unroll
     for (int b = 0; b < NB; b++) {
-        if (64 * b >= S.len - 1) break;                 // uniform
-        if (!__any(alive)) break;                        // uniform
-        u32 blo = 0, bhi = 0;
-        if (alive) {
-            u64 rlo, rhi, rnn, mis, sne;
+        if (64 * b >= S.len) break;                      // uniform
+        if (!__any(need)) break;                          // uniform
+        if (need) {
+            u64 rlo, rhi, rnn, m, s;
             int q = isB ? p - 64 * b - 63 : p + 64 * b;
             fetch_lds(S.win, wbase, q, isB, rlo, rhi, rnn);
-            block_masks<NB>(Q, b, comp, rlo, rhi, rnn, mis, sne);
-            if (b == 0) {
-                // mismatches among the first bps bases decide the level at L = bps
-                int level = __popcll(mis & low_bits(S.bps));
-                if (level >= S.T) alive = false;
-                else {
-                    atomicAdd(&S.ginit[level], val);
-                    cell = level * S.lh;
-                }
-            }
-            // events at consumed index j in [bps, len-2] -> L = j+1 in [bps+1, len-1]
-            u64 bits = mis & bit_range(S.bps - 64 * b, S.len - 1 - 64 * b);
-            blo = (u32)bits;
-            bhi = (u32)(bits >> 32);
+            block_masks<NB>(Q, b, comp, rlo, rhi, rnn, m, s);
+            const u64 lm = low_bits(S.len - 64 * b);
+            mis[b] = m & lm;
+            sne[b] = s & lm;
+            cum += __popcll(mis[b]);
         }
-        // one histogram update per mismatch, low word first; selects instead of branches
+        // later blocks matter only while the candidate is alive (fewer than T mismatches so far) or its
+        // whole-read Hamming count has not reached CheckMismatches' threshold yet
+        need = need && (cum < S.T || cum < S.thr);
+    }
+    const u32 hamok = cum >= S.thr ? 0x80000000u : 0u;
+    valid = valid && __popcll(mis[0] & low_bits(S.bps)) < S.T;         // dead before the first length: never counts
+    bool lng = valid;
+    if (S.tierA) lng = valid && __popc((u32)mis[0] & low32(S.bps + 16)) < S.T;
+    const Id id = make_id<Id>((u32)(p - origin), isB, region);
+    const u32 lenthr = (u32)(S.min_perfect + (isB ? 0 : 1));           // FORWARD: L > m, BACKWARD: L >= m
+    const u32 meta = (u32)((u64)id >> 32) | (lenthr << 8) | hamok;
+    const bool sht = valid && !lng;
+    const u64 shortm = ballot64(sht);
+    u64 longm[NB];
+    longm[0] = ballot64(lng);
 #pragma unroll
-        for (int half = 0; half < 2; half++) {
-            u32 w = half ? bhi : blo;
-            const int lbase = 64 * b + 32 * half + 1;
-            while (__any(alive && w != 0u)) {
-                const bool act = alive && w != 0u;
-                const int j = __ffs((int)w) - 1;
-                w &= w - 1u;
-                if (act) atomicAdd(&S.hist[cell + lbase + j], neg);   // leaves its level at L = 64b+j+1
-                cell += act ? S.lh : 0;
-                alive = alive && cell < cell_end;
-            }
+    for (int r = 1; r < NB; r++) {
+        int kk = 0;
+#pragma unroll
+        for (int b = 0; b < NB; b++)
+            if (b <= r) kk += __popcll(mis[b] & low_bits(S.bps + 64 * r - 64 * b));
+        longm[r] = ballot64(lng && kk < S.T);
+    }
+    if (sht) {
+        const int rank = __popcll(shortm & low_bits(lane));
+        S.bufA[rank] = make_uint4((u32)mis[0], (u32)sne[0], (u32)id, meta);
+    }
+    if (lng) {
+        uint4 *e = (uint4 *)(S.bufB + lane * EB);
+        e[0] = make_uint4((u32)id, meta, 0u, 0u);
+#pragma unroll
+        for (int b = 0; b < NB; b++)
+            e[1 + b] = make_uint4((u32)mis[b], (u32)(mis[b] >> 32), (u32)sne[b], (u32)(sne[b] >> 32));
+    }
+    __syncthreads();
+    // ---- tier A
+    const int nA = __popcll(shortm);
+    if (nA > 0) {
+        const int lA = opaque(lane);
+        const int L = S.bps + (lA & 15), qd = lA >> 4;
+        const u32 mk = low32(L);
+        const u32 bpm = mk & ~low32(L - S.min_perfect);               // bits [L - m, L)
+        for (int base = 0; base < nA; base += 4) {
+            const int idx = base + qd;
+            const uint4 e = S.bufA[idx];                               // bufA has 4 spare entries
+            u32 k = (u32)__popc(e.x & mk);
+            k = idx < nA ? k : PG_BIG;
+            u32 okc = (e.y & bpm) == 0u ? (e.w >> 31) : 0u;
+            if (S.len_check) okc = (u32)L >= ((e.w >> 8) & 0x7fu) ? okc : 0u;
+            const Id cid = sizeof(Id) == 8 ? (Id)((u64)e.z | ((u64)(e.w & 0xffu) << 32)) : (Id)e.z;
+            fold<Id>(A.a1, A.a2, A.aid, A.aok, k, cid, okc);
         }
     }
+    // ---- tier B
+#pragma unroll
+    for (int r = 0; r < NB; r++) {
+        const int L0 = S.bps + 64 * r;
+        if (L0 > S.len - 1) break;                        // uniform
+        u64 mask = longm[r];
+        if (mask == 0ull) continue;                       // uniform
+        const int L = L0 + opaque(lane);
+        u64 Mk[NB], BP[NB];
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            Mk[b] = low_bits(L - 64 * b);
+            BP[b] = bit_range(L - S.min_perfect - 64 * b, L - 64 * b);
+        }
+        while (mask != 0ull) {
+            const int i = __ffsll((long long)mask) - 1;
+            mask &= mask - 1ull;
+            const uint4 *e = (const uint4 *)(S.bufB + i * EB);
+            const uint4 h = e[0];
+            u32 k = 0u;
+            u64 bad = 0ull;
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                if (b > r + 1) continue;                  // L <= bps + 64 r + 63 < 64 (r + 2)
+                const uint4 w = e[1 + b];
+                const u64 m = (u64)w.x | ((u64)w.y << 32), s = (u64)w.z | ((u64)w.w << 32);
+                k += (u32)__popcll(b < r ? m : (m & Mk[b]));
+                if (b + 1 >= r) bad |= s & BP[b];         // L - m >= 64 r - 64 (m <= 64 <= 64 + bps)
+            }
+            u32 okc = bad == 0ull ? (h.y >> 31) : 0u;
+            if (S.len_check) okc = (u32)L >= ((h.y >> 8) & 0x7fu) ? okc : 0u;
+            const Id cid = sizeof(Id) == 8 ? (Id)((u64)h.x | ((u64)(h.y & 0xffu) << 32)) : (Id)h.x;
+            fold<Id>(A.m1[r], A.m2[r], A.id[r], A.ok[r], k, cid, okc);
+        }
+    }
+    __syncthreads();
 }
 
 // Stages bases [lo, hi) (hi - lo <= PG_CHUNK + 128 NB) of a chromosome into LDS: word i of the window
 // holds bases [lo + 32 i, lo + 32 i + 32) whatever the alignment of lo (funnel shift of two HBM words),
-// once as the code planes the dense pass / CheckMismatches use and once as one-hot planes (is-A, is-C,
-// is-G, is-T, is-not-N) for the bit-sliced seed filter.
-template <int NB, typename Cell>
-__device__ __forceinline__ void stage_window(const PgDevRef &ref, Search<Cell> &S, long long wo, int lo, int hi,
-                                             int lane)
+// once as the code planes the candidate pass uses and once as one-hot planes (is-A, is-C, is-G, is-T,
+// is-not-N) for the bit-sliced seed filter.
+template <int NB>
+__device__ __forceinline__ void stage_window(const PgDevRef &ref, Search &S, long long wo, int lo, int hi, int lane)
 {
     const int nw = ((hi - lo + 31) >> 5) + 2;
     const u32 sh = (u32)(lo & 31);
@@ -375,29 +425,15 @@ __device__ __forceinline__ void stage_window(const PgDevRef &ref, Search<Cell> &
     S.win_hi = hi;
 }
 
-__device__ __forceinline__ u32 bfi32(u32 m, u32 a, u32 b) { return (m & a) | (~m & b); }
 __device__ __forceinline__ u32 bits32(int lo, int hi)      // bits [lo,hi), clamped to [0,32]
 {
-    lo = lo < 0 ? 0 : lo;
-    hi = hi > 32 ? 32 : hi;
-    const u32 hm = hi >= 32 ? 0xffffffffu : ((1u << (hi & 31)) - 1u);
-    return lo < hi ? (hm & ~((1u << (lo & 31)) - 1u)) : 0u;
+    return low32(hi) & ~low32(lo);
 }
 
 #ifndef PG_SEED_J
 #define PG_SEED_J(T) (2 * (T) + 4)     // consumed bases the seed filter looks at
 #endif
 
-// SEED FILTER, bit sliced: the lane owns the 32 window positions of word `lane` of the chunk and returns
-// the mask of positions whose candidate (of kind F or B) can matter.  Position bit i, consumed base j
-// reads reference base p+j (F) / p-j (B): one alignbit of the one-hot plane of read base j.  Mismatch
-// counts are kept bit sliced (a 4-bit ripple counter per position + overflow), 9 VALU per base for 32
-// positions.  Which candidates matter (exact, DESIGN.md "relevance"): a candidate at level k at
-// length L can only influence the result if k <= g_maxMismatch[L] + ADD -- otherwise either a lower
-// level exists (lo + ADD < k) or it is the lowest level itself and the search aborts at L with or
-// without it.  With J > bps bases inspected: relevant at some L in [bps, J] implies
-// c(bps) <= g_maxMismatch[J] + ADD (the table is monotone); relevant later implies alive after J bases,
-// c(J) <= T-1.  With J <= bps only the second test applies.  Anything kept beyond that is harmless.
 // positions whose bit-sliced mismatch count (c3 c2 c1 c0, ov = overflowed) is <= thr (wave-uniform)
 __device__ __forceinline__ u32 count_le(u32 c0, u32 c1, u32 c2, u32 c3, u32 ov, int thr)
 {
@@ -412,8 +448,18 @@ __device__ __forceinline__ u32 count_le(u32 c0, u32 c1, u32 c2, u32 c3, u32 ov, 
     return thr >= 15 ? ~ov : (lt | eq);
 }
 
-template <int NB, typename Cell>
-__device__ __forceinline__ u32 seed_filter(const PgDevParams &prm, const Search<Cell> &S, const Query<NB> &Q,
+// SEED FILTER, bit sliced: the lane owns the 32 window positions of word `lane` of the chunk and returns
+// the mask of positions whose candidate (of kind F or B) can matter.  Position bit i, consumed base j
+// reads reference base p+j (F) / p-j (B): one alignbit of the one-hot plane of read base j.  Mismatch
+// counts are kept bit sliced (a 4-bit ripple counter per position + overflow), 9 VALU per base for 32
+// positions.  Which candidates matter (exact, DESIGN.md "relevance"): a candidate at level k at
+// length L can only influence the result if k <= g_maxMismatch[L] + ADD -- otherwise either a lower
+// level exists (lo + ADD < k) or it is the lowest level itself and the search aborts at L with or
+// without it.  With J > bps bases inspected: relevant at some L in [bps, J] implies
+// c(bps) <= g_maxMismatch[J] + ADD (the table is monotone); relevant later implies alive after J bases,
+// c(J) <= T-1.  With J <= bps only the second test applies.  Anything kept beyond that is harmless.
+template <int NB>
+__device__ __forceinline__ u32 seed_filter(const PgDevParams &prm, const Search &S, const Query<NB> &Q,
                                            bool kindB, int lane)
 {
     u32 lo = (u32)uni((int)(u32)q_lo<NB>(Q, 0)), hi = (u32)uni((int)(u32)q_hi<NB>(Q, 0));
@@ -473,13 +519,13 @@ __device__ __forceinline__ u32 seed_filter(const PgDevParams &prm, const Search<
 // Scan the positions of [s, e) outside [xs, xe) (wo = word index of AbsLoc 0 of the chromosome).
 // The window is cut into 2048-position chunks on the grid g0 + 2048 k; a chunk is staged into LDS
 // (up to e_max, so that later nested ranges find it resident), every lane filters one 32-position
-// word per candidate kind (seed_filter), the surviving positions are compacted into the LDS queue
-// and go through dense_pass 64 at a time.  cache*: filter masks of chunk 0 of the far-end window,
-// computed once and reused by the nested ranges.
-template <int NB, typename Cell, bool MIXED>
-__device__ __forceinline__ void scan_impl(const PgDevRef &ref, const PgDevParams &prm, Search<Cell> &S,
-                                          const Query<NB> &Q, long long wo, int g0, int s, int e, int e_max,
-                                          int xs, int xe, int origin, u32 region, int lane,
+// word per candidate kind (seed_filter); the survivors get queue slots from a wave prefix sum of the
+// per-lane popcounts and go through fold_candidates 64 at a time.  cache*: filter masks of chunk 0 of
+// the far-end window, computed once and reused by the nested ranges.
+template <int NB, typename Id, bool MIXED>
+__device__ __forceinline__ void scan_impl(const PgDevRef &ref, const PgDevParams &prm, Search &S,
+                                          const Query<NB> &Q, Acc<NB, Id> &A, long long wo, int g0, int s, int e,
+                                          int e_max, int xs, int xe, int origin, u32 region, int lane,
                                           bool use_cache, u32 &cacheF, u32 &cacheB, bool &cache_valid)
 {
     if (!Q.first_ok || s >= e) return;
@@ -495,248 +541,226 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, const PgDevParams
         // base (a close-end window that happens to start where this chunk starts) may be shorter.
         const int se = e_max < cs + (int)PG_CHUNK ? e_max : cs + (int)PG_CHUNK;
         if (!(wo == S.win_wo && S.wbase == wb && se + 64 * NB <= S.win_hi))
-        {
-            stage_window<NB, Cell>(ref, S, wo, wb, se + 64 * NB, lane);
-#if defined(PG_DUP) && PG_DUP == 2
-            stage_window<NB, Cell>(ref, S, wo, wb, se + 64 * NB, opaque(lane));
-#endif
-        }
+            stage_window<NB>(ref, S, wo, wb, se + 64 * NB, lane);
         const int pbase = cs + 32 * lane;
         const u32 rmask = bits32(ns - pbase, ne - pbase) & ~bits32(xs - pbase, xe - pbase);
         const bool cached = use_cache && k == 0 && cache_valid;
-        int qn = 0;                                          // queued survivors (uniform)
-#pragma unroll 1
-        for (int kb = 0; kb < 3; kb++) {                     // kind F, kind B, drain
-            u32 pm = 0u;
-            if (kb < 2 && (kb ? Q.allowB : Q.allowF)) {
-                u32 m;
-                if (cached) m = kb ? cacheB : cacheF;
-                else {
-                    m = seed_filter<NB, Cell>(prm, S, Q, kb != 0, lane);
-#if defined(PG_DUP) && PG_DUP == 3
-                    m &= seed_filter<NB, Cell>(prm, S, Q, kb != 0, opaque(lane)) | (u32)opaque(0);
-#endif
-                    if (use_cache && k == 0) { if (kb) cacheB = m; else cacheF = m; }
-                }
-                pm = m & rmask;
+        u32 mF = 0u, mB = 0u;
+        if (Q.allowF) {
+            if (cached) mF = cacheF;
+            else {
+                mF = seed_filter<NB>(prm, S, Q, false, lane);
+                if (use_cache && k == 0) cacheF = mF;
             }
-            for (;;) {
-                const bool more = __any(pm != 0u);
-                if (more) {
-                    const bool act = pm != 0u;
-                    const int bit = __ffs((int)pm) - 1;
-                    pm &= pm - 1u;
-                    const u64 bm = ballot64(act);
-                    if (act)
-                        S.queue[qn + __popcll(bm & low_bits(lane))] =
-                            ((u32)(64 * NB + 32 * lane + bit) << 1) | (u32)kb;
-                    const int add = __popcll(bm);
-                    qn += add;
-                    S.nsurv += add;
-                }
-                const bool drain = !more && kb == 2 && qn > 0;
-                if (qn >= WAVE || drain) {
-                    const int n = qn < WAVE ? qn : WAVE;
-                    __syncthreads();
-#ifndef PG_ABL_NODENSE
-                    dense_pass<NB, Cell, MIXED>(S, Q, wb, origin, region, n, lane);
-#if defined(PG_DUP) && PG_DUP == 4
-                    __syncthreads();
-                    dense_pass<NB, Cell, MIXED>(S, Q, wb, origin, region, n, opaque(lane), true);
-                    __syncthreads();
-                    dense_pass<NB, Cell, MIXED>(S, Q, wb, origin, region, n, opaque(lane));
-#endif
-#endif
-                    __syncthreads();
-                    // move the remainder (< 128 entries) to the front
-                    const int rem = qn - n;
-                    const u32 m0 = (lane < rem) ? S.queue[WAVE + lane] : 0u;
-                    const u32 m1 = (WAVE + lane < rem) ? S.queue[2 * WAVE + lane] : 0u;
-                    __syncthreads();
-                    if (lane < rem) S.queue[lane] = m0;
-                    if (WAVE + lane < rem) S.queue[WAVE + lane] = m1;
-                    qn = rem;
-                } else if (!more) break;
+            mF &= rmask;
+        }
+        if (Q.allowB) {
+            if (cached) mB = cacheB;
+            else {
+                mB = seed_filter<NB>(prm, S, Q, true, lane);
+                if (use_cache && k == 0) cacheB = mB;
             }
+            mB &= rmask;
         }
         if (use_cache && k == 0) cache_valid = true;
+        // queue slots: exclusive prefix sum of the per-lane survivor counts (a lane's F survivors first)
+        const u32 cnt = (u32)(__popc(mF) + __popc(mB));
+        const u32 incl = wave_scan(cnt);
+        const int total = (int)read_lane(incl, 63);
+        int slot = (int)(incl - cnt);
+        for (int base = 0; base < total; base += WAVE) {
+            __syncthreads();
+            const int top = base + WAVE;
+            while (mF != 0u && slot < top) {
+                const int bit = __ffs((int)mF) - 1;
+                mF &= mF - 1u;
+                S.queue[slot - base] = (u32)(64 * NB + 32 * lane + bit) << 1;
+                slot++;
+            }
+            while (mF == 0u && mB != 0u && slot < top) {
+                const int bit = __ffs((int)mB) - 1;
+                mB &= mB - 1u;
+                S.queue[slot - base] = ((u32)(64 * NB + 32 * lane + bit) << 1) | 1u;
+                slot++;
+            }
+            const int n = total - base < WAVE ? total - base : WAVE;
+            S.nsurv += n;
+            __syncthreads();
+            fold_candidates<NB, Id, MIXED>(S, Q, A, wb, origin, region, n, lane);
+        }
     }
-    __syncthreads();
 }
 
-template <int NB, typename Cell>
-__device__ __forceinline__ void scan_range(const PgDevRef &ref, const PgDevParams &prm, Search<Cell> &S,
-                                           const Query<NB> &Q, long long wo, int g0, int s, int e, int e_max,
-                                           int xs, int xe, int origin, u32 region, int lane,
+template <int NB, typename Id>
+__device__ __forceinline__ void scan_range(const PgDevRef &ref, const PgDevParams &prm, Search &S,
+                                           const Query<NB> &Q, Acc<NB, Id> &A, long long wo, int g0, int s, int e,
+                                           int e_max, int xs, int xe, int origin, u32 region, int lane,
                                            bool use_cache, u32 &cacheF, u32 &cacheB, bool &cache_valid)
 {
     // window coordinates come out of LDS / per-read loads: tell the compiler they are wave-uniform
     g0 = uni(g0); s = uni(s); e = uni(e); e_max = uni(e_max); xs = uni(xs); xe = uni(xe); origin = uni(origin);
     if (Q.allowF && Q.allowB)
-        scan_impl<NB, Cell, true>(ref, prm, S, Q, wo, g0, s, e, e_max, xs, xe, origin, region, lane,
-                                  use_cache, cacheF, cacheB, cache_valid);
+        scan_impl<NB, Id, true>(ref, prm, S, Q, A, wo, g0, s, e, e_max, xs, xe, origin, region, lane,
+                                use_cache, cacheF, cacheB, cache_valid);
     else
-        scan_impl<NB, Cell, false>(ref, prm, S, Q, wo, g0, s, e, e_max, xs, xe, origin, region, lane,
-                                   use_cache, cacheF, cacheB, cache_valid);
+        scan_impl<NB, Id, false>(ref, prm, S, Q, A, wo, g0, s, e, e_max, xs, xe, origin, region, lane,
+                                 use_cache, cacheF, cacheB, cache_valid);
 }
 
 // ---------------------------------------------------------------------------------
 // Where the candidates of a search live.
 struct RegionInfo {
-    int chr;                 // range / close searches: one region on `chr` ...
-    long long wo;            // ... whose AbsLoc 0 is at word index wo, positions relative to `origin`
+    int chr;                 // range / close searches: one region on `chr`, positions relative to `origin`
     int origin;
     const pg_window *bd;     // non-null: BreakDancer cluster search, regions from the window list
 };
 
-// Evaluate the reference's emission rules for every L (lanes own L).  The runs with index in
-// [skip, skip+cap) are written to out[0..cap); the total number of runs is returned, so a caller
-// whose buffer is too small can come back for the next chunk.  max_len = LengthStr of the last
-// emitted point (0 if none).  The histogram is not modified.
-template <int NB, typename Cell>
-__device__ __forceinline__ int evaluate(const PgDevRef &ref, const PgDevParams &prm, const Search<Cell> &S,
-                                        const Query<NB> &Q, const RegionInfo &R, pg_run *out, int skip,
-                                        int cap, int &max_len, int lane)
+// What evaluate leaves behind for the emission of the runs (registers): per round the lane's winner and
+// the ballots that delimit the runs.
+template <int NB, typename Id>
+struct Eval {
+    Id id[NB];
+    u32 lo[NB];
+    u64 candm[NB], startm[NB], brkm[NB];
+    int rounds;              // rounds evaluated (the last one may have been cut by the abort rule)
+    int n_runs, max_len;
+    Id id_last;              // winner of the last emitted point
+    int len_last;            // its LengthStr
+};
+
+// The reference's rules for every L (lanes own L): "if (minimumNumberOfMismatches > g_maxMismatch[L]) return"
+// (searcher.cpp:167, pindel.cpp:2836), emission iff the lowest level holds exactly one position and the
+// levels up to +ADDITIONAL_MISMATCH hold no other (searcher.cpp:171-191, pindel.cpp:2849-2893), after
+// CheckMismatches (already folded into A.ok).  The reduction itself is not modified.
+template <int NB, typename Id>
+__device__ __forceinline__ void evaluate(const PgDevParams &prm, const Search &S, const Acc<NB, Id> &A,
+                                         Eval<NB, Id> &E, int lane)
 {
-    typedef CellFmt<Cell> F;
-    int n_runs = 0;
-    max_len = 0;
-    // G[k](bps) = sum over l <= k of the candidates that entered at level l
-    __syncthreads();
-    {
-        Cell g = lane < S.T ? S.ginit[lane] : (Cell)0;
-        g = group_scan<Cell>(g, lane & 15, 16);
-        if (lane < S.T) S.carry[lane] = g;
+    E.n_runs = 0;
+    E.max_len = 0;
+    E.rounds = 0;
+    E.id_last = 0;
+    E.len_last = 0;
+    // tier A lives in four 16-lane quarters: bring quarters 1..3 to quarter 0 through LDS and merge
+    u32 t1 = A.m1[0], t2 = A.m2[0], tok = A.ok[0];
+    Id tid = A.id[0];
+    if (S.tierA) {
+        __syncthreads();
+        S.bufA[lane] = make_uint4(A.a1, A.a2 | (A.aok << 16), (u32)A.aid, (u32)((u64)A.aid >> 32));
+        __syncthreads();
+        u32 a1 = PG_BIG, a2 = PG_BIG, aok = 0u;
+        Id aid = 0;
+        if (lane < 16) {
+            a1 = A.a1; a2 = A.a2; aok = A.aok; aid = A.aid;
+#pragma unroll
+            for (int q = 1; q < 4; q++) {
+                const uint4 o = S.bufA[lane + 16 * q];
+                const Id oid = sizeof(Id) == 8 ? (Id)((u64)o.z | ((u64)o.w << 32)) : (Id)o.z;
+                merge<Id>(a1, a2, aid, aok, o.x, o.y & 0xffffu, oid, o.y >> 16);
+            }
+        }
+        merge<Id>(t1, t2, tid, tok, a1, a2, aid, aok);
+        __syncthreads();
     }
-    __syncthreads();
-    // Lanes own L and one DPP wave scan per level turns the differences into G[k](L); lane k of cv
-    // carries G[k] at the end of the previous 64-length round.
-    Cell cv = lane < S.T ? S.carry[lane] : (Cell)0;
     bool aborted = false;
-    for (int r0 = S.bps; r0 <= S.len - 1 && !aborted; r0 += WAVE) {
+#pragma unroll
+    for (int r = 0; r < NB; r++) {
+        E.candm[r] = E.startm[r] = 0ull;
+        E.brkm[r] = ~0ull;
+        E.id[r] = 0;
+        E.lo[r] = 0u;
+        const int r0 = S.bps + 64 * r;
+        if (r0 > S.len - 1 || aborted) continue;          // uniform
         const int L = r0 + lane;
         const bool valid = L <= S.len - 1;
-        int lo = -1;
-        u32 cnt_lo = 0, sumw = 0;
-        u64 id_lo = 0;
-        {
-            u32 zc = 0u, n1 = 0u;
-            Cell gid = 0;
-            for (int k = 0; k < S.T; k++) {
-                const Cell d = valid ? S.hist[k * S.lh + L] : (Cell)0;
-                const Cell g = wave_scan(d) + read_lane(cv, k);
-                const Cell g63 = read_lane(g, 63);
-                cv = lane == k ? g63 : cv;
-                // G[k](L) is non-decreasing in k, so three counters say everything the rules need:
-                // zc = levels <= M with G = 0 (= the lowest non-empty level, M+1 if none), n1 = levels
-                // with G = 1 (a block starting at zc when G[zc] = 1, hence G[zc] = G[zc+ADD] = 1 <=>
-                // n1 > ADD) and the candidate id of any level with G = 1 (the same single candidate)
-                const u32 cnt = (u32)(g & (Cell)((1ull << F::CB) - 1ull));
-                zc += (k <= S.M && cnt == 0u) ? 1u : 0u;
-                n1 += cnt == 1u ? 1u : 0u;
-                gid = cnt == 1u ? g : gid;
-            }
-            lo = (int)zc <= S.M ? (int)zc : -1;
-            cnt_lo = sumw = n1 > (u32)S.add_mm ? 1u : 0u;
-            id_lo = (u64)(gid >> F::CB);
-        }
-        int mmL = 0;                                  // g_maxMismatch[L] (<= M for L <= len)
-        for (int k = 0; k < S.M; k++) mmL += (valid && (u32)L >= prm.mm_bp[k]) ? 1 : 0;
-        // "if (minimumNumberOfMismatches(...) > g_maxMismatch[L]) return;"
-        const bool abortL = valid && ((lo < 0 ? S.M + 1 : lo) > mmL);
-        const u64 ab = ballot64(abortL);
+        const u32 m1 = r == 0 ? t1 : A.m1[r], m2 = r == 0 ? t2 : A.m2[r], ok = r == 0 ? tok : A.ok[r];
+        const Id wid = r == 0 ? tid : A.id[r];
+        int mmL = 0;                                      // g_maxMismatch[L] (<= M for L <= len)
+        for (int k = 0; k < S.M; k++) mmL += (u32)L >= prm.mm_bp[k] ? 1 : 0;
+        const u32 lo = m1 <= (u32)S.M ? m1 : (u32)S.M + 1u;
+        const u64 ab = ballot64(valid && lo > (u32)mmL);
         const int first_abort = ab ? __ffsll((long long)ab) - 1 : WAVE;
-        // cumulative counts: G[lo] == 1 and G[lo+ADD] == 1 <=> the level-lo position is the only one
-        // within ADDITIONAL_MISMATCH extra mismatches; its id is the id field of G[lo+ADD]
-        bool cand = valid && lane < first_abort && lo >= 0 && cnt_lo == 1 && L >= S.bps + lo &&
-                    sumw == 1;
-        // ---- CheckMismatches (searcher.cpp:331-388) on the singleton
-        bool isB = false;
-        int p = 0;
-        int chr = R.chr;
-        if (cand) {
-            u32 rel = (u32)(id_lo & ((1ull << F::RB) - 1ull));
-            isB = (id_lo >> F::RB) & 1ull;
-            u32 region = (u32)(id_lo >> (F::RB + 1));
-            int origin = R.origin;
-            long long wo = R.wo;
-            if (R.bd) {
-                pg_window w = R.bd[region];
-                chr = w.chr_id;
-                wo = (long long)ref.chr_word_off[chr];
-                int st = w.start < 0 ? w.end - 1 : w.start;
-                origin = st;
-            }
-            p = origin + (int)rel;
-            const bool comp = isB ? Q.cB : Q.cF;
-            // the whole read placed at the candidate lies inside the staged window?
-            const bool in_lds = wo == S.win_wo && (isB ? (p - 64 * NB + 1 >= S.win_lo && p < S.win_hi)
-                                                       : (p >= S.win_lo && p + 64 * NB <= S.win_hi));
-            int ham = 0;
-            bool bad = false;
-#pragma unroll
-            for (int b = 0; b < NB; b++) {
-                if (64 * b < S.len) {
-                    u64 rlo, rhi, rnn, mis, sne;
-                    int q = isB ? p - 64 * b - 63 : p + 64 * b;
-                    if (in_lds) fetch_lds(S.win, S.wbase, q, isB, rlo, rhi, rnn);
-                    else fetch_global(ref, wo, q, isB, rlo, rhi, rnn);
-                    block_masks<NB>(Q, b, comp, rlo, rhi, rnn, mis, sne);
-                    ham += __popcll(mis & low_bits(S.len - 64 * b));
-                    bad |= (sne & bit_range(L - S.min_perfect - 64 * b, L - 64 * b)) != 0;
-                }
-            }
-            bool len_ok = isB ? (L >= S.min_perfect) : (L > S.min_perfect);
-            cand = len_ok && !bad && ham >= S.thr;
-        }
-        // ---- run-length encode consecutive points of the same candidate / level
-        const u64 key = cand ? ((id_lo << 8) | (u64)(lo + 1)) : 0ull;
+        const bool cand = valid && lane < first_abort && m1 <= (u32)S.M && m2 > m1 + (u32)S.add_mm &&
+                          (u32)L >= (u32)S.bps + m1 && ok != 0u;
+        // run-length encode consecutive points of the same candidate / level
+        const u64 key = cand ? (((u64)wid << 8) | (u64)(lo + 1u)) : 0ull;
         const u64 prev_key = wave_shr1(key);   // lane 0 gets 0: runs never span two 64-length rounds
         const bool start = cand && key != prev_key;
-        const u64 starts = ballot64(start);
-        const u64 brk = ballot64(start || !cand);
-        if (start) {
-            u64 higher = lane == 63 ? 0ull : (brk & ~low_bits(lane + 1));
-            int end_lane = higher ? __ffsll((long long)higher) - 2 : WAVE - 1;
-            int idx = n_runs + __popcll(starts & low_bits(lane)) - skip;
-            if (idx >= 0 && idx < cap) {
-                pg_run run;
-                run.abs_loc_first = isB ? (u32)(p - L + 1) : (u32)(p + L - 1);
-                run.len_first = (uint16_t)L;
-                run.len_last = (uint16_t)(r0 + end_lane);
-                run.mismatches = (uint8_t)lo;
-                bool anti = isB ? Q.antisenseB : Q.antisenseF;
-                run.flags = (uint8_t)((isB ? PG_RUN_BACKWARD : 0u) | (anti ? PG_RUN_ANTISENSE : 0u));
-                run.chr_id = (int16_t)chr;
-                out[idx] = run;
-            }
+        E.id[r] = wid;
+        E.lo[r] = lo;
+        E.candm[r] = ballot64(cand);
+        E.startm[r] = ballot64(start);
+        E.brkm[r] = ballot64(start || !cand);
+        E.rounds = r + 1;
+        E.n_runs += __popcll(E.startm[r]);
+        if (E.candm[r]) {
+            const int top = 63 - __clzll((long long)E.candm[r]);
+            E.max_len = r0 + top;
+            E.len_last = r0 + top;
+            E.id_last = read_lane(wid, top);
         }
-        n_runs += __popcll(starts);
-        const u64 em = ballot64(cand);
-        if (em) max_len = r0 + 63 - __clzll((long long)em);
         if (ab) aborted = true;
     }
-    __syncthreads();
-    return n_runs;
 }
 
-template <typename Cell>
-__device__ __forceinline__ void zero_hist(const Search<Cell> &S, int lane)
+// Number of runs emit_runs will write: all of them (far end), or those of the candidate of the last point
+// (close end: CleanUniquePoints, pindel.cpp:2904-2941, keeps the points whose implied read terminal equals
+// the last point's = the runs of the last run's candidate).
+template <int NB, typename Id>
+__device__ __forceinline__ int count_kept(const Eval<NB, Id> &E, bool only_last)
 {
-    __syncthreads();
-    // hist is 16-byte aligned; its padded tail belongs to it (pg_lds_layout)
-    const int n16 = (int)(((size_t)S.T * S.lh * sizeof(Cell) + 15) / 16);
-    uint4 *h = (uint4 *)S.hist;
-    for (int i = lane; i < n16; i += WAVE) h[i] = make_uint4(0u, 0u, 0u, 0u);
-    if (lane < PG_MAX_LEVELS) S.ginit[lane] = (Cell)0;
-    __syncthreads();
+    if (!only_last) return E.n_runs;
+    int n = 0;
+#pragma unroll
+    for (int r = 0; r < NB; r++)
+        if (r < E.rounds) n += __popcll(E.startm[r] & ballot64(E.id[r] == E.id_last));
+    return n;
 }
 
+template <int NB, typename Id>
+__device__ __forceinline__ void emit_runs(const Search &S, const Query<NB> &Q, const RegionInfo &R,
+                                          const Eval<NB, Id> &E, bool only_last, pg_run *out, int lane)
+{
+    typedef IdFmt<Id> F;
+    int written = 0;
+#pragma unroll
+    for (int r = 0; r < NB; r++) {
+        if (r >= E.rounds || E.startm[r] == 0ull) continue;          // uniform
+        const bool keep = !only_last || E.id[r] == E.id_last;
+        const u64 km = E.startm[r] & ballot64(keep);
+        if (((E.startm[r] >> lane) & 1ull) && keep) {
+            const int L = S.bps + 64 * r + lane;
+            const u64 higher = lane == 63 ? 0ull : (E.brkm[r] & ~low_bits(lane + 1));
+            const int end_lane = higher ? __ffsll((long long)higher) - 2 : WAVE - 1;
+            const u64 id = (u64)E.id[r];
+            const u32 rel = (u32)(id & ((1ull << F::RB) - 1ull));
+            const bool isB = (id >> F::RB) & 1ull;
+            int chr = R.chr, origin = R.origin;
+            if (R.bd) {
+                const pg_window w = R.bd[(u32)(id >> (F::RB + 1))];
+                chr = w.chr_id;
+                origin = w.start < 0 ? w.end - 1 : w.start;
+            }
+            const int p = origin + (int)rel;
+            pg_run run;
+            run.abs_loc_first = isB ? (u32)(p - L + 1) : (u32)(p + L - 1);
+            run.len_first = (uint16_t)L;
+            run.len_last = (uint16_t)(S.bps + 64 * r + end_lane);
+            run.mismatches = (uint8_t)E.lo[r];
+            const bool anti = isB ? Q.antisenseB : Q.antisenseF;
+            run.flags = (uint8_t)((isB ? PG_RUN_BACKWARD : 0u) | (anti ? PG_RUN_ANTISENSE : 0u));
+            run.chr_id = (int16_t)chr;
+            out[written + __popcll(km & low_bits(lane))] = run;
+        }
+        written += __popcll(km);
+    }
+}
 
 // ---------------------------------------------------------------------------------
 template <int NB>
 __device__ __forceinline__ void load_planes(const uint8_t *seq, int len, int lane, u64 *qp)
 {
+    __syncthreads();
 #pragma unroll
     for (int b = 0; b < NB; b++) {
         int idx = 64 * b + lane;
@@ -767,7 +791,7 @@ __device__ __forceinline__ u32 pool_alloc(const PgDevBatch &B, int n, int lane, 
     const u32 shard = blockIdx.x & (PG_POOL_SHARDS - 1u);
     u32 off = 0;
     if (n > 0 && lane == 0) off = atomicAdd(B.pool_used + shard * 16u, (u32)n);
-    off = __shfl(off, 0, WAVE);
+    off = (u32)uni((int)off);
     fits = (u64)off + (u64)n <= (u64)B.pool_shard_cap;
     return shard * B.pool_shard_cap + off;
 }
@@ -779,68 +803,31 @@ __device__ __forceinline__ bool first_base_ok(const Query<NB> &Q)
     return (x & 1u) == 0u;
 }
 
-// One read per 64-thread workgroup.  The read goes through a sequence of search STEPS that share
-// one scan site and one evaluate site:
+// One read.  The read goes through a sequence of search STEPS that share one scan site and one
+// evaluate site:
 //   steps 0..3  close-end attempts (R0,seq) (R0,RC) (R1,RC) (R1,seq)   pindel.cpp:2537-2575
 //   step  4     far end, BreakDancer cluster                            pindel.cpp:1006-1018
 //   steps 5..   far end, ranges r = 1 .. MaxRangeIndex+1                pindel.cpp:1025-1070
-template <int NB, typename Cell, int mode>
-__global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevRef ref, PgDevParams prm,
-                                                         PgDevBatch B, uint32_t max_len, uint32_t levels)
+template <int NB, typename Id, int mode>
+__device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevParams &prm, const PgDevBatch &B,
+                                            Search &S, u64 *qplanes, const uint32_t rid, const int lane)
 {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int lane = threadIdx.x;
-    if (blockIdx.x >= B.n_reads) return;
-    // XCD-aware read order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so
-    // workgroup b runs on XCD b % 8.  Give every XCD a CONTIGUOUS eighth of the reads: the per-read input
-    // and output fields of neighbouring reads share cache lines, which then live in one L2 instead of
-    // being fetched and written back by up to eight.
-    uint32_t local = blockIdx.x;
-    {
-        const uint32_t per = B.n_reads / PG_N_XCD;
-        if (local < per * PG_N_XCD) local = (local % PG_N_XCD) * per + local / PG_N_XCD;
-    }
-    const uint32_t rid = B.first_read + local;
-
-    const PgLdsLayout lay = pg_lds_layout(max_len, levels, NB, (uint32_t)sizeof(Cell));
-    Search<Cell> S;
-    S.hist = (Cell *)(smem + lay.hist_off);
-    S.ginit = (Cell *)(smem + lay.carry_off);
-    S.carry = S.ginit + PG_MAX_LEVELS;
-    S.queue = (u32 *)(smem + lay.queue_off);
-    S.win = (uint4 *)(smem + lay.win_off);
-    S.eq = (u32 *)(smem + lay.eq_off);
-    S.eq_stride = (int)lay.win_words;
-    pg_run *runs_tmp = (pg_run *)(smem + lay.runs_off);
-    S.lh = (int)lay.lh;
     S.win_wo = -1;
     S.win_lo = S.win_hi = S.wbase = 0;
     S.nsurv = 0;
 
     const u64 off = B.seq_off[rid];
-    const int len = (int)(B.seq_off[rid + 1] - off);
+    const int len = uni((int)(B.seq_off[rid + 1] - off));
     const uint8_t *seq = B.seq + off;
     const int chr = uni((int)B.chr[rid]);
     const long long chr_wo = (long long)ref.chr_word_off[chr];
     const int chr_size = (int)ref.chr_size[chr];
     S.len = len;
     S.M = max_mismatch_at(prm, len);
-    S.add_mm = prm.add_mm;
     S.T = S.M + prm.add_mm + 1;
-    S.min_perfect = prm.min_perfect;
     S.thr = prm.thr_tab[len];
 
-    PT_DECL
-    u64 *qplanes = (u64 *)(smem + lay.qp_off);   // [0]: forward, [1]: reversed consumption order
     load_planes<NB>(seq, len, lane, qplanes);
-#if defined(PG_DUP) && PG_DUP == 1
-    load_planes<NB>(seq, len, opaque(lane), qplanes);
-#endif
-    PT_MARK(0)
-#if defined(PG_STOP_AFTER) && PG_STOP_AFTER == 0
-    if (lane == 0) B.rc_flag[rid] = (uint8_t)(qplanes[0] ^ qplanes[4 * NB + NB]);
-    return;
-#endif
 
     int alg8 = (mode & PG_MODE_CLOSE) ? 8 * len : 0;         // algorithmic bytes x 8; the read itself is counted once
     int flipped = 0, close_max = 0, n_close = 0, n_far = 0, far_max = 0;
@@ -859,7 +846,7 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
     const pg_window *bd = nullptr;
     if (do_far && B.bd_off) {
         const u64 b0 = B.bd_off[rid];
-        nbd = (int)(B.bd_off[rid + 1] - b0);
+        nbd = uni((int)(B.bd_off[rid + 1] - b0));
         bd = B.bd + b0;
     }
     int maxspan = 64;
@@ -871,12 +858,14 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
     int close_bases = 0, far_bases = 0;
     u32 cacheF = 0u, cacheB = 0u;                    // seed-filter masks of the innermost far-end chunk
     bool cache_valid = false;
+    Acc<NB, Id> A;
+    A.reset();
 
     int step = do_close ? 0 : 4;
     if (do_close && !(len - 1 >= prm.min_close && (strand == '+' || strand == '-')))
         step = 4;                                    // no close end possible
     bool far_ready = false;                          // far-end query configured
-    int nsurv_eval = -1;                             // S.nsurv when the histogram was last evaluated
+    int nsurv_eval = -1;                             // S.nsurv when the state was last evaluated
     while (step <= last_step) {
         const bool is_close = step < 4;
         if (!is_close && !do_far) break;
@@ -934,7 +923,7 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
                 origin = center - maxspan;
                 if (step == 5) { zero = true; ps = pe = 0; span = 64; cache_valid = false; }
                 // window of this range, clipped to the non-spacer part (pindel.cpp:1034-1043); the
-                // histogram is additive, so only the flanks the previous ranges did not cover are
+                // reduction is additive, so only the flanks the previous ranges did not cover are
                 // scanned.  Chunk grid: the innermost 2048 positions are one chunk (one LDS fill and
                 // one seed-filter pass serve the ranges up to 1024).
                 int s, e;
@@ -958,18 +947,12 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
                 span *= 4;
             }
         }
+        S.tierA = S.bps + 16 <= 32;
+        S.len_check = prm.min_perfect >= S.bps;
         Q.first_ok = first_base_ok<NB>(Q);
         if (!is_close && !Q.first_ok) break;         // far end: first base N (or not ACGT): nothing to find
-        PT_MARK(5)
-        if (zero) { zero_hist(S, opaque(lane)); S.nsurv = 0; nsurv_eval = -1; }
-#if defined(PG_DUP) && PG_DUP == 6
-        if (zero) zero_hist(S, opaque(lane));
-#endif
-        PT_MARK(4)
+        if (zero) { A.reset(); S.nsurv = 0; nsurv_eval = -1; }
         // ---------------- scan
-#ifdef PG_ABL_NOSCAN
-        nwin = 0;
-#endif
         for (int w = 0; w < nwin; w++) {
             long long wo = chr_wo;
             int s = s1, e = e1, org = origin;
@@ -987,118 +970,44 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
                 emax = e;
                 far_bases += (e > s ? e - s : 0) + 2 * len;
             }
-            scan_range<NB, Cell>(ref, prm, S, Q, wo, g0, s, e, emax, xs, xe, org, region, opaque(lane),
-                                 step >= 5, cacheF, cacheB, cache_valid);
+            scan_range<NB, Id>(ref, prm, S, Q, A, wo, g0, s, e, emax, xs, xe, org, region, opaque(lane),
+                               step >= 5, cacheF, cacheB, cache_valid);
         }
-        PT_MARK(1)
-#if defined(PG_STOP_AFTER) && PG_STOP_AFTER == 1
-        if (lane == 0) B.rc_flag[rid] = (uint8_t)S.nsurv;
-        return;
-#endif
         // ---------------- evaluate (NumberOfHits == 0 leaves UP_Far untouched, farend_searcher.cpp:87)
-        // One evaluate site inside a small pass machine.  Normally a search yields <= PG_RUN_TMP runs
-        // and every pass works on the LDS copy; with more runs the later passes re-evaluate chunk by
-        // chunk (skip = first run of the chunk).
-        //   pass 0  evaluate; decide whether the result is kept (close: any point; far: NewUPFarIsBetter)
-        //   pass 1  close end with > PG_RUN_TMP runs: fetch the last run
-        //   pass 2  close end: count the runs CleanUniquePoints keeps (pindel.cpp:2904-2941: points whose
-        //           implied read terminal equals the last point's = runs of the last run's candidate)
-        //   pass 3  write the (kept) runs to the pool
-        // An evaluation can only differ from the previous one of the same histogram if candidates were
-        // added since; an empty histogram yields no point (and "replaces" an empty UP_Far by itself).
+        // An evaluation can only differ from the previous one of the same state if candidates were
+        // folded since; an empty state yields no point (and "replaces" an empty UP_Far by itself).
         const bool fresh = S.nsurv != nsurv_eval && S.nsurv > 0;
         if (!fresh && is_close) close_max = 0;
         nsurv_eval = S.nsurv;
         if (fresh) {
-            const RegionInfo R = { chr, chr_wo, origin, step == 4 ? bd : nullptr };
-            const u32 *tmp32 = (const u32 *)runs_tmp;
-            int n = 0, mx = 0, kept = 0, wr = 0, pass = 0, skip = 0;
-            u32 base = 0, last0 = 0, last1 = 0, last2 = 0;
+            const RegionInfo R = { chr, origin, step == 4 ? bd : nullptr };
+            Eval<NB, Id> E;
+            evaluate<NB, Id>(prm, S, A, E, opaque(lane));
+            const int n = uni(E.n_runs), mx = uni(E.max_len);
             bool fits = true;
-            for (;;) {
-                if (pass == 0 || n > PG_RUN_TMP) {
-                    int mm;
-#ifdef PG_ABL_NOEVAL
-                    int nn = 0; mm = 0;
-#else
-                    int nn = evaluate<NB, Cell>(ref, prm, S, Q, R, runs_tmp, skip, PG_RUN_TMP, mm, opaque(lane));
-#if defined(PG_DUP) && PG_DUP == 5
-                    { int mm2; nn = evaluate<NB, Cell>(ref, prm, S, Q, R, runs_tmp, skip, PG_RUN_TMP, mm2, opaque(lane)); mm = mm2; }
-#endif
-#endif
-                    if (pass == 0) { n = uni(nn); mx = uni(mm); }
-                    PT_MARK(2)
-#if defined(PG_STOP_AFTER) && PG_STOP_AFTER == 2
-                    if (lane == 0) B.rc_flag[rid] = (uint8_t)(n + mx);
-                    return;
-#endif
+            if (is_close) {
+                close_max = mx;
+                if (n > 0) {
+                    const int kept = uni(count_kept<NB, Id>(E, true));
+                    const u32 base = pool_alloc(B, kept, lane, fits);
+                    if (fits) emit_runs<NB, Id>(S, Q, R, E, true, B.pool + base, opaque(lane));
+                    n_close = kept;
+                    close_base = base;
+                    // AbsLoc of the last point (getLastAbsLocCloseEnd)
+                    const u64 idl = (u64)E.id_last;
+                    const int pl = origin + (int)(u32)(idl & ((1ull << IdFmt<Id>::RB) - 1ull));
+                    const bool lb = (idl >> IdFmt<Id>::RB) & 1ull;
+                    close_last = lb ? (u32)(pl - E.len_last + 1) : (u32)(pl + E.len_last - 1);
                 }
-                if (pass == 0) {
-                    if (is_close) {
-                        close_max = mx;
-                        if (n == 0) break;
-                        if (n > PG_RUN_TMP) { pass = 1; skip = ((n - 1) / PG_RUN_TMP) * PG_RUN_TMP; }
-                        else pass = 2;
-                    } else {
-                        if (mx < far_max) break;              // the earlier UP_Far stays
-                        far_max = mx;
-                        n_far = n;
-                        far_base = 0;
-                        if (n == 0) break;
-                        base = (u32)uni((int)pool_alloc(B, n, lane, fits));
-                        far_base = base;
-                        pass = 3;
-                    }
-                    continue;
+            } else if (mx >= far_max) {                   // NewUPFarIsBetter: ">=" (farend_searcher.cpp:30-44)
+                far_max = mx;
+                n_far = n;
+                far_base = 0;
+                if (n > 0) {
+                    const u32 base = pool_alloc(B, n, lane, fits);
+                    if (fits) emit_runs<NB, Id>(S, Q, R, E, false, B.pool + base, opaque(lane));
+                    far_base = base;
                 }
-                if (pass == 1 || (pass == 2 && skip == 0 && n <= PG_RUN_TMP)) {
-                    const int li = (n - 1) - (pass == 1 ? skip : 0);
-                    last0 = (u32)uni((int)tmp32[3 * li]);
-                    last1 = (u32)uni((int)tmp32[3 * li + 1]);
-                    last2 = (u32)uni((int)tmp32[3 * li + 2]);
-                    if (pass == 1) { pass = 2; skip = 0; continue; }
-                }
-                // one chunk of runs, one run per lane
-                const int cn = n - skip < PG_RUN_TMP ? n - skip : PG_RUN_TMP;
-                u32 r0 = 0, r1 = 0, r2 = 0;
-                bool keep = lane < cn;
-                if (keep) {
-                    r0 = tmp32[3 * lane];
-                    r1 = tmp32[3 * lane + 1];
-                    r2 = tmp32[3 * lane + 2];
-                    if (is_close) {
-                        const bool back = (r2 >> 8) & PG_RUN_BACKWARD, lback = (last2 >> 8) & PG_RUN_BACKWARD;
-                        const u32 term = back ? r0 + (r1 & 0xffffu) : r0 - (r1 & 0xffffu);
-                        const u32 lterm = lback ? last0 + (last1 & 0xffffu) : last0 - (last1 & 0xffffu);
-                        keep = term == lterm && (r2 >> 8) == (last2 >> 8);   // same flags and chromosome
-                    }
-                }
-                const u64 km = ballot64(keep);
-                if (pass == 2) {
-                    kept += __popcll(km);
-                    skip += PG_RUN_TMP;
-                    if (skip >= n) {
-                        base = (u32)uni((int)pool_alloc(B, kept, lane, fits));
-                        pass = 3;
-                        skip = 0;
-                    }
-                    continue;
-                }
-                // pass 3
-                if (keep && fits) {
-                    u32 *dst = (u32 *)(B.pool + base + wr + __popcll(km & low_bits(lane)));
-                    dst[0] = r0; dst[1] = r1; dst[2] = r2;
-                }
-                wr += __popcll(km);
-                skip += PG_RUN_TMP;
-                if (skip >= n) break;
-            }
-            PT_MARK(3)
-            if (is_close && n > 0) {
-                n_close = kept;
-                close_base = base;
-                const u32 sp = (last1 >> 16) - (last1 & 0xffffu);
-                close_last = ((last2 >> 8) & PG_RUN_BACKWARD) ? last0 - sp : last0 + sp;
             }
         }
         // ---------------- next step
@@ -1127,40 +1036,84 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
         alg8 += 3 * far_bases + 96 * n_far;
         if (lane == 0) { B.far_run_off[rid] = far_base; B.far_run_cnt[rid] = (u32)n_far; }
     }
-#ifdef PG_PHASE_TIMING
-    PT_MARK(6)
-    if (B.alg_bytes && lane == 0 && rid < 65536) {      // overwrites the alg-bytes of the first reads
-        u32 *d = B.alg_bytes + (size_t)B.n_reads - 65536 * 16 + (size_t)rid * 16 + (do_close ? 0 : 8);
-        for (int k = 0; k < 8; k++) d[k] = (u32)pt_acc[k];
-    }
-    return;
-#endif
     if (B.alg_bytes && lane == 0) {
         if (do_close) B.alg_bytes[rid] = (u32)(alg8 + 4) >> 3;
         else B.alg_bytes[rid] += (u32)(alg8 + 4) >> 3;        // the far-end launch adds to the close-end launch
     }
 }
 
+// Persistent 64-thread workgroups.  The reads of the launch are split into PG_N_XCD contiguous parts; a
+// workgroup (which the dispatcher places on XCD blockIdx % 8) claims PG_CLAIM reads at a time from its own
+// part's counter and moves on to the next part when that one is exhausted.
+template <int NB, typename Id, int mode>
+__global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevRef ref, PgDevParams prm,
+                                                         PgDevBatch B, uint32_t max_len, uint32_t levels)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const PgLdsLayout lay = pg_lds_layout(max_len, levels, NB);
+    Search S;
+    S.queue = (u32 *)(smem + lay.queue_off);
+    S.win = (uint4 *)(smem + lay.win_off);
+    S.eq = (u32 *)(smem + lay.eq_off);
+    S.bufA = (uint4 *)(smem + lay.bufa_off);
+    S.bufB = smem + lay.bufb_off;
+    S.add_mm = prm.add_mm;
+    S.min_perfect = prm.min_perfect;
+    u64 *qplanes = (u64 *)(smem + lay.qp_off);   // [0]: forward, [1]: reversed consumption order
+
+    const uint32_t n = B.n_reads;
+    const uint32_t per = n / PG_N_XCD;
+    uint32_t part = blockIdx.x % PG_N_XCD, tried = 0;
+    while (tried < PG_N_XCD) {
+        const uint32_t lo = part * per, hi = part + 1 == PG_N_XCD ? n : lo + per;
+        uint32_t got = 0;
+        if (lane == 0) got = atomicAdd(B.work_ctr + part * 16u, PG_CLAIM);
+        got = (u32)uni((int)got);
+        if (got >= hi - lo) {                             // this part is exhausted
+            part = part + 1 == PG_N_XCD ? 0 : part + 1;
+            tried++;
+            continue;
+        }
+        const uint32_t first = lo + got, end = hi - first < PG_CLAIM ? hi : first + PG_CLAIM;
+        for (uint32_t i = first; i < end; i++)
+            search_read<NB, Id, mode>(ref, prm, B, S, qplanes, B.first_read + i, opaque(lane));
+    }
+}
+
 // ---------------------------------------------------------------------------------
-template <int NB, typename Cell>
+template <int NB, typename Id>
 static void launch(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch *batch, int mode,
                    uint32_t max_len, uint32_t levels, hipStream_t st, unsigned lds_pad)
 {
-    PgLdsLayout lay = pg_lds_layout(max_len, levels, NB, (uint32_t)sizeof(Cell));
-    dim3 grid(batch->n_reads), block(WAVE);
+    PgLdsLayout lay = pg_lds_layout(max_len, levels, NB);
+    // a few resident workgroups per CU (the launch is persistent); more than fit simply queue up and find
+    // the remaining chunks
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n_cu = p.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    const uint32_t chunks = (batch->n_reads + PG_CLAIM - 1) / PG_CLAIM + PG_N_XCD;
+    const uint32_t want = (uint32_t)n_cu * 4u * (uint32_t)PG_WAVES_PER_EU;
+    dim3 grid(chunks < want ? chunks : want), block(WAVE);
     // close end + far end in one launch; PG_SPLIT_LAUNCH=1 runs the two seams as separate launches
     const bool fused = getenv("PG_SPLIT_LAUNCH") == nullptr;
     if (mode == PG_MODE_BOTH && fused) {
-        hipLaunchKernelGGL((pg_search_kernel<NB, Cell, PG_MODE_BOTH>), grid, block, lay.total + lds_pad, st,
+        hipLaunchKernelGGL((pg_search_kernel<NB, Id, PG_MODE_BOTH>), grid, block, lay.total + lds_pad, st,
                            *ref, *prm, *batch, max_len, levels);
         return;
     }
     if (mode & PG_MODE_CLOSE)
-        hipLaunchKernelGGL((pg_search_kernel<NB, Cell, PG_MODE_CLOSE>), grid, block, lay.total + lds_pad, st,
+        hipLaunchKernelGGL((pg_search_kernel<NB, Id, PG_MODE_CLOSE>), grid, block, lay.total + lds_pad, st,
                            *ref, *prm, *batch, max_len, levels);
-    if (mode & PG_MODE_FAR)
-        hipLaunchKernelGGL((pg_search_kernel<NB, Cell, PG_MODE_FAR>), grid, block, lay.total + lds_pad, st,
+    if (mode & PG_MODE_FAR) {
+        if (mode & PG_MODE_CLOSE) (void)hipMemsetAsync(batch->work_ctr, 0, PG_N_XCD * 16u * sizeof(uint32_t), st);
+        hipLaunchKernelGGL((pg_search_kernel<NB, Id, PG_MODE_FAR>), grid, block, lay.total + lds_pad, st,
                            *ref, *prm, *batch, max_len, levels);
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -1218,33 +1171,33 @@ extern "C" int pg_debug_calib_stream(const void *src, size_t n_dwords, void *sin
 }
 
 // Debug/diagnostics: resident workgroups per CU the runtime predicts for the close/far kernels.
-extern "C" int pg_debug_occupancy(uint32_t max_len, uint32_t levels, int small_cells, int *close_blocks,
+extern "C" int pg_debug_occupancy(uint32_t max_len, uint32_t levels, int small_ids, int *close_blocks,
                                   int *far_blocks, unsigned *lds_bytes)
 {
     const int nb = max_len <= 128 ? 2 : (max_len <= 256 ? 4 : 8);
-    PgLdsLayout lay = pg_lds_layout(max_len, levels, nb, small_cells ? 4u : 8u);
+    PgLdsLayout lay = pg_lds_layout(max_len, levels, nb);
     *lds_bytes = lay.total;
     hipError_t e1, e2;
-    if (small_cells && nb == 2) {
+    if (small_ids && nb == 2) {
         e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(close_blocks, pg_search_kernel<2, u32, PG_MODE_CLOSE>, WAVE, lay.total);
-        e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(far_blocks, pg_search_kernel<2, u32, PG_MODE_FAR>, WAVE, lay.total);
+        e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(far_blocks, pg_search_kernel<2, u32, PG_MODE_BOTH>, WAVE, lay.total);
     } else {
         e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(close_blocks, pg_search_kernel<2, u64, PG_MODE_CLOSE>, WAVE, lay.total);
-        e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(far_blocks, pg_search_kernel<2, u64, PG_MODE_FAR>, WAVE, lay.total);
+        e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(far_blocks, pg_search_kernel<2, u64, PG_MODE_BOTH>, WAVE, lay.total);
     }
     return (int)e1 | (int)e2;
 }
 
 extern "C" int pg_launch_search(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch *batch,
-                                int mode, uint32_t max_len, uint32_t levels, int small_cells, void *stream)
+                                int mode, uint32_t max_len, uint32_t levels, int small_ids, void *stream)
 {
     if (batch->n_reads == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     // experiment knob: extra dynamic LDS per workgroup (lowers occupancy), bytes
     static const unsigned lds_pad = getenv("PG_LDS_PAD") ? (unsigned)atoi(getenv("PG_LDS_PAD")) : 0u;
-    // 64-base blocks per read: 1/2/3/4/8 with 32-bit cells (the common case), 2/4/8 with 64-bit cells
+    // 64-base blocks per read: 1/2/3/4/8 with 32-bit candidate ids (the common case), 2/4/8 with 64-bit ids
     const int nb = max_len <= 128 ? 2 : (max_len <= 256 ? 4 : 8);
-    if (small_cells) {
+    if (small_ids) {
         if (max_len <= 64) launch<1, u32>(ref, prm, batch, mode, max_len, levels, st, lds_pad);
         else if (nb == 2) launch<2, u32>(ref, prm, batch, mode, max_len, levels, st, lds_pad);
         else if (max_len <= 192) launch<3, u32>(ref, prm, batch, mode, max_len, levels, st, lds_pad);
