@@ -37,6 +37,7 @@ struct pg_ctx {
     uint32_t mm[512]{};
     uint16_t thr[512]{};
     uint16_t *d_thr = nullptr;
+    uint32_t *d_mm = nullptr;
     hipStream_t stream = nullptr, copy_stream = nullptr;   // kernels / host-to-device input copies
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // reference
@@ -71,6 +72,9 @@ struct pg_device_batch {
     pg_window *bd = nullptr;
     uint32_t *close_off = nullptr, *close_cnt = nullptr, *far_off = nullptr, *far_cnt = nullptr;
     uint32_t *alg = nullptr;
+    PgInRec *in_rec = nullptr;         // packed per-read records the kernel reads / writes (pg_device.h)
+    PgOutRec *out_rec = nullptr;
+    bool unpacked = true;              // the SoA output arrays reflect out_rec
     pg_run *pool = nullptr;
     uint32_t pool_shard_cap = 0;       // runs per shard (PG_POOL_SHARDS shards)
     uint32_t *pool_used = nullptr;     // [PG_POOL_SHARDS * 16]
@@ -204,7 +208,6 @@ PgDevParams dev_params(const pg_ctx *ctx)
                 break;
             }
     }
-    p.thr_tab = ctx->d_thr;
     return p;
 }
 
@@ -212,7 +215,7 @@ void free_batch_buffers(pg_device_batch *b)
 {
     void *ptrs[] = { b->seq, b->seq_off, b->strand, b->pos, b->isz, b->chr, b->rc_flag,
                      b->close_last, b->close_max, b->bd_off, b->bd, b->close_off, b->close_cnt,
-                     b->far_off, b->far_cnt, b->alg, b->pool, b->pool_used };
+                     b->far_off, b->far_cnt, b->alg, b->pool, b->pool_used, b->in_rec, b->out_rec };
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -288,6 +291,8 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, std::vector<
     AL(far_off, n);
     AL(far_cnt, n + 1);
     AL(alg, n);
+    AL(in_rec, n);
+    AL(out_rec, n);
     AL(pool_used, PG_POOL_SHARDS * 16 + PG_WORK_CTRS * 16);     // run-pool cursors + the launch's read counters
     b->pool_shard_cap = (uint32_t)std::min<uint64_t>((3ull * n) / PG_POOL_SHARDS + 96ull, 0x7fffffffull / PG_POOL_SHARDS);
     if (getenv("PG_TEST_TINY_POOL")) b->pool_shard_cap = 1;      // tests: force the overflow/regrow path
@@ -302,6 +307,7 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, std::vector<
         if (e == hipSuccess) e = hipMemset(b->rc_flag, 0, std::max<size_t>(n, 1));
         if (e == hipSuccess) e = hipMemset(b->close_max, 0, std::max<size_t>(n, 1) * sizeof(uint16_t));
         if (e == hipSuccess) e = hipMemset(b->alg, 0, std::max<size_t>(n, 1) * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemset(b->out_rec, 0, std::max<size_t>(n, 1) * sizeof(PgOutRec));
         if (e != hipSuccess) {
             free_batch_buffers(b);
             delete b;
@@ -326,10 +332,67 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, std::vector<
     return PG_OK;
 }
 
+PgSoaIn soa_in(const pg_ctx *ctx, const pg_device_batch *b)
+{
+    PgSoaIn a;
+    a.seq_off = b->seq_off;
+    a.strand = b->strand;
+    a.pos = b->pos;
+    a.isz = b->isz;
+    a.chr = b->chr;
+    a.bd_off = b->bd_off;
+    a.mm = ctx->d_mm;
+    a.thr = ctx->d_thr;
+    a.spacer = ctx->prm.spacer;
+    return a;
+}
+
+PgSoaOut soa_out(const pg_device_batch *b)
+{
+    PgSoaOut a;
+    a.rc_flag = b->rc_flag;
+    a.close_last = b->close_last;
+    a.close_max = b->close_max;
+    a.close_off = b->close_off;
+    a.close_cnt = b->close_cnt;
+    a.far_off = b->far_off;
+    a.far_cnt = b->far_cnt;
+    a.alg = b->alg;
+    return a;
+}
+
+// Builds the packed records of reads [lo, lo + cnt) from the SoA inputs (on the ctx stream).
+int pack_reads(pg_ctx *ctx, pg_device_batch *b, uint32_t lo, uint32_t cnt)
+{
+    const PgSoaIn a = soa_in(ctx, b);
+    int rc = pg_pack_reads(&a, b->in_rec, lo, cnt, ctx->stream);
+    if (rc) return fail(ctx, PG_E_DEVICE, std::string("pack kernel: ") + hipGetErrorString((hipError_t)rc));
+    return PG_OK;
+}
+
+// Scatters the kernel's output records into the SoA arrays the CSR scan / download read.
+int unpack_results(pg_ctx *ctx, pg_device_batch *b)
+{
+    if (b->unpacked) return PG_OK;
+    const PgSoaOut a = soa_out(b);
+    int rc = pg_unpack_results(b->out_rec, &a, b->n, ctx->stream);
+    if (rc) return fail(ctx, PG_E_DEVICE, std::string("unpack kernel: ") + hipGetErrorString((hipError_t)rc));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    b->unpacked = true;
+    return PG_OK;
+}
+
 int upload_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_device_batch **out)
 {
     std::vector<uint64_t> off;
-    return alloc_batch(ctx, reads, true, off, out);
+    int rc = alloc_batch(ctx, reads, true, off, out);
+    if (rc) return rc;
+    if ((rc = pack_reads(ctx, *out, 0, (*out)->n))) {
+        free_batch_buffers(*out);
+        delete *out;
+        *out = nullptr;
+    }
+    return rc;
 }
 
 PgDevBatch dev_batch(const pg_device_batch *b)
@@ -337,26 +400,14 @@ PgDevBatch dev_batch(const pg_device_batch *b)
     PgDevBatch d;
     d.n_reads = b->n;
     d.first_read = 0;
+    d.in = b->in_rec;
+    d.out = b->out_rec;
     d.seq = b->seq;
-    d.seq_off = b->seq_off;
-    d.strand = b->strand;
-    d.pos = b->pos;
-    d.isz = b->isz;
-    d.chr = b->chr;
-    d.rc_flag = b->rc_flag;
-    d.close_last_abs = b->close_last;
-    d.close_max_len = b->close_max;
-    d.bd_off = b->bd_off;
-    d.bd = b->bd;
-    d.close_run_off = b->close_off;
-    d.close_run_cnt = b->close_cnt;
-    d.far_run_off = b->far_off;
-    d.far_run_cnt = b->far_cnt;
+    d.bd = b->bd_off ? b->bd : nullptr;
     d.pool = b->pool;
     d.pool_shard_cap = b->pool_shard_cap;
     d.pool_used = b->pool_used;
     d.work_ctr = b->pool_used + PG_POOL_SHARDS * 16;
-    d.alg_bytes = b->alg;
     return d;
 }
 
@@ -419,6 +470,7 @@ int run_search(pg_ctx *ctx, pg_device_batch *b, int mode)
             ctx->last_runs = total;
             b->runs_used = total;
             b->modes_done |= mode;
+            b->unpacked = false;
             return PG_OK;
         }
         // overflow: grow the pool and redo the launch
@@ -448,6 +500,10 @@ int download(pg_ctx *ctx, pg_device_batch *b, pg_result *r)
     r->close_last.resize(n);
     r->close_max.resize(n);
     if (!n) return PG_OK;
+    {
+        int urc = unpack_results(ctx, b);
+        if (urc) return urc;
+    }
     uint32_t *csr[2] = { nullptr, nullptr };
     pg_run *outp[2] = { nullptr, nullptr };
     void *tmp = nullptr;
@@ -575,7 +631,7 @@ int pg_create(const pg_params *p, pg_ctx **out)
             pg_destroy(ctx);
             return PG_E_UNSUPPORTED;
         }
-    if (dev_upload(ctx, &ctx->d_thr, ctx->thr, 512)) {
+    if (dev_upload(ctx, &ctx->d_thr, ctx->thr, 512) || dev_upload(ctx, &ctx->d_mm, ctx->mm, 512)) {
         pg_destroy(ctx);
         return PG_E_DEVICE;
     }
@@ -588,6 +644,7 @@ void pg_destroy(pg_ctx *ctx)
     if (!ctx) return;
     free_reference(ctx);
     if (ctx->d_thr) (void)hipFree(ctx->d_thr);
+    if (ctx->d_mm) (void)hipFree(ctx->d_mm);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -868,6 +925,10 @@ void pg_device_batch_free(pg_ctx *ctx, pg_device_batch *b)
 int pg_debug_read_alg(pg_ctx *ctx, pg_device_batch *b, uint32_t *out, uint32_t n)
 {
     if (!ctx || !b || !out || n > b->n) return PG_E_INVALID;
+    {
+        int urc = unpack_results(ctx, b);
+        if (urc) return urc;
+    }
     HIP_TRY(ctx, hipMemcpy(out, b->alg, (size_t)n * 4, hipMemcpyDeviceToHost));
     return PG_OK;
 }
@@ -883,6 +944,10 @@ int pg_last_search_stats(const pg_ctx *ctx, double *kernel_ms, uint64_t *n_runs)
 int pg_device_batch_algorithmic_bytes(pg_ctx *ctx, pg_device_batch *b, double *bytes)
 {
     if (!ctx || !b || !bytes) return PG_E_INVALID;
+    {
+        int urc = unpack_results(ctx, b);
+        if (urc) return urc;
+    }
     std::vector<uint32_t> alg(b->n);
     if (b->n) HIP_TRY(ctx, hipMemcpy(alg.data(), b->alg, (size_t)b->n * 4, hipMemcpyDeviceToHost));
     double s = 0.0;
@@ -941,7 +1006,8 @@ static int search_host(pg_ctx *ctx, const pg_read_batch *reads, int mode, pg_res
                 e = hipEventRecord(ev, cs);
             }
             if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ev, 0);
-            if (e == hipSuccess) rc = launch_range(ctx, b, mode, lo, cn);
+            if (e == hipSuccess) rc = pack_reads(ctx, b, lo, cn);
+            if (e == hipSuccess && rc == PG_OK) rc = launch_range(ctx, b, mode, lo, cn);
         }
         if (e == hipSuccess) e = hipEventRecord(ctx->ev1, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -958,6 +1024,7 @@ static int search_host(pg_ctx *ctx, const pg_read_batch *reads, int mode, pg_res
             ctx->last_runs = total;
             b->runs_used = total;
             b->modes_done |= mode;
+            b->unpacked = false;
         } else if ((rc = run_search(ctx, b, mode))) {      // a pool shard overflowed: regrow and search again
             return bail(rc);
         }
@@ -992,7 +1059,7 @@ static int attach_windows(pg_ctx *ctx, pg_device_batch *b, const pg_windows *bd_
     if (b->bd_off) { (void)hipFree(b->bd_off); b->bd_off = nullptr; }
     if (b->bd) { (void)hipFree(b->bd); b->bd = nullptr; }
     b->max_bd_window = 0;
-    if (!(bd_hints && bd_hints->offset && n)) return PG_OK;
+    if (!(bd_hints && bd_hints->offset && n)) return n ? pack_reads(ctx, b, 0, b->n) : PG_OK;
     const uint64_t nw = bd_hints->offset[n];
     for (size_t i = 0; i < n; i++) {
         if (bd_hints->offset[i + 1] < bd_hints->offset[i] ||
@@ -1009,10 +1076,11 @@ static int attach_windows(pg_ctx *ctx, pg_device_batch *b, const pg_windows *bd_
         b->max_bd_window = std::max<int64_t>(b->max_bd_window, (long long)w.end - st);
     }
     int rc;
+    if (nw > 0xffffffffull) return fail(ctx, PG_E_UNSUPPORTED, "more than 2^32 BreakDancer windows in a batch");
     if ((rc = dev_upload(ctx, &b->bd_off, bd_hints->offset, n + 1)) ||
         (rc = dev_upload(ctx, &b->bd, bd_hints->windows, (size_t)nw)))
         return rc;
-    return PG_OK;
+    return pack_reads(ctx, b, 0, b->n);
 }
 
 int pg_far_end_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_result *close, const pg_windows *bd_hints)
@@ -1033,6 +1101,9 @@ int pg_far_end_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_result *close, 
             hipMemcpy(b->close_last, close->close_last.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(b->close_max, close->close_max.data(), n * 2, hipMemcpyHostToDevice) != hipSuccess)
             return bail(fail(ctx, PG_E_DEVICE, "upload of close-end summary failed"));
+        const PgSoaOut a = soa_out(b);
+        if (pg_pack_close_summary(&a, b->out_rec, b->n, ctx->stream) != 0)
+            return bail(fail(ctx, PG_E_DEVICE, "close-end summary pack kernel failed"));
     }
     if ((rc = attach_windows(ctx, b, bd_hints))) return bail(rc);
     rc = run_search(ctx, b, PG_MODE_FAR);

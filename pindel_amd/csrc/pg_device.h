@@ -30,32 +30,42 @@ struct PgDevParams {
     uint32_t spacer;
     // g_maxMismatch as breakpoints (the table is monotone): mm(L) = #{k : L >= mm_bp[k]}
     uint32_t mm_bp[16];
-    const uint16_t *thr_tab; // [512] smallest n with (float)n >= (float)(len * u)
 };
 
 enum PgMode { PG_MODE_CLOSE = 1, PG_MODE_FAR = 2, PG_MODE_BOTH = 3 };
 
+// Packed per-read records (32 bytes each, one scalar load / two vector stores per read in the search
+// kernel).  pg_pack_reads builds the input records on the device from the SoA arrays of the C ABI;
+// pg_unpack_results scatters the output records back into SoA arrays for the CSR scan / download.
+struct PgInRec {
+    uint64_t seq_off;       // offset of the read's bases in PgDevBatch::seq
+    int32_t  apos;          // anchor position + spacer (AbsLoc of MatchedRelPos)
+    int32_t  chr;           // chromosome of the anchor
+    uint16_t len;           // read length (<= PG_MAX_READ_LEN)
+    int16_t  isz;           // InsertSize
+    uint16_t thr;           // CheckMismatches: smallest n with (float)n >= (float)(len * u)
+    uint8_t  strand;        // MatchedD
+    uint8_t  M;             // g_maxMismatch[len]
+    uint32_t bd_cnt;        // BreakDancer windows of this read ...
+    uint32_t bd_off;        // ... starting at PgDevBatch::bd[bd_off]
+};
+struct PgOutRec {
+    uint32_t close_off, close_cnt, far_off, far_cnt;   // runs in the pool
+    uint32_t close_last;    // getLastAbsLocCloseEnd()
+    uint16_t close_max;     // MaxLenCloseEnd(), 0 = no close end
+    uint8_t  rc_flag;       // GetCloseEnd left the read reverse-complemented
+    uint8_t  pad;
+    uint32_t alg;           // algorithmic bytes of this read
+    uint32_t reserved;
+};
+
 struct PgDevBatch {
     uint32_t n_reads;
     uint32_t first_read;           // offset into the batch arrays handled by this launch
+    const PgInRec *in;
+    PgOutRec *out;                 // close-end fields: written in CLOSE/BOTH mode, read in FAR mode
     const uint8_t *seq;
-    const uint64_t *seq_off;
-    const uint8_t *strand;
-    const int32_t *pos;
-    const int16_t *isz;
-    const int32_t *chr;
-    // close-end summary: written in CLOSE/BOTH mode, read in FAR mode
-    uint8_t *rc_flag;
-    uint32_t *close_last_abs;      // getLastAbsLocCloseEnd()
-    uint16_t *close_max_len;       // MaxLenCloseEnd(), 0 = no close end
-    // BreakDancer hints (nullable)
-    const uint64_t *bd_off;
-    const pg_window *bd;
-    // outputs: runs go to a bump-allocated pool, (offset, count) per read
-    uint32_t *close_run_off;
-    uint32_t *close_run_cnt;
-    uint32_t *far_run_off;
-    uint32_t *far_run_cnt;
+    const pg_window *bd;           // BreakDancer windows (nullable)
     // Run pool, split into PG_POOL_SHARDS equal regions with one bump cursor each (a single
     // device-wide cursor saturates at ~88 M atomics/s, MI355X_MICROARCH.md "dequeue").  Workgroup b
     // allocates from shard b % PG_POOL_SHARDS; cursors are 64 bytes apart.
@@ -63,7 +73,25 @@ struct PgDevBatch {
     uint32_t pool_shard_cap;       // runs per shard
     uint32_t *pool_used;           // [PG_POOL_SHARDS * 16]; cursor > pool_shard_cap means overflow (retry bigger)
     uint32_t *work_ctr;            // [PG_WORK_CTRS * 16] reads claimed per XCD part (zeroed before every launch)
-    uint32_t *alg_bytes;           // [n] algorithmic bytes per read, nullable
+};
+
+// SoA views for the pack / unpack kernels
+struct PgSoaIn {
+    const uint64_t *seq_off;
+    const uint8_t *strand;
+    const int32_t *pos;
+    const int16_t *isz;
+    const int32_t *chr;
+    const uint64_t *bd_off;        // nullable
+    const uint32_t *mm;            // [512] g_maxMismatch
+    const uint16_t *thr;           // [512]
+    uint32_t spacer;
+};
+struct PgSoaOut {
+    uint8_t *rc_flag;
+    uint32_t *close_last;
+    uint16_t *close_max;
+    uint32_t *close_off, *close_cnt, *far_off, *far_cnt, *alg;
 };
 
 // Candidate id = position relative to the search origin | kind (F/B) | window index of a BreakDancer cluster.
@@ -77,39 +105,11 @@ struct PgDevBatch {
 #define PG_POOL_SHARDS 1024u
 #define PG_WORK_CTRS 8u           // per-XCD read counters of the persistent launch, 64 bytes apart
 
-// Dynamic LDS layout (bytes), computed identically on host and device.
-struct PgLdsLayout {
-    uint32_t queue_off, win_off, eq_off, qp_off, bufa_off, bufb_off, total;
-    uint32_t win_words; // LDS window capacity in 32-base words
-};
-
 #define PG_CHUNK 2048u            // window positions staged per LDS fill (= 64 lanes x 32-base words)
 #define PG_CHUNK_SHIFT 11
 #define PG_EQ_ROWS 5u
 // LDS window capacity in 32-base words: chunk + overhang of nb 64-base blocks on both sides + slack
 #define PG_WIN_WORDS(nb) ((PG_CHUNK + 2u * (64u * (nb))) / 32u + 6u)
-
-static inline
-#ifdef __HIPCC__
-__host__ __device__
-#endif
-PgLdsLayout pg_lds_layout(uint32_t max_len, uint32_t levels, uint32_t nb)
-{
-    (void)max_len;
-    (void)levels;
-    PgLdsLayout l;
-    l.queue_off = 0;                                                 // queue[64]: survivors of one candidate pass
-    l.win_off = l.queue_off + 64u * 4u;                              // window, code planes (uint4 per word)
-    l.win_words = PG_WIN_WORDS(nb);
-    // one-hot planes of the same window (rows A, C, G, T, not-N; win_words words each)
-    l.eq_off = (l.win_off + l.win_words * 16u + 15u) & ~15u;
-    // the read's bit planes: 2 orientations x (lo, hi, N, other) x nb 64-base blocks
-    l.qp_off = (l.eq_off + PG_EQ_ROWS * l.win_words * 4u + 15u) & ~15u;
-    l.bufa_off = l.qp_off + 2u * 4u * nb * 8u;                       // tier A entries: 68 x 16 bytes
-    l.bufb_off = l.bufa_off + 68u * 16u;                             // tier B entries: 64 x (16 + 16 nb) bytes
-    l.total = (l.bufb_off + 64u * (16u + 16u * nb) + 15u) & ~15u;
-    return l;
-}
 
 #ifdef __cplusplus
 extern "C" {
@@ -121,6 +121,11 @@ int pg_launch_search(const PgDevRef *ref, const PgDevParams *prm, const PgDevBat
 // Device-side CSR of a result list: first the scan (gather = 0: csr[0..n] = exclusive sums of cnt, cnt has
 // n + 1 readable entries), then the gather (gather = 1: out[csr[i] + k] = pool[off[i] + k]).
 size_t pg_scan_tmp_bytes(uint32_t n);
+// in[lo .. lo + cnt) from the SoA input arrays; cnt = 0 is allowed
+int pg_pack_reads(const PgSoaIn *soa, PgInRec *in, uint32_t lo, uint32_t cnt, void *stream);
+// close-end summary (rc flag, last AbsLoc, max length) of a host result into the output records
+int pg_pack_close_summary(const PgSoaOut *soa, PgOutRec *out, uint32_t n, void *stream);
+int pg_unpack_results(const PgOutRec *out, const PgSoaOut *soa, uint32_t n, void *stream);
 int pg_compact_runs(const pg_run *pool, const uint32_t *off, const uint32_t *cnt, uint32_t *csr,
                     pg_run *out, uint32_t n, void *tmp, size_t tmp_bytes, int gather, void *stream);
 #ifdef __cplusplus

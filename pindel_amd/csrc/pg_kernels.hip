@@ -164,13 +164,27 @@ template <int NB> __device__ __forceinline__ u64 q_hi(const Query<NB> &Q, int b)
 template <int NB> __device__ __forceinline__ u64 q_nn(const Query<NB> &Q, int b) { return Q.qp[QP_NN * NB + b]; }
 template <int NB> __device__ __forceinline__ u64 q_oo(const Query<NB> &Q, int b) { return Q.qp[QP_OO * NB + b]; }
 
+// Static LDS of a workgroup (one wave).  Static, not dynamic: every address below is a compile-time constant,
+// which keeps the five base pointers out of the scalar registers the kernel is short of.
+template <int NB>
+struct Lds {
+    uint4 win[PG_WIN_WORDS(NB)];              // staged window: code planes (lo, hi, N)
+    uint4 bufA[68];                           // tier A entries {mis0 lo, sne0 lo, id lo, meta}; scratch for the quarter merge
+    uint4 bufB[64 * (1 + NB)];                // tier B entries {id lo, meta, -, -} + NB x {mis lo, mis hi, sne lo, sne hi}
+    uint4 accB[NB > 1 ? 64 * (NB - 1) : 1];   // reduction state of the rounds >= 1 {m1, m2 | ok << 16, id lo, id hi}
+    u64 qp[2 * 4 * NB];                       // the read's bit planes, two orientations
+    u32 queue[64];                            // survivors of the prefilter for one candidate pass
+    u32 mm_bp[PG_MM_BREAKS];                  // breakpoints of g_maxMismatch (copied from the kernel arguments)
+};
+
 struct Search {
     int len, T, M, add_mm, bps, min_perfect, thr;
-    u32 *queue;          // [64] survivors of the prefilter for one candidate pass
-    uint4 *win;          // staged window: code planes (lo, hi, N)
-    u32 *eq;             // staged window: one-hot planes [5][win_words]
-    uint4 *bufA;         // [68] tier A entries {mis0 lo, sne0 lo, id lo, meta}; scratch for the quarter merge
-    unsigned char *bufB; // [64] tier B entries {id lo, meta, -, -} + NB x {mis lo, mis hi, sne lo, sne hi}
+    u32 *queue;
+    uint4 *win;
+    uint4 *bufA;
+    uint4 *bufB;
+    uint4 *accB;
+    const u32 *mm_bp;    // LDS copy of PgDevParams::mm_bp
     // what the LDS window currently holds: bases [win_lo, win_hi) of the chromosome whose AbsLoc 0 is
     // at word index win_wo; the first staged base is wbase = win_lo (any alignment)
     long long win_wo;
@@ -180,19 +194,22 @@ struct Search {
     bool len_check;      // Min_Perfect_Match_Around_BP >= bps: the "L > m" test of CheckMismatches can fail
 };
 
-// Running reduction of a search (registers).  Tier B: lane owns L = bps + 64 r + lane in round r.
-// Tier A: lane = 16 q + j owns L = bps + j; quarter q holds a partial reduction.
+// Running reduction of a search.  Tier B: lane owns L = bps + 64 r + lane in round r; round 0 lives in
+// registers, the rounds >= 1 (touched only by candidates that match 64+ bases) in LDS (Lds::accB), `dirty`
+// says which of them hold anything.  Tier A: lane = 16 q + j owns L = bps + j; quarter q holds a partial
+// reduction (registers).
 template <int NB, typename Id>
 struct Acc {
-    u32 m1[NB], m2[NB], ok[NB];
-    Id id[NB];
+    u32 m1, m2, ok;
+    Id id;
     u32 a1, a2, aok;
     Id aid;
+    u32 dirty;
     __device__ __forceinline__ void reset()
     {
-#pragma unroll
-        for (int r = 0; r < NB; r++) { m1[r] = m2[r] = PG_BIG; ok[r] = 0u; id[r] = 0; }
+        m1 = m2 = PG_BIG; ok = 0u; id = 0;
         a1 = a2 = PG_BIG; aok = 0u; aid = 0;
+        dirty = 0u;
     }
 };
 
@@ -219,11 +236,11 @@ __device__ __forceinline__ void merge(u32 &a1, u32 &a2, Id &aid, u32 &aok, u32 b
 }
 
 // g_maxMismatch[L] from its breakpoints (the table is monotone): #{k : L >= mm_bp[k]}
-__device__ __forceinline__ int max_mismatch_at(const PgDevParams &prm, int L)
+__device__ __forceinline__ int max_mismatch_at(const u32 *mm_bp, int L)
 {
     int m = 0;
 #pragma unroll
-    for (int k = 0; k < PG_MM_BREAKS; k++) m += (u32)L >= prm.mm_bp[k] ? 1 : 0;
+    for (int k = 0; k < PG_MM_BREAKS; k++) m += (u32)L >= mm_bp[k] ? 1 : 0;
     return m;
 }
 
@@ -271,7 +288,7 @@ template <int NB, typename Id, bool MIXED>
 __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB> &Q, Acc<NB, Id> &A, int wbase,
                                                 int origin, u32 region, int n, int lane)
 {
-    constexpr int EB = 16 + 16 * NB;
+    constexpr int EW = 1 + NB;                            // uint4 words per tier B entry
     bool valid = lane < n;
     int p = 0;
     bool isB = MIXED ? false : Q.allowB;
@@ -281,10 +298,14 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
         p = wbase + (int)(e >> 1);
     }
     const bool comp = isB ? Q.cB : Q.cF;
-    u64 mis[NB], sne[NB];
+    // Per 64-base block: mismatch / inequality words go straight into the candidate's tier B entry (LDS);
+    // only popcounts stay in registers.  Words of blocks that are not computed keep stale bits: they can
+    // only add mismatches to a candidate that is dead there anyway.
+    int cum = 0, lvl0 = 0, kA = 0;
+    int kk[NB];
+    u32 m0lo = 0u, s0lo = 0u;
 #pragma unroll
-    for (int b = 0; b < NB; b++) mis[b] = sne[b] = 0ull;
-    int cum = 0;
+    for (int r = 0; r < NB; r++) kk[r] = 0;
     bool need = valid;
 #pragma unroll
     for (int b = 0; b < NB; b++) {
@@ -296,18 +317,28 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
             fetch_lds(S.win, wbase, q, isB, rlo, rhi, rnn);
             block_masks<NB>(Q, b, comp, rlo, rhi, rnn, m, s);
             const u64 lm = low_bits(S.len - 64 * b);
-            mis[b] = m & lm;
-            sne[b] = s & lm;
-            cum += __popcll(mis[b]);
+            m &= lm;
+            s &= lm;
+            S.bufB[lane * EW + 1 + b] = make_uint4((u32)m, (u32)(m >> 32), (u32)s, (u32)(s >> 32));
+            cum += __popcll(m);
+            if (b == 0) {
+                lvl0 = __popcll(m & low_bits(S.bps));
+                kA = __popc((u32)m & low32(S.bps + 16));
+                m0lo = (u32)m;
+                s0lo = (u32)s;
+            }
+#pragma unroll
+            for (int r = 1; r < NB; r++)
+                if (b <= r) kk[r] += __popcll(m & low_bits(S.bps + 64 * r - 64 * b));
         }
         // later blocks matter only while the candidate is alive (fewer than T mismatches so far) or its
         // whole-read Hamming count has not reached CheckMismatches' threshold yet
         need = need && (cum < S.T || cum < S.thr);
     }
     const u32 hamok = cum >= S.thr ? 0x80000000u : 0u;
-    valid = valid && __popcll(mis[0] & low_bits(S.bps)) < S.T;         // dead before the first length: never counts
+    valid = valid && lvl0 < S.T;                           // dead before the first length: never counts
     bool lng = valid;
-    if (S.tierA) lng = valid && __popc((u32)mis[0] & low32(S.bps + 16)) < S.T;
+    if (S.tierA) lng = valid && kA < S.T;
     const Id id = make_id<Id>((u32)(p - origin), isB, region);
     const u32 lenthr = (u32)(S.min_perfect + (isB ? 0 : 1));           // FORWARD: L > m, BACKWARD: L >= m
     const u32 meta = (u32)((u64)id >> 32) | (lenthr << 8) | hamok;
@@ -316,24 +347,12 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
     u64 longm[NB];
     longm[0] = ballot64(lng);
 #pragma unroll
-    for (int r = 1; r < NB; r++) {
-        int kk = 0;
-#pragma unroll
-        for (int b = 0; b < NB; b++)
-            if (b <= r) kk += __popcll(mis[b] & low_bits(S.bps + 64 * r - 64 * b));
-        longm[r] = ballot64(lng && kk < S.T);
-    }
+    for (int r = 1; r < NB; r++) longm[r] = ballot64(lng && kk[r] < S.T);
     if (sht) {
         const int rank = __popcll(shortm & low_bits(lane));
-        S.bufA[rank] = make_uint4((u32)mis[0], (u32)sne[0], (u32)id, meta);
+        S.bufA[rank] = make_uint4(m0lo, s0lo, (u32)id, meta);
     }
-    if (lng) {
-        uint4 *e = (uint4 *)(S.bufB + lane * EB);
-        e[0] = make_uint4((u32)id, meta, 0u, 0u);
-#pragma unroll
-        for (int b = 0; b < NB; b++)
-            e[1 + b] = make_uint4((u32)mis[b], (u32)(mis[b] >> 32), (u32)sne[b], (u32)(sne[b] >> 32));
-    }
+    if (lng) S.bufB[lane * EW] = make_uint4((u32)id, meta, 0u, 0u);
     __syncthreads();
     // ---- tier A
     const int nA = __popcll(shortm);
@@ -360,17 +379,28 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
         if (L0 > S.len - 1) break;                        // uniform
         u64 mask = longm[r];
         if (mask == 0ull) continue;                       // uniform
-        const int L = L0 + opaque(lane);
+        const int lB = opaque(lane);
+        const int L = L0 + lB;
         u64 Mk[NB], BP[NB];
 #pragma unroll
         for (int b = 0; b < NB; b++) {
             Mk[b] = low_bits(L - 64 * b);
             BP[b] = bit_range(L - S.min_perfect - 64 * b, L - 64 * b);
         }
+        u32 m1 = A.m1, m2 = A.m2, ok = A.ok;
+        Id wid = A.id;
+        if (r > 0) {
+            m1 = m2 = PG_BIG; ok = 0u; wid = 0;
+            if ((A.dirty >> r) & 1u) {
+                const uint4 st = S.accB[(r - 1) * 64 + lB];
+                m1 = st.x; m2 = st.y & 0xffffu; ok = st.y >> 16;
+                wid = sizeof(Id) == 8 ? (Id)((u64)st.z | ((u64)st.w << 32)) : (Id)st.z;
+            }
+        }
         while (mask != 0ull) {
             const int i = __ffsll((long long)mask) - 1;
             mask &= mask - 1ull;
-            const uint4 *e = (const uint4 *)(S.bufB + i * EB);
+            const uint4 *e = S.bufB + i * EW;
             const uint4 h = e[0];
             u32 k = 0u;
             u64 bad = 0ull;
@@ -378,23 +408,27 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
             for (int b = 0; b < NB; b++) {
                 if (b > r + 1) continue;                  // L <= bps + 64 r + 63 < 64 (r + 2)
                 const uint4 w = e[1 + b];
-                const u64 m = (u64)w.x | ((u64)w.y << 32), s = (u64)w.z | ((u64)w.w << 32);
+                const u64 m = (u64)w.x | ((u64)w.y << 32), sn = (u64)w.z | ((u64)w.w << 32);
                 k += (u32)__popcll(b < r ? m : (m & Mk[b]));
-                if (b + 1 >= r) bad |= s & BP[b];         // L - m >= 64 r - 64 (m <= 64 <= 64 + bps)
+                if (b + 1 >= r) bad |= sn & BP[b];        // L - m >= 64 r - 64 (m <= 64 <= 64 + bps)
             }
             u32 okc = bad == 0ull ? (h.y >> 31) : 0u;
             if (S.len_check) okc = (u32)L >= ((h.y >> 8) & 0x7fu) ? okc : 0u;
             const Id cid = sizeof(Id) == 8 ? (Id)((u64)h.x | ((u64)(h.y & 0xffu) << 32)) : (Id)h.x;
-            fold<Id>(A.m1[r], A.m2[r], A.id[r], A.ok[r], k, cid, okc);
+            fold<Id>(m1, m2, wid, ok, k, cid, okc);
+        }
+        if (r == 0) { A.m1 = m1; A.m2 = m2; A.ok = ok; A.id = wid; }
+        else {
+            S.accB[(r - 1) * 64 + lB] = make_uint4(m1, m2 | (ok << 16), (u32)wid, (u32)((u64)wid >> 32));
+            A.dirty |= 1u << r;
         }
     }
     __syncthreads();
 }
 
 // Stages bases [lo, hi) (hi - lo <= PG_CHUNK + 128 NB) of a chromosome into LDS: word i of the window
-// holds bases [lo + 32 i, lo + 32 i + 32) whatever the alignment of lo (funnel shift of two HBM words),
-// once as the code planes the candidate pass uses and once as one-hot planes (is-A, is-C, is-G, is-T,
-// is-not-N) for the bit-sliced seed filter.
+// holds bases [lo + 32 i, lo + 32 i + 32) whatever the alignment of lo (funnel shift of two HBM words), as
+// the code planes (lo, hi, N) that both the candidate pass and the seed filter read.
 template <int NB>
 __device__ __forceinline__ void stage_window(const PgDevRef &ref, Search &S, long long wo, int lo, int hi, int lane)
 {
@@ -404,18 +438,11 @@ __device__ __forceinline__ void stage_window(const PgDevRef &ref, Search &S, lon
     {
         const long long g0 = wo + (long long)(lo >> 5);     // arithmetic shift = floor
         const u32 *glo = ref.lo + g0, *ghi = ref.hi + g0, *gnn = ref.nn + g0;
-        constexpr int st = (int)PG_WIN_WORDS(NB);
         for (int i = lane; i < nw; i += WAVE) {
             const u32 x = __builtin_amdgcn_alignbit(glo[i + 1], glo[i], sh);
             const u32 y = __builtin_amdgcn_alignbit(ghi[i + 1], ghi[i], sh);
             const u32 z = __builtin_amdgcn_alignbit(gnn[i + 1], gnn[i], sh);
             S.win[i] = make_uint4(x, y, z, 0u);
-            const u32 ok = ~z;
-            S.eq[i] = ~x & ~y & ok;
-            S.eq[st + i] = x & ~y & ok;
-            S.eq[2 * st + i] = ~x & y & ok;
-            S.eq[3 * st + i] = x & y & ok;
-            S.eq[4 * st + i] = ok;
         }
     }
     __syncthreads();
@@ -459,7 +486,7 @@ __device__ __forceinline__ u32 count_le(u32 c0, u32 c1, u32 c2, u32 c3, u32 ov, 
 // c(bps) <= g_maxMismatch[J] + ADD (the table is monotone); relevant later implies alive after J bases,
 // c(J) <= T-1.  With J <= bps only the second test applies.  Anything kept beyond that is harmless.
 template <int NB>
-__device__ __forceinline__ u32 seed_filter(const PgDevParams &prm, const Search &S, const Query<NB> &Q,
+__device__ __forceinline__ u32 seed_filter(const Search &S, const Query<NB> &Q,
                                            bool kindB, int lane)
 {
     u32 lo = (u32)uni((int)(u32)q_lo<NB>(Q, 0)), hi = (u32)uni((int)(u32)q_hi<NB>(Q, 0));
@@ -471,24 +498,49 @@ __device__ __forceinline__ u32 seed_filter(const PgDevParams &prm, const Search 
     if (J > PG_SEED_J(T)) J = PG_SEED_J(T);
     const int jb = S.bps < J ? S.bps : J;
     const u32 jmask = bits32(1, J), g0mask = bits32(1, jb);
-    int cap0 = max_mismatch_at(prm, J) + S.add_mm;        // min(T-1, g_maxMismatch[J] + ADD)
+    int cap0 = uni(max_mismatch_at(S.mm_bp, J)) + S.add_mm;        // min(T-1, g_maxMismatch[J] + ADD)
     if (cap0 > T - 1) cap0 = T - 1;
     const int a = 2 * NB + lane - (kindB ? 1 : 0);         // LDS word holding the low half of the pair
-    constexpr int st = (int)PG_WIN_WORDS(NB);              // compile-time row stride: immediate LDS offsets
-
-    const int x0 = (int)((lo & 1u) | ((hi & 1u) << 1));    // first base is ACGT (first_ok)
-    const u32 seed = S.eq[x0 * st + 2 * NB + lane];
     // read symbols: A C G T N other; bases [1, jb) first, snapshot, then bases [jb, J)
     const u32 sym[6] = { ~lo & ~hi & acgt, lo & ~hi & acgt, ~lo & hi & acgt, lo & hi & acgt, nn, oo };
+    // one-hot planes (is-A, is-C, is-G, is-T, is-not-N) of the lane's two window words, from the code planes
+    const uint4 pa = S.win[a], pb = S.win[a + 1];
     u32 wl[6], wh[6];
-#pragma unroll
-    for (int X = 0; X < 5; X++) {
-        wl[X] = S.eq[X * st + a];
-        wh[X] = S.eq[X * st + a + 1];
-    }
+    wl[0] = ~(pa.x | pa.y | pa.z); wh[0] = ~(pb.x | pb.y | pb.z);
+    wl[1] = pa.x & ~(pa.y | pa.z); wh[1] = pb.x & ~(pb.y | pb.z);
+    wl[2] = pa.y & ~(pa.x | pa.z); wh[2] = pb.y & ~(pb.x | pb.z);
+    wl[3] = pa.x & pa.y & ~pa.z;   wh[3] = pb.x & pb.y & ~pb.z;
+    wl[4] = ~pa.z;                 wh[4] = ~pb.z;
     wl[5] = wh[5] = 0u;                                     // symbol 5 (not ACGTN) never matches
+    // the seed: position's own base equals the first read base (first_ok: it is one of ACGT)
+    const u32 sx = kindB ? pb.x : pa.x, sy = kindB ? pb.y : pa.y, sz = kindB ? pb.z : pa.z;
+    const u32 seed = ~((sx ^ ((lo & 1u) ? ~0u : 0u)) | (sy ^ ((hi & 1u) ? ~0u : 0u)) | sz);
     u32 c0 = 0u, c1 = 0u, c2 = 0u, c3 = 0u, ov = 0u;        // mismatch count per position, bit sliced
     u32 snap = 0u;
+    if (T <= 8) {
+        // counts up to 7 decide everything (cap0 <= T - 1 <= 7): three slices + overflow, 7 VALU per base
+#pragma unroll
+        for (int it = 0; it < 12; it++) {
+            const int X = it >= 6 ? it - 6 : it;
+            if (it == 6) snap = count_le(c0, c1, c2, 0u, ov, cap0);
+            u32 pm = sym[X] & (it >= 6 ? (jmask & ~g0mask) : g0mask);
+            while (pm != 0u) {
+                const int j = __ffs((int)pm) - 1;
+                pm &= pm - 1u;
+                const u32 m = __builtin_amdgcn_alignbit(wh[X], wl[X], (u32)(kindB ? 32 - j : j));
+                u32 k0, k1;
+                asm("v_bfi_b32 %4, %6, 0, %0\n\t"          // k0 = ~m & c0
+                    "v_xnor_b32 %0, %0, %6\n\t"            // c0 ^= ~m
+                    "v_and_b32 %5, %1, %4\n\t"             // k1 = c1 & k0
+                    "v_xor_b32 %1, %1, %4\n\t"             // c1 ^= k0
+                    "v_and_or_b32 %3, %2, %5, %3\n\t"      // ov |= c2 & k1
+                    "v_xor_b32 %2, %2, %5"                   // c2 ^= k1
+                    : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(ov), "=&v"(k0), "=&v"(k1)
+                    : "v"(m));
+            }
+        }
+        return seed & (snap | count_le(c0, c1, c2, 0u, ov, T - 1));
+    }
 #pragma unroll
     for (int it = 0; it < 12; it++) {
         const int X = it >= 6 ? it - 6 : it;
@@ -523,7 +575,7 @@ __device__ __forceinline__ u32 seed_filter(const PgDevParams &prm, const Search 
 // per-lane popcounts and go through fold_candidates 64 at a time.  cache*: filter masks of chunk 0 of
 // the far-end window, computed once and reused by the nested ranges.
 template <int NB, typename Id, bool MIXED>
-__device__ __forceinline__ void scan_impl(const PgDevRef &ref, const PgDevParams &prm, Search &S,
+__device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
                                           const Query<NB> &Q, Acc<NB, Id> &A, long long wo, int g0, int s, int e,
                                           int e_max, int xs, int xe, int origin, u32 region, int lane,
                                           bool use_cache, u32 &cacheF, u32 &cacheB, bool &cache_valid)
@@ -549,7 +601,7 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, const PgDevParams
         if (Q.allowF) {
             if (cached) mF = cacheF;
             else {
-                mF = seed_filter<NB>(prm, S, Q, false, lane);
+                mF = seed_filter<NB>(S, Q, false, lane);
                 if (use_cache && k == 0) cacheF = mF;
             }
             mF &= rmask;
@@ -557,7 +609,7 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, const PgDevParams
         if (Q.allowB) {
             if (cached) mB = cacheB;
             else {
-                mB = seed_filter<NB>(prm, S, Q, true, lane);
+                mB = seed_filter<NB>(S, Q, true, lane);
                 if (use_cache && k == 0) cacheB = mB;
             }
             mB &= rmask;
@@ -592,7 +644,7 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, const PgDevParams
 }
 
 template <int NB, typename Id>
-__device__ __forceinline__ void scan_range(const PgDevRef &ref, const PgDevParams &prm, Search &S,
+__device__ __forceinline__ void scan_range(const PgDevRef &ref, Search &S,
                                            const Query<NB> &Q, Acc<NB, Id> &A, long long wo, int g0, int s, int e,
                                            int e_max, int xs, int xe, int origin, u32 region, int lane,
                                            bool use_cache, u32 &cacheF, u32 &cacheB, bool &cache_valid)
@@ -600,10 +652,10 @@ __device__ __forceinline__ void scan_range(const PgDevRef &ref, const PgDevParam
     // window coordinates come out of LDS / per-read loads: tell the compiler they are wave-uniform
     g0 = uni(g0); s = uni(s); e = uni(e); e_max = uni(e_max); xs = uni(xs); xe = uni(xe); origin = uni(origin);
     if (Q.allowF && Q.allowB)
-        scan_impl<NB, Id, true>(ref, prm, S, Q, A, wo, g0, s, e, e_max, xs, xe, origin, region, lane,
+        scan_impl<NB, Id, true>(ref, S, Q, A, wo, g0, s, e, e_max, xs, xe, origin, region, lane,
                                 use_cache, cacheF, cacheB, cache_valid);
     else
-        scan_impl<NB, Id, false>(ref, prm, S, Q, A, wo, g0, s, e, e_max, xs, xe, origin, region, lane,
+        scan_impl<NB, Id, false>(ref, S, Q, A, wo, g0, s, e, e_max, xs, xe, origin, region, lane,
                                  use_cache, cacheF, cacheB, cache_valid);
 }
 
@@ -633,7 +685,7 @@ struct Eval {
 // levels up to +ADDITIONAL_MISMATCH hold no other (searcher.cpp:171-191, pindel.cpp:2849-2893), after
 // CheckMismatches (already folded into A.ok).  The reduction itself is not modified.
 template <int NB, typename Id>
-__device__ __forceinline__ void evaluate(const PgDevParams &prm, const Search &S, const Acc<NB, Id> &A,
+__device__ __forceinline__ void evaluate(const Search &S, const Acc<NB, Id> &A,
                                          Eval<NB, Id> &E, int lane)
 {
     E.n_runs = 0;
@@ -642,8 +694,8 @@ __device__ __forceinline__ void evaluate(const PgDevParams &prm, const Search &S
     E.id_last = 0;
     E.len_last = 0;
     // tier A lives in four 16-lane quarters: bring quarters 1..3 to quarter 0 through LDS and merge
-    u32 t1 = A.m1[0], t2 = A.m2[0], tok = A.ok[0];
-    Id tid = A.id[0];
+    u32 t1 = A.m1, t2 = A.m2, tok = A.ok;
+    Id tid = A.id;
     if (S.tierA) {
         __syncthreads();
         S.bufA[lane] = make_uint4(A.a1, A.a2 | (A.aok << 16), (u32)A.aid, (u32)((u64)A.aid >> 32));
@@ -673,10 +725,18 @@ __device__ __forceinline__ void evaluate(const PgDevParams &prm, const Search &S
         if (r0 > S.len - 1 || aborted) continue;          // uniform
         const int L = r0 + lane;
         const bool valid = L <= S.len - 1;
-        const u32 m1 = r == 0 ? t1 : A.m1[r], m2 = r == 0 ? t2 : A.m2[r], ok = r == 0 ? tok : A.ok[r];
-        const Id wid = r == 0 ? tid : A.id[r];
+        u32 m1 = t1, m2 = t2, ok = tok;
+        Id wid = tid;
+        if (r > 0) {
+            m1 = m2 = PG_BIG; ok = 0u; wid = 0;
+            if ((A.dirty >> r) & 1u) {                    // uniform
+                const uint4 st = S.accB[(r - 1) * 64 + lane];
+                m1 = st.x; m2 = st.y & 0xffffu; ok = st.y >> 16;
+                wid = sizeof(Id) == 8 ? (Id)((u64)st.z | ((u64)st.w << 32)) : (Id)st.z;
+            }
+        }
         int mmL = 0;                                      // g_maxMismatch[L] (<= M for L <= len)
-        for (int k = 0; k < S.M; k++) mmL += (u32)L >= prm.mm_bp[k] ? 1 : 0;
+        for (int k = 0; k < S.M; k++) mmL += (u32)L >= S.mm_bp[k] ? 1 : 0;
         const u32 lo = m1 <= (u32)S.M ? m1 : (u32)S.M + 1u;
         const u64 ab = ballot64(valid && lo > (u32)mmL);
         const int first_abort = ab ? __ffsll((long long)ab) - 1 : WAVE;
@@ -816,16 +876,19 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     S.win_lo = S.win_hi = S.wbase = 0;
     S.nsurv = 0;
 
-    const u64 off = B.seq_off[rid];
-    const int len = uni((int)(B.seq_off[rid + 1] - off));
+    // the read's packed record: one scalar load (rid is wave-uniform)
+    const uint4 *rp = (const uint4 *)(B.in + rid);
+    const uint4 r0 = rp[0], r1 = rp[1];
+    const u64 off = (u64)r0.x | ((u64)r0.y << 32);
+    const int len = (int)(r1.x & 0xffffu);
     const uint8_t *seq = B.seq + off;
-    const int chr = uni((int)B.chr[rid]);
+    const int chr = (int)r0.w;
     const long long chr_wo = (long long)ref.chr_word_off[chr];
     const int chr_size = (int)ref.chr_size[chr];
     S.len = len;
-    S.M = max_mismatch_at(prm, len);
+    S.M = (int)(r1.y >> 24);
     S.T = S.M + prm.add_mm + 1;
-    S.thr = prm.thr_tab[len];
+    S.thr = (int)(r1.y & 0xffffu);
 
     load_planes<NB>(seq, len, lane, qplanes);
 
@@ -834,20 +897,24 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     u32 close_last = 0, close_base = 0, far_base = 0;
 
     const bool do_close = (mode & PG_MODE_CLOSE) != 0, do_far = (mode & PG_MODE_FAR) != 0;
-    const char strand = do_close ? (char)uni((int)B.strand[rid]) : '+';   // byte loads go through VMEM
-    const int apos = do_close ? uni((int)(B.pos[rid] + (int)prm.spacer)) : 0;
-    const int isz = do_close ? uni((int)B.isz[rid]) : 0;
+    const char strand = (char)((r1.y >> 16) & 0xffu);
+    const int apos = (int)r0.z;
+    const int isz = (int)(short)(r1.x >> 16);
+    u32 alg_prev = 0u;
     if (!do_close) {
-        flipped = uni((int)B.rc_flag[rid]);
-        close_last = (u32)uni((int)B.close_last_abs[rid]);
-        close_max = uni((int)B.close_max_len[rid]);
+        // far-end launch: the close-end summary of the earlier launch
+        const uint4 *op = (const uint4 *)(B.out + rid);
+        const uint4 o1 = op[1];
+        close_last = (u32)uni((int)o1.x);
+        close_max = uni((int)(o1.y & 0xffffu));
+        flipped = uni((int)((o1.y >> 16) & 0xffu));
+        alg_prev = (u32)uni((int)o1.z);
     }
     int nbd = 0;
     const pg_window *bd = nullptr;
-    if (do_far && B.bd_off) {
-        const u64 b0 = B.bd_off[rid];
-        nbd = uni((int)(B.bd_off[rid + 1] - b0));
-        bd = B.bd + b0;
+    if (do_far && B.bd) {
+        nbd = (int)r1.z;
+        bd = B.bd + r1.w;
     }
     int maxspan = 64;
     for (int i = 0; i < prm.max_range_index; i++) maxspan *= 4;
@@ -970,7 +1037,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                 emax = e;
                 far_bases += (e > s ? e - s : 0) + 2 * len;
             }
-            scan_range<NB, Id>(ref, prm, S, Q, A, wo, g0, s, e, emax, xs, xe, org, region, opaque(lane),
+            scan_range<NB, Id>(ref, S, Q, A, wo, g0, s, e, emax, xs, xe, org, region, opaque(lane),
                                step >= 5, cacheF, cacheB, cache_valid);
         }
         // ---------------- evaluate (NumberOfHits == 0 leaves UP_Far untouched, farend_searcher.cpp:87)
@@ -982,7 +1049,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
         if (fresh) {
             const RegionInfo R = { chr, origin, step == 4 ? bd : nullptr };
             Eval<NB, Id> E;
-            evaluate<NB, Id>(prm, S, A, E, opaque(lane));
+            evaluate<NB, Id>(S, A, E, opaque(lane));
             const int n = uni(E.n_runs), mx = uni(E.max_len);
             bool fits = true;
             if (is_close) {
@@ -1021,24 +1088,23 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     }
     if (do_close && n_close == 0) { flipped = 0; close_max = 0; }   // back to the original orientation
 
-    if (do_close) {
-        alg8 += 3 * (close_bases + 2 * len) + 96 * n_close;   // 3 bits per base, 12 bytes per run
-        if (lane == 0) {
-            B.rc_flag[rid] = (uint8_t)flipped;
-            B.close_last_abs[rid] = close_last;
-            B.close_max_len[rid] = (uint16_t)close_max;
-            B.close_run_off[rid] = close_base;
-            B.close_run_cnt[rid] = (u32)n_close;
-        }
-    }
+    if (do_close) alg8 += 3 * (close_bases + 2 * len) + 96 * n_close;   // 3 bits per base, 12 bytes per run
     if (do_far) {
         if (far_ready) far_bases += reach + 2 * len;
         alg8 += 3 * far_bases + 96 * n_far;
-        if (lane == 0) { B.far_run_off[rid] = far_base; B.far_run_cnt[rid] = (u32)n_far; }
     }
-    if (B.alg_bytes && lane == 0) {
-        if (do_close) B.alg_bytes[rid] = (u32)(alg8 + 4) >> 3;
-        else B.alg_bytes[rid] += (u32)(alg8 + 4) >> 3;        // the far-end launch adds to the close-end launch
+    const u32 alg = alg_prev + ((u32)(alg8 + 4) >> 3);
+    if (lane == 0) {
+        uint4 *op = (uint4 *)(B.out + rid);
+        if (do_close) {
+            op[0] = make_uint4(close_base, (u32)n_close, far_base, (u32)n_far);
+            op[1] = make_uint4(close_last, (u32)close_max | ((u32)flipped << 16), alg, 0u);
+        } else {
+            u32 *o = (u32 *)op;
+            o[2] = far_base;
+            o[3] = (u32)n_far;
+            o[6] = alg;                                  // the far-end launch adds to the close-end launch
+        }
     }
 }
 
@@ -1049,18 +1115,20 @@ template <int NB, typename Id, int mode>
 __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevRef ref, PgDevParams prm,
                                                          PgDevBatch B, uint32_t max_len, uint32_t levels)
 {
-    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ Lds<NB> lds;
     const int lane = threadIdx.x;
-    const PgLdsLayout lay = pg_lds_layout(max_len, levels, NB);
+    if (lane < PG_MM_BREAKS) lds.mm_bp[lane] = prm.mm_bp[lane];
+    __syncthreads();
     Search S;
-    S.queue = (u32 *)(smem + lay.queue_off);
-    S.win = (uint4 *)(smem + lay.win_off);
-    S.eq = (u32 *)(smem + lay.eq_off);
-    S.bufA = (uint4 *)(smem + lay.bufa_off);
-    S.bufB = smem + lay.bufb_off;
+    S.queue = lds.queue;
+    S.win = lds.win;
+    S.bufA = lds.bufA;
+    S.bufB = lds.bufB;
+    S.accB = lds.accB;
+    S.mm_bp = lds.mm_bp;
     S.add_mm = prm.add_mm;
     S.min_perfect = prm.min_perfect;
-    u64 *qplanes = (u64 *)(smem + lay.qp_off);   // [0]: forward, [1]: reversed consumption order
+    u64 *qplanes = lds.qp;                        // [0]: forward, [1]: reversed consumption order
 
     const uint32_t n = B.n_reads;
     const uint32_t per = n / PG_N_XCD;
@@ -1086,7 +1154,6 @@ template <int NB, typename Id>
 static void launch(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch *batch, int mode,
                    uint32_t max_len, uint32_t levels, hipStream_t st, unsigned lds_pad)
 {
-    PgLdsLayout lay = pg_lds_layout(max_len, levels, NB);
     // a few resident workgroups per CU (the launch is persistent); more than fit simply queue up and find
     // the remaining chunks
     static int n_cu = 0;
@@ -1102,18 +1169,92 @@ static void launch(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch
     // close end + far end in one launch; PG_SPLIT_LAUNCH=1 runs the two seams as separate launches
     const bool fused = getenv("PG_SPLIT_LAUNCH") == nullptr;
     if (mode == PG_MODE_BOTH && fused) {
-        hipLaunchKernelGGL((pg_search_kernel<NB, Id, PG_MODE_BOTH>), grid, block, lay.total + lds_pad, st,
+        hipLaunchKernelGGL((pg_search_kernel<NB, Id, PG_MODE_BOTH>), grid, block, lds_pad, st,
                            *ref, *prm, *batch, max_len, levels);
         return;
     }
     if (mode & PG_MODE_CLOSE)
-        hipLaunchKernelGGL((pg_search_kernel<NB, Id, PG_MODE_CLOSE>), grid, block, lay.total + lds_pad, st,
+        hipLaunchKernelGGL((pg_search_kernel<NB, Id, PG_MODE_CLOSE>), grid, block, lds_pad, st,
                            *ref, *prm, *batch, max_len, levels);
     if (mode & PG_MODE_FAR) {
         if (mode & PG_MODE_CLOSE) (void)hipMemsetAsync(batch->work_ctr, 0, PG_N_XCD * 16u * sizeof(uint32_t), st);
-        hipLaunchKernelGGL((pg_search_kernel<NB, Id, PG_MODE_FAR>), grid, block, lay.total + lds_pad, st,
+        hipLaunchKernelGGL((pg_search_kernel<NB, Id, PG_MODE_FAR>), grid, block, lds_pad, st,
                            *ref, *prm, *batch, max_len, levels);
     }
+}
+
+// ---------------------------------------------------------------------------------
+// Packed per-read records <-> the SoA arrays of the C ABI (pg_device.h).
+__global__ void pg_pack_reads_kernel(PgSoaIn a, PgInRec *in, uint32_t lo, uint32_t cnt)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= cnt) return;
+    const uint32_t i = lo + k;
+    PgInRec r;
+    r.seq_off = a.seq_off[i];
+    const uint32_t len = (uint32_t)(a.seq_off[i + 1] - a.seq_off[i]);
+    r.apos = a.pos[i] + (int32_t)a.spacer;
+    r.chr = a.chr[i];
+    r.len = (uint16_t)len;
+    r.isz = a.isz[i];
+    r.thr = a.thr[len < 512u ? len : 511u];
+    r.strand = a.strand[i];
+    r.M = (uint8_t)a.mm[len < 512u ? len : 511u];
+    r.bd_cnt = 0;
+    r.bd_off = 0;
+    if (a.bd_off) {
+        r.bd_off = (uint32_t)a.bd_off[i];
+        r.bd_cnt = (uint32_t)(a.bd_off[i + 1] - a.bd_off[i]);
+    }
+    in[i] = r;
+}
+
+__global__ void pg_pack_close_kernel(PgSoaOut a, PgOutRec *out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    PgOutRec r;
+    r.close_off = r.close_cnt = r.far_off = r.far_cnt = 0;
+    r.close_last = a.close_last[i];
+    r.close_max = a.close_max[i];
+    r.rc_flag = a.rc_flag[i];
+    r.pad = 0;
+    r.alg = 0;
+    r.reserved = 0;
+    out[i] = r;
+}
+
+__global__ void pg_unpack_kernel(const PgOutRec *out, PgSoaOut a, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const PgOutRec r = out[i];
+    a.rc_flag[i] = r.rc_flag;
+    a.close_last[i] = r.close_last;
+    a.close_max[i] = r.close_max;
+    a.close_off[i] = r.close_off;
+    a.close_cnt[i] = r.close_cnt;
+    a.far_off[i] = r.far_off;
+    a.far_cnt[i] = r.far_cnt;
+    a.alg[i] = r.alg;
+}
+
+extern "C" int pg_pack_reads(const PgSoaIn *soa, PgInRec *in, uint32_t lo, uint32_t cnt, void *stream)
+{
+    if (cnt) pg_pack_reads_kernel<<<(cnt + 255u) / 256u, 256, 0, (hipStream_t)stream>>>(*soa, in, lo, cnt);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pg_pack_close_summary(const PgSoaOut *soa, PgOutRec *out, uint32_t n, void *stream)
+{
+    if (n) pg_pack_close_kernel<<<(n + 255u) / 256u, 256, 0, (hipStream_t)stream>>>(*soa, out, n);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pg_unpack_results(const PgOutRec *out, const PgSoaOut *soa, uint32_t n, void *stream)
+{
+    if (n) pg_unpack_kernel<<<(n + 255u) / 256u, 256, 0, (hipStream_t)stream>>>(out, *soa, n);
+    return (int)hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------
@@ -1174,16 +1315,16 @@ extern "C" int pg_debug_calib_stream(const void *src, size_t n_dwords, void *sin
 extern "C" int pg_debug_occupancy(uint32_t max_len, uint32_t levels, int small_ids, int *close_blocks,
                                   int *far_blocks, unsigned *lds_bytes)
 {
-    const int nb = max_len <= 128 ? 2 : (max_len <= 256 ? 4 : 8);
-    PgLdsLayout lay = pg_lds_layout(max_len, levels, nb);
-    *lds_bytes = lay.total;
+    (void)max_len;
+    (void)levels;
+    *lds_bytes = (unsigned)sizeof(Lds<2>);
     hipError_t e1, e2;
-    if (small_ids && nb == 2) {
-        e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(close_blocks, pg_search_kernel<2, u32, PG_MODE_CLOSE>, WAVE, lay.total);
-        e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(far_blocks, pg_search_kernel<2, u32, PG_MODE_BOTH>, WAVE, lay.total);
+    if (small_ids) {
+        e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(close_blocks, pg_search_kernel<2, u32, PG_MODE_CLOSE>, WAVE, 0);
+        e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(far_blocks, pg_search_kernel<2, u32, PG_MODE_BOTH>, WAVE, 0);
     } else {
-        e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(close_blocks, pg_search_kernel<2, u64, PG_MODE_CLOSE>, WAVE, lay.total);
-        e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(far_blocks, pg_search_kernel<2, u64, PG_MODE_BOTH>, WAVE, lay.total);
+        e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(close_blocks, pg_search_kernel<2, u64, PG_MODE_CLOSE>, WAVE, 0);
+        e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(far_blocks, pg_search_kernel<2, u64, PG_MODE_BOTH>, WAVE, 0);
     }
     return (int)e1 | (int)e2;
 }
