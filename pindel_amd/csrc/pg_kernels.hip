@@ -593,7 +593,12 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
         // base (a close-end window that happens to start where this chunk starts) may be shorter.
         const int se = e_max < cs + (int)PG_CHUNK ? e_max : cs + (int)PG_CHUNK;
         if (!(wo == S.win_wo && S.wbase == wb && se + 64 * NB <= S.win_hi))
+        {
             stage_window<NB>(ref, S, wo, wb, se + 64 * NB, lane);
+#if defined(PG_DUP) && PG_DUP == 2
+            stage_window<NB>(ref, S, wo, wb, se + 64 * NB, opaque(lane));
+#endif
+        }
         const int pbase = cs + 32 * lane;
         const u32 rmask = bits32(ns - pbase, ne - pbase) & ~bits32(xs - pbase, xe - pbase);
         const bool cached = use_cache && k == 0 && cache_valid;
@@ -602,6 +607,9 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
             if (cached) mF = cacheF;
             else {
                 mF = seed_filter<NB>(S, Q, false, lane);
+#if defined(PG_DUP) && PG_DUP == 3
+                mF &= seed_filter<NB>(S, Q, false, opaque(lane)) | (u32)opaque(0);
+#endif
                 if (use_cache && k == 0) cacheF = mF;
             }
             mF &= rmask;
@@ -610,6 +618,9 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
             if (cached) mB = cacheB;
             else {
                 mB = seed_filter<NB>(S, Q, true, lane);
+#if defined(PG_DUP) && PG_DUP == 3
+                mB &= seed_filter<NB>(S, Q, true, opaque(lane)) | (u32)opaque(0);
+#endif
                 if (use_cache && k == 0) cacheB = mB;
             }
             mB &= rmask;
@@ -638,6 +649,13 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
             const int n = total - base < WAVE ? total - base : WAVE;
             S.nsurv += n;
             __syncthreads();
+#if defined(PG_DUP) && PG_DUP == 4
+            {   // diagnostics: the same pass into a throw-away copy of the state
+                Acc<NB, Id> A2 = A;
+                fold_candidates<NB, Id, MIXED>(S, Q, A2, wb, origin, region, n, opaque(lane));
+                if (A2.m1 == 0x12345u) A.m1 = A2.m2;
+            }
+#endif
             fold_candidates<NB, Id, MIXED>(S, Q, A, wb, origin, region, n, lane);
         }
     }
@@ -673,31 +691,34 @@ template <int NB, typename Id>
 struct Eval {
     Id id[NB];
     u32 lo[NB];
-    u64 candm[NB], startm[NB], brkm[NB];
-    int rounds;              // rounds evaluated (the last one may have been cut by the abort rule)
-    int n_runs, max_len;
+    u64 startm[NB], brkm[NB];
+    int n_runs, max_len;     // max_len = LengthStr of the last emitted point (0 if none)
     Id id_last;              // winner of the last emitted point
-    int len_last;            // its LengthStr
 };
+
+// g_maxMismatch[L] for the lane's L (<= M for L <= len)
+__device__ __forceinline__ u32 mm_of(const Search &S, int L)
+{
+    u32 mmL = 0u;
+    for (int k = 0; k < S.M; k++) mmL += (u32)L >= S.mm_bp[k] ? 1u : 0u;
+    return mmL;
+}
 
 // The reference's rules for every L (lanes own L): "if (minimumNumberOfMismatches > g_maxMismatch[L]) return"
 // (searcher.cpp:167, pindel.cpp:2836), emission iff the lowest level holds exactly one position and the
 // levels up to +ADDITIONAL_MISMATCH hold no other (searcher.cpp:171-191, pindel.cpp:2849-2893), after
-// CheckMismatches (already folded into A.ok).  The reduction itself is not modified.
+// CheckMismatches (already folded into the state).  mm0 = g_maxMismatch[bps + lane] (round 0).  The
+// reduction itself is not modified.
 template <int NB, typename Id>
-__device__ __forceinline__ void evaluate(const Search &S, const Acc<NB, Id> &A,
-                                         Eval<NB, Id> &E, int lane)
+__device__ __forceinline__ void evaluate(const Search &S, const Acc<NB, Id> &A, u32 mm0, Eval<NB, Id> &E, int lane)
 {
     E.n_runs = 0;
     E.max_len = 0;
-    E.rounds = 0;
     E.id_last = 0;
-    E.len_last = 0;
     // tier A lives in four 16-lane quarters: bring quarters 1..3 to quarter 0 through LDS and merge
     u32 t1 = A.m1, t2 = A.m2, tok = A.ok;
     Id tid = A.id;
     if (S.tierA) {
-        __syncthreads();
         S.bufA[lane] = make_uint4(A.a1, A.a2 | (A.aok << 16), (u32)A.aid, (u32)((u64)A.aid >> 32));
         __syncthreads();
         u32 a1 = PG_BIG, a2 = PG_BIG, aok = 0u;
@@ -717,7 +738,7 @@ __device__ __forceinline__ void evaluate(const Search &S, const Acc<NB, Id> &A,
     bool aborted = false;
 #pragma unroll
     for (int r = 0; r < NB; r++) {
-        E.candm[r] = E.startm[r] = 0ull;
+        E.startm[r] = 0ull;
         E.brkm[r] = ~0ull;
         E.id[r] = 0;
         E.lo[r] = 0u;
@@ -725,94 +746,93 @@ __device__ __forceinline__ void evaluate(const Search &S, const Acc<NB, Id> &A,
         if (r0 > S.len - 1 || aborted) continue;          // uniform
         const int L = r0 + lane;
         const bool valid = L <= S.len - 1;
-        u32 m1 = t1, m2 = t2, ok = tok;
+        u32 m1 = t1, m2 = t2, ok = tok, mmL = mm0;
         Id wid = tid;
         if (r > 0) {
             m1 = m2 = PG_BIG; ok = 0u; wid = 0;
+            mmL = mm_of(S, L);
             if ((A.dirty >> r) & 1u) {                    // uniform
                 const uint4 st = S.accB[(r - 1) * 64 + lane];
                 m1 = st.x; m2 = st.y & 0xffffu; ok = st.y >> 16;
                 wid = sizeof(Id) == 8 ? (Id)((u64)st.z | ((u64)st.w << 32)) : (Id)st.z;
             }
         }
-        int mmL = 0;                                      // g_maxMismatch[L] (<= M for L <= len)
-        for (int k = 0; k < S.M; k++) mmL += (u32)L >= S.mm_bp[k] ? 1 : 0;
         const u32 lo = m1 <= (u32)S.M ? m1 : (u32)S.M + 1u;
-        const u64 ab = ballot64(valid && lo > (u32)mmL);
+        const u64 ab = ballot64(valid && lo > mmL);
         const int first_abort = ab ? __ffsll((long long)ab) - 1 : WAVE;
         const bool cand = valid && lane < first_abort && m1 <= (u32)S.M && m2 > m1 + (u32)S.add_mm &&
                           (u32)L >= (u32)S.bps + m1 && ok != 0u;
-        // run-length encode consecutive points of the same candidate / level
-        const u64 key = cand ? (((u64)wid << 8) | (u64)(lo + 1u)) : 0ull;
-        const u64 prev_key = wave_shr1(key);   // lane 0 gets 0: runs never span two 64-length rounds
-        const bool start = cand && key != prev_key;
+        // run-length encode consecutive points of the same candidate / level (a run never spans two rounds)
+        const u32 lok = cand ? lo + 1u : 0u;               // 0 = no point here
+        const u32 plok = wave_shr1(lok);                   // lane 0 gets 0
+        bool same = wave_shr1((u32)wid) == (u32)wid;
+        if (sizeof(Id) == 8) same = same && wave_shr1((u32)((u64)wid >> 32)) == (u32)((u64)wid >> 32);
+        const bool start = cand && !(plok == lok && same);
+        const u64 cm = ballot64(cand);
         E.id[r] = wid;
         E.lo[r] = lo;
-        E.candm[r] = ballot64(cand);
         E.startm[r] = ballot64(start);
-        E.brkm[r] = ballot64(start || !cand);
-        E.rounds = r + 1;
+        E.brkm[r] = E.startm[r] | ~cm;
         E.n_runs += __popcll(E.startm[r]);
-        if (E.candm[r]) {
-            const int top = 63 - __clzll((long long)E.candm[r]);
+        if (cm) {
+            const int top = 63 - __clzll((long long)cm);
             E.max_len = r0 + top;
-            E.len_last = r0 + top;
             E.id_last = read_lane(wid, top);
         }
         if (ab) aborted = true;
     }
 }
 
-// Number of runs emit_runs will write: all of them (far end), or those of the candidate of the last point
-// (close end: CleanUniquePoints, pindel.cpp:2904-2941, keeps the points whose implied read terminal equals
-// the last point's = the runs of the last run's candidate).
+// Writes the runs of the evaluation to out[0..): all of them (far end), or those of the candidate of the
+// last point (close end: CleanUniquePoints, pindel.cpp:2904-2941, keeps the points whose implied read
+// terminal equals the last point's = the runs of the last run's candidate).  kept = masks of the run starts
+// that are written.
 template <int NB, typename Id>
-__device__ __forceinline__ int count_kept(const Eval<NB, Id> &E, bool only_last)
+__device__ __forceinline__ int count_kept(const Eval<NB, Id> &E, bool only_last, u64 *kept)
 {
-    if (!only_last) return E.n_runs;
     int n = 0;
 #pragma unroll
-    for (int r = 0; r < NB; r++)
-        if (r < E.rounds) n += __popcll(E.startm[r] & ballot64(E.id[r] == E.id_last));
+    for (int r = 0; r < NB; r++) {
+        kept[r] = E.startm[r];
+        if (only_last && E.startm[r]) kept[r] &= ballot64(E.id[r] == E.id_last);
+        n += __popcll(kept[r]);
+    }
     return n;
 }
 
 template <int NB, typename Id>
-__device__ __forceinline__ void emit_runs(const Search &S, const Query<NB> &Q, const RegionInfo &R,
-                                          const Eval<NB, Id> &E, bool only_last, pg_run *out, int lane)
+__device__ __forceinline__ void emit_runs(const Search &S, bool antiF, bool antiB, int chr0, int origin0,
+                                          const pg_window *bd, const Eval<NB, Id> &E, const u64 *kept,
+                                          pg_run *out, int lane)
 {
     typedef IdFmt<Id> F;
     int written = 0;
 #pragma unroll
     for (int r = 0; r < NB; r++) {
-        if (r >= E.rounds || E.startm[r] == 0ull) continue;          // uniform
-        const bool keep = !only_last || E.id[r] == E.id_last;
-        const u64 km = E.startm[r] & ballot64(keep);
-        if (((E.startm[r] >> lane) & 1ull) && keep) {
+        if (kept[r] == 0ull) continue;                    // uniform
+        if ((kept[r] >> lane) & 1ull) {
             const int L = S.bps + 64 * r + lane;
             const u64 higher = lane == 63 ? 0ull : (E.brkm[r] & ~low_bits(lane + 1));
             const int end_lane = higher ? __ffsll((long long)higher) - 2 : WAVE - 1;
             const u64 id = (u64)E.id[r];
             const u32 rel = (u32)(id & ((1ull << F::RB) - 1ull));
             const bool isB = (id >> F::RB) & 1ull;
-            int chr = R.chr, origin = R.origin;
-            if (R.bd) {
-                const pg_window w = R.bd[(u32)(id >> (F::RB + 1))];
+            int chr = chr0, origin = origin0;
+            if (bd) {
+                const pg_window w = bd[(u32)(id >> (F::RB + 1))];
                 chr = w.chr_id;
                 origin = w.start < 0 ? w.end - 1 : w.start;
             }
             const int p = origin + (int)rel;
-            pg_run run;
-            run.abs_loc_first = isB ? (u32)(p - L + 1) : (u32)(p + L - 1);
-            run.len_first = (uint16_t)L;
-            run.len_last = (uint16_t)(S.bps + 64 * r + end_lane);
-            run.mismatches = (uint8_t)E.lo[r];
-            const bool anti = isB ? Q.antisenseB : Q.antisenseF;
-            run.flags = (uint8_t)((isB ? PG_RUN_BACKWARD : 0u) | (anti ? PG_RUN_ANTISENSE : 0u));
-            run.chr_id = (int16_t)chr;
-            out[written + __popcll(km & low_bits(lane))] = run;
+            const bool anti = isB ? antiB : antiF;
+            // pg_run as three dwords: abs_loc_first | len_first, len_last | mismatches, flags, chr_id
+            u32 *dst = (u32 *)(out + written + __popcll(kept[r] & low_bits(lane)));
+            dst[0] = isB ? (u32)(p - L + 1) : (u32)(p + L - 1);
+            dst[1] = (u32)L | ((u32)(S.bps + 64 * r + end_lane) << 16);
+            dst[2] = E.lo[r] | ((isB ? PG_RUN_BACKWARD : 0u) << 8) | ((anti ? PG_RUN_ANTISENSE : 0u) << 8) |
+                     ((u32)(chr & 0xffff) << 16);
         }
-        written += __popcll(km);
+        written += __popcll(kept[r]);
     }
 }
 
@@ -863,237 +883,207 @@ __device__ __forceinline__ bool first_base_ok(const Query<NB> &Q)
     return (x & 1u) == 0u;
 }
 
-// One read.  The read goes through a sequence of search STEPS that share one scan site and one
-// evaluate site:
-//   steps 0..3  close-end attempts (R0,seq) (R0,RC) (R1,RC) (R1,seq)   pindel.cpp:2537-2575
-//   step  4     far end, BreakDancer cluster                            pindel.cpp:1006-1018
-//   steps 5..   far end, ranges r = 1 .. MaxRangeIndex+1                pindel.cpp:1025-1070
+// One read: close end, then far end.
+//   close end   attempts (R0,seq) (R0,RC) (R1,RC) (R1,seq) until one yields points    pindel.cpp:2537-2575
+//   far end     BreakDancer cluster (if the read has one), then the ranges
+//               r = 1 .. MaxRangeIndex+1 until goodFarEndFound                          pindel.cpp:1006-1070
 template <int NB, typename Id, int mode>
 __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevParams &prm, const PgDevBatch &B,
                                             Search &S, u64 *qplanes, const uint32_t rid, const int lane)
 {
     S.win_wo = -1;
-    S.win_lo = S.win_hi = S.wbase = 0;
-    S.nsurv = 0;
-
-    // the read's packed record: one scalar load (rid is wave-uniform)
+    S.win_hi = S.wbase = 0;
+    // the read's packed record (rid is wave-uniform)
     const uint4 *rp = (const uint4 *)(B.in + rid);
     const uint4 r0 = rp[0], r1 = rp[1];
-    const u64 off = (u64)r0.x | ((u64)r0.y << 32);
-    const int len = (int)(r1.x & 0xffffu);
-    const uint8_t *seq = B.seq + off;
-    const int chr = (int)r0.w;
+    const int len = uni((int)(r1.x & 0xffffu));
+    const int chr = uni((int)r0.w);
     const long long chr_wo = (long long)ref.chr_word_off[chr];
-    const int chr_size = (int)ref.chr_size[chr];
     S.len = len;
-    S.M = (int)(r1.y >> 24);
+    S.M = uni((int)(r1.y >> 24));
     S.T = S.M + prm.add_mm + 1;
-    S.thr = (int)(r1.y & 0xffffu);
-
-    load_planes<NB>(seq, len, lane, qplanes);
-
-    int alg8 = (mode & PG_MODE_CLOSE) ? 8 * len : 0;         // algorithmic bytes x 8; the read itself is counted once
-    int flipped = 0, close_max = 0, n_close = 0, n_far = 0, far_max = 0;
-    u32 close_last = 0, close_base = 0, far_base = 0;
+    S.thr = uni((int)(r1.y & 0xffffu));
+    load_planes<NB>(B.seq + ((u64)r0.x | ((u64)r0.y << 32)), len, lane, qplanes);
+#if defined(PG_DUP) && PG_DUP == 1
+    load_planes<NB>(B.seq + ((u64)r0.x | ((u64)r0.y << 32)), len, opaque(lane), qplanes);
+#endif
 
     const bool do_close = (mode & PG_MODE_CLOSE) != 0, do_far = (mode & PG_MODE_FAR) != 0;
-    const char strand = (char)((r1.y >> 16) & 0xffu);
-    const int apos = (int)r0.z;
-    const int isz = (int)(short)(r1.x >> 16);
-    u32 alg_prev = 0u;
-    if (!do_close) {
+    int flipped = 0, close_max = 0, n_close = 0;
+    u32 close_last = 0, close_base = 0, alg = 0u;
+    u32 unused0 = 0u, unused1 = 0u;
+    bool unused_valid = false;
+    Acc<NB, Id> A;
+    bool fits = true;
+
+    // ------------------------------------------------------------------------------- close end
+    if (do_close) {
+        const int strand = uni((int)((r1.y >> 16) & 0xffu));
+        const int apos = uni((int)r0.z);
+        const int isz = uni((int)(short)(r1.x >> 16));
+        int close_bases = 0;
+        if (len - 1 >= prm.min_close && (strand == '+' || strand == '-')) {
+            S.bps = prm.min_close;
+            S.tierA = S.bps + 16 <= 32;
+            S.len_check = prm.min_perfect >= S.bps;
+            const u32 mm0 = mm_of(S, S.bps + lane);
+            for (int att = 0; att < 4; att++) {
+                const int Rg = att >> 1;
+                flipped = (att == 1 || att == 2) ? 1 : 0;
+                // '+' anchor: CurrentReadSeq = RC(cur), grown left to right (pindel.cpp:2271-2291)
+                // '-' anchor: CurrentReadSeq = cur, grown right to left     (pindel.cpp:2298-2319)
+                Query<NB> Q;
+                Q.qp = qplanes + (!flipped ? 4 * NB : 0);
+                int s1, e1;
+                if (strand == '+') {
+                    Q.cF = !flipped; Q.cB = false; Q.allowF = true; Q.allowB = false;
+                    s1 = apos - Rg * isz;
+                    e1 = s1 + (2 * Rg + 1) * isz;
+                } else {
+                    Q.cB = flipped; Q.cF = false; Q.allowF = false; Q.allowB = true;
+                    e1 = apos + Rg * isz;
+                    s1 = e1 - (2 * Rg + 1) * isz;
+                }
+                Q.antisenseF = true;      // CheckLeft_Close: FORWARD, ANTISENSE
+                Q.antisenseB = false;     // CheckRight_Close: BACKWARD, SENSE
+                Q.first_ok = first_base_ok<NB>(Q);
+                close_bases = e1 > s1 ? e1 - s1 : 0;
+                A.reset();
+                S.nsurv = 0;
+                scan_range<NB, Id>(ref, S, Q, A, chr_wo, s1, s1, e1, e1, 0, 0, s1, 0u, opaque(lane), false,
+                                   unused0, unused1, unused_valid);
+                if (S.nsurv > 0) {
+                    Eval<NB, Id> E;
+                    evaluate<NB, Id>(S, A, mm0, E, opaque(lane));
+                    close_max = uni(E.max_len);
+                    if (uni(E.n_runs) > 0) {
+                        u64 kept[NB];
+                        n_close = uni(count_kept<NB, Id>(E, true, kept));
+                        close_base = pool_alloc(B, n_close, lane, fits);
+                        if (fits) emit_runs<NB, Id>(S, true, false, chr, s1, nullptr, E, kept, B.pool + close_base, opaque(lane));
+                        // AbsLoc of the last point (getLastAbsLocCloseEnd)
+                        const u64 idl = (u64)E.id_last;
+                        const int pl = s1 + (int)(u32)(idl & ((1ull << IdFmt<Id>::RB) - 1ull));
+                        close_last = ((idl >> IdFmt<Id>::RB) & 1ull) ? (u32)(pl - close_max + 1) : (u32)(pl + close_max - 1);
+                        break;
+                    }
+                }
+            }
+        }
+        if (n_close == 0) { flipped = 0; close_max = 0; }       // back to the original orientation
+        alg = (u32)(8 * len + 3 * (close_bases + 2 * len) + 96 * n_close);   // x 8: the read once, 3 bits per base, 12 bytes per run
+    } else {
         // far-end launch: the close-end summary of the earlier launch
-        const uint4 *op = (const uint4 *)(B.out + rid);
-        const uint4 o1 = op[1];
+        const uint4 o1 = ((const uint4 *)(B.out + rid))[1];
         close_last = (u32)uni((int)o1.x);
         close_max = uni((int)(o1.y & 0xffffu));
         flipped = uni((int)((o1.y >> 16) & 0xffu));
-        alg_prev = (u32)uni((int)o1.z);
+        alg = (u32)uni((int)o1.z) << 3;
     }
-    int nbd = 0;
-    const pg_window *bd = nullptr;
-    if (do_far && B.bd) {
-        nbd = (int)r1.z;
-        bd = B.bd + r1.w;
-    }
-    int maxspan = 64;
-    for (int i = 0; i < prm.max_range_index; i++) maxspan *= 4;
-    const int last_step = 5 + prm.max_range_index;
 
-    // far-range bookkeeping (nested windows)
-    int ps = 0, pe = 0, span = 64, reach = 0;
-    int close_bases = 0, far_bases = 0;
-    u32 cacheF = 0u, cacheB = 0u;                    // seed-filter masks of the innermost far-end chunk
-    bool cache_valid = false;
-    Acc<NB, Id> A;
-    A.reset();
-
-    int step = do_close ? 0 : 4;
-    if (do_close && !(len - 1 >= prm.min_close && (strand == '+' || strand == '-')))
-        step = 4;                                    // no close end possible
-    bool far_ready = false;                          // far-end query configured
-    int nsurv_eval = -1;                             // S.nsurv when the state was last evaluated
-    while (step <= last_step) {
-        const bool is_close = step < 4;
-        if (!is_close && !do_far) break;
-        if (!is_close && !far_ready) {
-            // entering the far end: "if (CurrentBase == 'N' || MaxLenCloseEnd() == 0) return;"
-            if (!(close_max > 0 && len - 1 >= 10)) break;
-            far_ready = true;
-        }
-        // ---------------- configure the step
+    // ------------------------------------------------------------------------------- far end
+    int n_far = 0, far_max = 0;
+    u32 far_base = 0;
+    // "if (CurrentBase == 'N' || MaxLenCloseEnd() == 0) return;" (farend_searcher.cpp:60-66)
+    if (do_far && close_max > 0 && len - 1 >= 10) {
+        S.bps = 10;               // farend_searcher.cpp:90
+        S.tierA = true;
+        S.len_check = prm.min_perfect >= 10;
+        // cur = flipped ? RC(orig) : orig.  Plus strand consumes cur left to right, Minus strand
+        // consumes complement(cur) walking the reference right to left.
         Query<NB> Q;
-        int nwin = 0;                 // windows to scan this step (<= 1, or nbd)
-        int s1 = 0, e1 = 0;           // positions [s1, e1) minus [xs, xe) are new in this step
-        int xs = 0, xe = 0, g0 = 0, emax = 0;
-        int origin = 0;
-        bool zero = false;
-        if (is_close) {
-            const int Rg = step >> 1;
-            flipped = (step == 1 || step == 2) ? 1 : 0;
-            S.bps = prm.min_close;
-            // '+' anchor: CurrentReadSeq = RC(cur), grown left to right (pindel.cpp:2271-2291)
-            // '-' anchor: CurrentReadSeq = cur, grown right to left     (pindel.cpp:2298-2319)
-            Q.qp = qplanes + (!flipped ? 4 * NB : 0);
-            if (strand == '+') {
-                Q.cF = !flipped; Q.cB = false; Q.allowF = true; Q.allowB = false;
-                s1 = apos - Rg * isz;
-                e1 = s1 + (2 * Rg + 1) * isz;
-            } else {
-                Q.cB = flipped; Q.cF = false; Q.allowF = false; Q.allowB = true;
-                e1 = apos + Rg * isz;
-                s1 = e1 - (2 * Rg + 1) * isz;
+        Q.qp = qplanes + (flipped ? 4 * NB : 0);
+        Q.cF = flipped; Q.cB = !flipped;
+        Q.allowF = Q.allowB = true;
+        Q.antisenseF = false;     // FORWARD, SENSE
+        Q.antisenseB = true;      // BACKWARD, ANTISENSE
+        Q.first_ok = first_base_ok<NB>(Q);
+        if (Q.first_ok) {
+            const u32 mm0 = mm_of(S, 10 + lane);
+            const int chr_size = (int)ref.chr_size[chr];
+            int far_bases = 0;
+            // a search window's result replaces UP_Far if its MaxLen is >= (NewUPFarIsBetter, farend_searcher.cpp:30-44)
+            auto far_update = [&](int origin, const pg_window *bdw) {
+                Eval<NB, Id> E;
+                evaluate<NB, Id>(S, A, mm0, E, opaque(lane));
+                const int mx = uni(E.max_len);
+                if (mx >= far_max) {
+                    far_max = mx;
+                    n_far = uni(E.n_runs);
+                    far_base = 0;
+                    if (n_far > 0) {
+                        u64 kept[NB];
+                        (void)count_kept<NB, Id>(E, false, kept);
+                        far_base = pool_alloc(B, n_far, lane, fits);
+                        if (fits) emit_runs<NB, Id>(S, false, true, chr, origin, bdw, E, kept, B.pool + far_base, opaque(lane));
+                    }
+                }
+            };
+            bool done = false;
+            // BreakDancer / read-pair cluster of this read first (pindel.cpp:1006-1018)
+            if (B.bd && r1.z != 0u) {
+                const int nbd = uni((int)r1.z);
+                const pg_window *bd = B.bd + uni((int)r1.w);
+                A.reset();
+                S.nsurv = 0;
+                for (int w = 0; w < nbd; w++) {
+                    const pg_window bw = bd[w];
+                    const int st = bw.start < 0 ? bw.end - 1 : bw.start;
+                    const int csz = (int)ref.chr_size[bw.chr_id];
+                    const int s = st < 0 ? 0 : st, e = bw.end > csz ? csz : bw.end;
+                    far_bases += (e > s ? e - s : 0) + 2 * len;
+                    scan_range<NB, Id>(ref, S, Q, A, (long long)ref.chr_word_off[bw.chr_id], s, s, e, e, 0, 0, st,
+                                       (u32)w, opaque(lane), false, unused0, unused1, unused_valid);
+                }
+                if (S.nsurv > 0) far_update(0, bd);
+                done = far_max + close_max >= len;           // goodFarEndFound (pindel.cpp:480-483)
             }
-            Q.antisenseF = true;      // CheckLeft_Close: FORWARD, ANTISENSE
-            Q.antisenseB = false;     // CheckRight_Close: BACKWARD, SENSE
-            origin = s1;
-            g0 = s1;
-            emax = e1;
-            nwin = 1;
-            zero = true;
-            close_bases = e1 > s1 ? e1 - s1 : 0;
-        } else {
-            S.bps = 10;               // farend_searcher.cpp:90
-            // cur = flipped ? RC(orig) : orig.  Plus strand consumes cur left to right, Minus strand
-            // consumes complement(cur) walking the reference right to left.
-            Q.qp = qplanes + (flipped ? 4 * NB : 0);
-            Q.cF = flipped; Q.cB = !flipped;
-            Q.allowF = Q.allowB = true;
-            Q.antisenseF = false;     // FORWARD, SENSE
-            Q.antisenseB = true;      // BACKWARD, ANTISENSE
-            if (step == 4) {
-                if (nbd == 0) { step++; continue; }
-                nwin = nbd;
-                zero = true;
-            } else {
+            if (!done) {
+                // ranges 128 * 4^r around the last close-end point, clipped to the non-spacer part
+                // (pindel.cpp:1025-1070).  The reduction is additive, so only the flanks the previous ranges
+                // did not cover are scanned.  Chunk grid: the innermost 2048 positions are one chunk (one LDS
+                // fill and one seed-filter pass serve the ranges up to 1024).
                 const int center = (int)close_last;
-                origin = center - maxspan;
-                if (step == 5) { zero = true; ps = pe = 0; span = 64; cache_valid = false; }
-                // window of this range, clipped to the non-spacer part (pindel.cpp:1034-1043); the
-                // reduction is additive, so only the flanks the previous ranges did not cover are
-                // scanned.  Chunk grid: the innermost 2048 positions are one chunk (one LDS fill and
-                // one seed-filter pass serve the ranges up to 1024).
-                int s, e;
-                if ((u32)center > (u32)span + prm.spacer) s = center - span; else s = (int)prm.spacer;
-                if ((u32)center + (u32)span + prm.spacer < (u32)chr_size) e = center + span;
-                else e = chr_size - (int)prm.spacer;
-                g0 = center - (int)PG_CHUNK / 2;
+                const int maxspan = 64 << (2 * prm.max_range_index);
+                const int origin = center - maxspan;
+                const int g0 = center - (int)PG_CHUNK / 2;
+                int emax;
                 if ((u32)center + (u32)maxspan + prm.spacer < (u32)chr_size) emax = center + maxspan;
                 else emax = chr_size - (int)prm.spacer;
-                if (s < e) {
-                    s1 = s; e1 = e; nwin = 1;
-                    xs = ps; xe = pe;
-                    if (ps < pe) {
-                        ps = s < ps ? s : ps;
-                        pe = e > pe ? e : pe;
-                    } else {
-                        ps = s; pe = e;
+                u32 cacheF = 0u, cacheB = 0u;                    // seed-filter masks of the innermost chunk
+                bool cache_valid = false;
+                int ps = 0, pe = 0, span = 64, nsurv_eval = 0;
+                A.reset();
+                S.nsurv = 0;
+                for (int r = 0; r <= prm.max_range_index; r++, span *= 4) {
+                    int s, e;
+                    if ((u32)center > (u32)span + prm.spacer) s = center - span; else s = (int)prm.spacer;
+                    if ((u32)center + (u32)span + prm.spacer < (u32)chr_size) e = center + span;
+                    else e = chr_size - (int)prm.spacer;
+                    if (s < e) {
+                        scan_range<NB, Id>(ref, S, Q, A, chr_wo, g0, s, e, emax, ps, pe, origin, 0u, opaque(lane), true,
+                                           cacheF, cacheB, cache_valid);
+                        if (ps < pe) {
+                            ps = s < ps ? s : ps;
+                            pe = e > pe ? e : pe;
+                        } else {
+                            ps = s; pe = e;
+                        }
                     }
-                    reach = pe - ps;
+                    // an evaluation can only differ from the previous one if candidates were folded since; an
+                    // empty state yields no point ("NumberOfHits == 0" leaves UP_Far untouched, farend_searcher.cpp:87)
+                    if (S.nsurv != nsurv_eval) {
+                        nsurv_eval = S.nsurv;
+                        far_update(origin, nullptr);
+                    }
+                    if (far_max + close_max >= len) break;       // goodFarEndFound
                 }
-                span *= 4;
+                far_bases += (pe - ps) + 2 * len;
             }
-        }
-        S.tierA = S.bps + 16 <= 32;
-        S.len_check = prm.min_perfect >= S.bps;
-        Q.first_ok = first_base_ok<NB>(Q);
-        if (!is_close && !Q.first_ok) break;         // far end: first base N (or not ACGT): nothing to find
-        if (zero) { A.reset(); S.nsurv = 0; nsurv_eval = -1; }
-        // ---------------- scan
-        for (int w = 0; w < nwin; w++) {
-            long long wo = chr_wo;
-            int s = s1, e = e1, org = origin;
-            u32 region = 0;
-            if (step == 4) {
-                const pg_window bw = bd[w];
-                const int st = bw.start < 0 ? bw.end - 1 : bw.start;
-                const int csz = (int)ref.chr_size[bw.chr_id];
-                wo = (long long)ref.chr_word_off[bw.chr_id];
-                s = st < 0 ? 0 : st;
-                e = bw.end > csz ? csz : bw.end;
-                org = st;
-                region = (u32)w;
-                g0 = s;
-                emax = e;
-                far_bases += (e > s ? e - s : 0) + 2 * len;
-            }
-            scan_range<NB, Id>(ref, S, Q, A, wo, g0, s, e, emax, xs, xe, org, region, opaque(lane),
-                               step >= 5, cacheF, cacheB, cache_valid);
-        }
-        // ---------------- evaluate (NumberOfHits == 0 leaves UP_Far untouched, farend_searcher.cpp:87)
-        // An evaluation can only differ from the previous one of the same state if candidates were
-        // folded since; an empty state yields no point (and "replaces" an empty UP_Far by itself).
-        const bool fresh = S.nsurv != nsurv_eval && S.nsurv > 0;
-        if (!fresh && is_close) close_max = 0;
-        nsurv_eval = S.nsurv;
-        if (fresh) {
-            const RegionInfo R = { chr, origin, step == 4 ? bd : nullptr };
-            Eval<NB, Id> E;
-            evaluate<NB, Id>(S, A, E, opaque(lane));
-            const int n = uni(E.n_runs), mx = uni(E.max_len);
-            bool fits = true;
-            if (is_close) {
-                close_max = mx;
-                if (n > 0) {
-                    const int kept = uni(count_kept<NB, Id>(E, true));
-                    const u32 base = pool_alloc(B, kept, lane, fits);
-                    if (fits) emit_runs<NB, Id>(S, Q, R, E, true, B.pool + base, opaque(lane));
-                    n_close = kept;
-                    close_base = base;
-                    // AbsLoc of the last point (getLastAbsLocCloseEnd)
-                    const u64 idl = (u64)E.id_last;
-                    const int pl = origin + (int)(u32)(idl & ((1ull << IdFmt<Id>::RB) - 1ull));
-                    const bool lb = (idl >> IdFmt<Id>::RB) & 1ull;
-                    close_last = lb ? (u32)(pl - E.len_last + 1) : (u32)(pl + E.len_last - 1);
-                }
-            } else if (mx >= far_max) {                   // NewUPFarIsBetter: ">=" (farend_searcher.cpp:30-44)
-                far_max = mx;
-                n_far = n;
-                far_base = 0;
-                if (n > 0) {
-                    const u32 base = pool_alloc(B, n, lane, fits);
-                    if (fits) emit_runs<NB, Id>(S, Q, R, E, false, B.pool + base, opaque(lane));
-                    far_base = base;
-                }
-            }
-        }
-        // ---------------- next step
-        if (is_close) {
-            if (n_close > 0 || step == 3) step = 4;          // found, or all four attempts failed
-            else step++;
-        } else {
-            if (far_max + close_max >= len) break;           // goodFarEndFound (pindel.cpp:480-483)
-            step++;
+            alg += (u32)(3 * far_bases + 96 * n_far);
         }
     }
-    if (do_close && n_close == 0) { flipped = 0; close_max = 0; }   // back to the original orientation
-
-    if (do_close) alg8 += 3 * (close_bases + 2 * len) + 96 * n_close;   // 3 bits per base, 12 bytes per run
-    if (do_far) {
-        if (far_ready) far_bases += reach + 2 * len;
-        alg8 += 3 * far_bases + 96 * n_far;
-    }
-    const u32 alg = alg_prev + ((u32)(alg8 + 4) >> 3);
+    alg = (alg + 4u) >> 3;
     if (lane == 0) {
         uint4 *op = (uint4 *)(B.out + rid);
         if (do_close) {
