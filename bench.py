@@ -266,6 +266,7 @@ def main():
     # ---- outside the timed region: accounting, result digests, the host-buffer seam, the CPU baseline
     alg_bytes = eng.algorithmic_bytes(dbatch)     # per launch
     n_runs = eng.last_stats()[1]
+    n_cand = eng.candidates(dbatch)
     res = eng.download(dbatch)
     n_close = int((res.close_off[1:] > res.close_off[:-1]).sum())
     n_far = int((res.far_off[1:] > res.far_off[:-1]).sum())
@@ -310,6 +311,7 @@ def main():
                 "reads_per_gpu": batch.n, "reads_total": units, "read_len": args.read_len, "insert_size": 500,
                 "parallelism": f"reads sharded over {world} GPU(s) ({args.scaling} scaling), reference replicated, no collective",
                 "reads_with_close_end": n_close, "reads_with_far_end": n_far, "runs_out": int(n_runs),
+                "candidates_per_read": n_cand / max(batch.n, 1),    # seed-filter survivors that went through the full comparison
                 "result_sha256": shard.digest_hex(digests),
                 "host_path_reads_per_s": host_path,
             },

@@ -194,6 +194,9 @@ int  pg_last_search_stats(const pg_ctx *ctx, double *kernel_ms, uint64_t *n_runs
  * read by the kernel; DESIGN.md "roofline accounting").  Copies n x 4 bytes back: call it
  * outside any timed region. */
 int  pg_device_batch_algorithmic_bytes(pg_ctx *ctx, pg_device_batch *b, double *bytes);
+/* Diagnostics: candidate positions (survivors of the kernel's seed filter) that went through the full
+ * comparison in the last search of this batch -- what a repeat-rich reference drives up. */
+int  pg_device_batch_candidates(pg_ctx *ctx, pg_device_batch *b, double *n_candidates);
 
 #ifdef __cplusplus
 }

@@ -66,7 +66,8 @@ EXPORTS = [
     "pg_reference_comp_size", "pg_reference_fetch", "pg_close_end_batch", "pg_far_end_batch",
     "pg_search_batch", "pg_result_view_get", "pg_result_free", "pg_expand_runs",
     "pg_device_batch_upload", "pg_device_batch_set_windows", "pg_device_batch_search", "pg_device_batch_download",
-    "pg_device_batch_free", "pg_last_search_stats", "pg_device_batch_algorithmic_bytes"]
+    "pg_device_batch_free", "pg_last_search_stats", "pg_device_batch_algorithmic_bytes",
+    "pg_device_batch_candidates"]
 
 
 def build(force: bool = False) -> str:
@@ -137,6 +138,7 @@ def lib():
     L.pg_device_batch_free.restype = None
     L.pg_last_search_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64)]
     L.pg_device_batch_algorithmic_bytes.argtypes = [vp, vp, C.POINTER(C.c_double)]
+    L.pg_device_batch_candidates.argtypes = [vp, vp, C.POINTER(C.c_double)]
     _lib = L
     return L
 
@@ -340,6 +342,12 @@ class Engine:
         runs = C.c_uint64()
         self._check(self._L.pg_last_search_stats(self._h, C.byref(ms), C.byref(runs)))
         return ms.value, runs.value
+
+    def candidates(self, dbatch):
+        """Diagnostics: seed-filter survivors folded by the last search of the batch."""
+        n = C.c_double()
+        self._check(self._L.pg_device_batch_candidates(self._h, dbatch, C.byref(n)))
+        return n.value
 
     def algorithmic_bytes(self, dbatch):
         b = C.c_double()

@@ -358,6 +358,7 @@ PgSoaOut soa_out(const pg_device_batch *b)
     a.far_off = b->far_off;
     a.far_cnt = b->far_cnt;
     a.alg = b->alg;
+    a.cand = nullptr;
     return a;
 }
 
@@ -938,6 +939,19 @@ int pg_last_search_stats(const pg_ctx *ctx, double *kernel_ms, uint64_t *n_runs)
     if (!ctx) return PG_E_INVALID;
     if (kernel_ms) *kernel_ms = ctx->last_ms;
     if (n_runs) *n_runs = ctx->last_runs;
+    return PG_OK;
+}
+
+// Diagnostics: candidates (survivors of the seed filter) the last search of this batch folded, in total.
+int pg_device_batch_candidates(pg_ctx *ctx, pg_device_batch *b, double *n_candidates)
+{
+    if (!ctx || !b || !n_candidates) return PG_E_INVALID;
+    std::vector<PgOutRec> recs(b->n);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (b->n) HIP_TRY(ctx, hipMemcpy(recs.data(), b->out_rec, (size_t)b->n * sizeof(PgOutRec), hipMemcpyDeviceToHost));
+    double s = 0.0;
+    for (const PgOutRec &r : recs) s += r.reserved;
+    *n_candidates = s;
     return PG_OK;
 }
 

@@ -56,7 +56,7 @@ struct PgOutRec {
     uint8_t  rc_flag;       // GetCloseEnd left the read reverse-complemented
     uint8_t  pad;
     uint32_t alg;           // algorithmic bytes of this read
-    uint32_t reserved;
+    uint32_t reserved;      // diagnostics: candidates (survivors of the seed filter) folded for this read
 };
 
 struct PgDevBatch {
@@ -92,6 +92,7 @@ struct PgSoaOut {
     uint32_t *close_last;
     uint16_t *close_max;
     uint32_t *close_off, *close_cnt, *far_off, *far_cnt, *alg;
+    uint32_t *cand;                // nullable
 };
 
 // Candidate id = position relative to the search origin | kind (F/B) | window index of a BreakDancer cluster.

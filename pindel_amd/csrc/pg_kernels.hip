@@ -173,13 +173,13 @@ struct Lds {
     uint4 bufB[64 * (1 + NB)];                // tier B entries {id lo, meta, -, -} + NB x {mis lo, mis hi, sne lo, sne hi}
     uint4 accB[NB > 1 ? 64 * (NB - 1) : 1];   // reduction state of the rounds >= 1 {m1, m2 | ok << 16, id lo, id hi}
     u64 qp[2 * 4 * NB];                       // the read's bit planes, two orientations
-    u32 queue[64];                            // survivors of the prefilter for one candidate pass
+    uint16_t queue[64];                       // survivors of the prefilter for one candidate pass: (window position << 1) | kind
     u32 mm_bp[PG_MM_BREAKS];                  // breakpoints of g_maxMismatch (copied from the kernel arguments)
 };
 
 struct Search {
     int len, T, M, add_mm, bps, min_perfect, thr;
-    u32 *queue;
+    uint16_t *queue;
     uint4 *win;
     uint4 *bufA;
     uint4 *bufB;
@@ -190,6 +190,7 @@ struct Search {
     long long win_wo;
     int win_lo, win_hi, wbase;
     int nsurv;           // candidates folded since the state was reset
+    int nsurv_total;     // ... since the read started (diagnostics: survivors of the seed filter)
     bool tierA;          // bps + 16 <= 32: the short-lived tier is usable
     bool len_check;      // Min_Perfect_Match_Around_BP >= bps: the "L > m" test of CheckMismatches can fail
 };
@@ -637,17 +638,18 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
             while (mF != 0u && slot < top) {
                 const int bit = __ffs((int)mF) - 1;
                 mF &= mF - 1u;
-                S.queue[slot - base] = (u32)(64 * NB + 32 * lane + bit) << 1;
+                S.queue[slot - base] = (uint16_t)((u32)(64 * NB + 32 * lane + bit) << 1);
                 slot++;
             }
             while (mF == 0u && mB != 0u && slot < top) {
                 const int bit = __ffs((int)mB) - 1;
                 mB &= mB - 1u;
-                S.queue[slot - base] = ((u32)(64 * NB + 32 * lane + bit) << 1) | 1u;
+                S.queue[slot - base] = (uint16_t)(((u32)(64 * NB + 32 * lane + bit) << 1) | 1u);
                 slot++;
             }
             const int n = total - base < WAVE ? total - base : WAVE;
             S.nsurv += n;
+            S.nsurv_total += n;
             __syncthreads();
 #if defined(PG_DUP) && PG_DUP == 4
             {   // diagnostics: the same pass into a throw-away copy of the state
@@ -893,6 +895,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
 {
     S.win_wo = -1;
     S.win_hi = S.wbase = 0;
+    S.nsurv_total = 0;
     // the read's packed record (rid is wave-uniform)
     const uint4 *rp = (const uint4 *)(B.in + rid);
     const uint4 r0 = rp[0], r1 = rp[1];
@@ -908,6 +911,9 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     load_planes<NB>(B.seq + ((u64)r0.x | ((u64)r0.y << 32)), len, opaque(lane), qplanes);
 #endif
 
+#if defined(PG_STOP) && PG_STOP == 1
+    return;                                           // diagnostics: instruction count up to here
+#endif
     const bool do_close = (mode & PG_MODE_CLOSE) != 0, do_far = (mode & PG_MODE_FAR) != 0;
     int flipped = 0, close_max = 0, n_close = 0;
     u32 close_last = 0, close_base = 0, alg = 0u;
@@ -952,6 +958,9 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                 S.nsurv = 0;
                 scan_range<NB, Id>(ref, S, Q, A, chr_wo, s1, s1, e1, e1, 0, 0, s1, 0u, opaque(lane), false,
                                    unused0, unused1, unused_valid);
+#if defined(PG_STOP) && PG_STOP == 2
+                if (A.m1 != 0x54321u) return;         // diagnostics: first attempt up to the end of its scan
+#endif
                 if (S.nsurv > 0) {
                     Eval<NB, Id> E;
                     evaluate<NB, Id>(S, A, mm0, E, opaque(lane));
@@ -968,6 +977,10 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                         break;
                     }
                 }
+#if defined(PG_STOP) && PG_STOP == 6
+                if (lane == 0) B.out[rid].alg = (u32)(n_close + close_max + close_last);   // diagnostics: first attempt incl. evaluation
+                return;
+#endif
             }
         }
         if (n_close == 0) { flipped = 0; close_max = 0; }       // back to the original orientation
@@ -981,6 +994,10 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
         alg = (u32)uni((int)o1.z) << 3;
     }
 
+#if defined(PG_STOP) && PG_STOP == 3
+    if (lane == 0) B.out[rid].alg = (u32)(n_close + close_max + close_last);   // diagnostics: the whole close end
+    return;
+#endif
     // ------------------------------------------------------------------------------- far end
     int n_far = 0, far_max = 0;
     u32 far_base = 0;
@@ -1072,10 +1089,16 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                     }
                     // an evaluation can only differ from the previous one if candidates were folded since; an
                     // empty state yields no point ("NumberOfHits == 0" leaves UP_Far untouched, farend_searcher.cpp:87)
+#if defined(PG_STOP) && PG_STOP == 4
+                    if (A.m1 != 0x54321u) break;      // diagnostics: + far end up to the end of the first range's scan
+#endif
                     if (S.nsurv != nsurv_eval) {
                         nsurv_eval = S.nsurv;
                         far_update(origin, nullptr);
                     }
+#if defined(PG_STOP) && PG_STOP == 5
+                    break;                            // diagnostics: + first range's evaluation
+#endif
                     if (far_max + close_max >= len) break;       // goodFarEndFound
                 }
                 far_bases += (pe - ps) + 2 * len;
@@ -1088,12 +1111,13 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
         uint4 *op = (uint4 *)(B.out + rid);
         if (do_close) {
             op[0] = make_uint4(close_base, (u32)n_close, far_base, (u32)n_far);
-            op[1] = make_uint4(close_last, (u32)close_max | ((u32)flipped << 16), alg, 0u);
+            op[1] = make_uint4(close_last, (u32)close_max | ((u32)flipped << 16), alg, (u32)S.nsurv_total);
         } else {
             u32 *o = (u32 *)op;
             o[2] = far_base;
             o[3] = (u32)n_far;
             o[6] = alg;                                  // the far-end launch adds to the close-end launch
+            o[7] += (u32)S.nsurv_total;
         }
     }
 }
@@ -1227,6 +1251,7 @@ __global__ void pg_unpack_kernel(const PgOutRec *out, PgSoaOut a, uint32_t n)
     a.far_off[i] = r.far_off;
     a.far_cnt[i] = r.far_cnt;
     a.alg[i] = r.alg;
+    if (a.cand) a.cand[i] = r.reserved;
 }
 
 extern "C" int pg_pack_reads(const PgSoaIn *soa, PgInRec *in, uint32_t lo, uint32_t cnt, void *stream)

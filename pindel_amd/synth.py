@@ -33,30 +33,42 @@ GRCH38_LENGTHS = [248956422, 242193529, 198295559, 190214555, 181538259, 1708059
 GRCH38_NAMES = [str(i) for i in range(1, 23)] + ["X", "Y"]
 
 
-def _plant_repeats(seq, g, device, repeat_frac, n_families=6, divergence=(0.03, 0.20), n_tracts_per_mb=20):
-    """Repeat-rich variant: `repeat_frac` of the sequence is overwritten by diverged copies
-    of a few repeat families (consensus 300 bp - 6 kb, per-copy divergence drawn from `divergence`), plus
-    low-complexity tracts (mono/di/tri-nucleotide runs of 30-300 bp).  A real genome is about half repeats;
-    the i.i.d. default has a survivor rate of the seed filter that is best-case."""
+def _plant_repeats(seq, g, device, repeat_frac, n_families=6, divergence=(0.02, 0.15), tract_frac=0.03):
+    """Repeat-rich variant.  Pindel's search is LOCAL (a few kb around the anchor), so what
+    makes it harder is local repetitiveness: `repeat_frac` of the sequence is overwritten by ARRAYS of diverged
+    copies of a few repeat families (consensus 150 bp - 3 kb; 2-6 copies within a few kb of each other, per-copy
+    divergence drawn from `divergence`) -- segmental / tandem duplications -- plus low-complexity tracts
+    (mono/di/tri-nucleotide runs of 30-300 bp, `tract_frac` of the sequence).  The i.i.d. default has a
+    survivor rate of the seed filter that is best-case."""
     length = seq.numel()
     acgt = _ACGT.to(device)
-    fam_len = [300, 300, 1200, 2500, 6000, 6000][:n_families]
-    share = [0.30, 0.15, 0.15, 0.15, 0.15, 0.10][:n_families]
+    fam_len = [150, 300, 300, 800, 1500, 3000][:n_families]
+    share = [0.15, 0.25, 0.15, 0.15, 0.15, 0.15][:n_families]
     for f in range(n_families):
         Lf = fam_len[f]
         cons = acgt[torch.randint(0, 4, (Lf,), generator=g, device=device)]
-        k = max(1, int(length * repeat_frac * share[f] / Lf))
+        k = max(1, int(length * repeat_frac * share[f] / Lf))        # copies
+        n_arr = max(1, k // 4)                                         # arrays of ~4 copies
         done = 0
-        while done < k:
-            kk = min(k - done, max(1, (1 << 24) // Lf))
-            pos = torch.randint(0, max(length - Lf, 1), (kk,), generator=g, device=device)
-            div = divergence[0] + (divergence[1] - divergence[0]) * torch.rand(kk, generator=g, device=device)
-            idx = pos[:, None] + torch.arange(Lf, device=device)[None, :]
-            mut = torch.rand(kk, Lf, generator=g, device=device) < div[:, None]
-            rnd = acgt[torch.randint(0, 4, (kk, Lf), generator=g, device=device)]
-            seq[idx.reshape(-1)] = torch.where(mut, rnd, cons[None, :].expand(kk, Lf)).reshape(-1)
-            done += kk
-    n_tr = max(1, int(length / 1e6 * n_tracts_per_mb))
+        while done < n_arr:
+            na = min(n_arr - done, max(1, (1 << 22) // Lf))
+            centre = torch.randint(8000, max(length - 8000 - Lf, 8001), (na,), generator=g, device=device)
+            ncopy = torch.randint(2, 7, (na,), generator=g, device=device)
+            for c in range(6):
+                use = ncopy > c
+                # copies of one array lie within +-(Lf + 2 kb) of its centre (tandem or interspersed)
+                off = torch.randint(-(Lf + 2000), Lf + 2000, (na,), generator=g, device=device)
+                pos = (centre + off)[use]
+                kk = int(pos.numel())
+                if kk == 0:
+                    continue
+                div = divergence[0] + (divergence[1] - divergence[0]) * torch.rand(kk, generator=g, device=device)
+                idx = pos[:, None] + torch.arange(Lf, device=device)[None, :]
+                mut = torch.rand(kk, Lf, generator=g, device=device) < div[:, None]
+                rnd = acgt[torch.randint(0, 4, (kk, Lf), generator=g, device=device)]
+                seq[idx.reshape(-1)] = torch.where(mut, rnd, cons[None, :].expand(kk, Lf)).reshape(-1)
+            done += na
+    n_tr = max(1, int(length * tract_frac / 165))
     pos = torch.randint(0, max(length - 400, 1), (n_tr,), generator=g, device=device)
     tl = torch.randint(30, 300, (n_tr,), generator=g, device=device)
     unit = torch.randint(1, 4, (n_tr,), generator=g, device=device)

@@ -12,3 +12,11 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("seed", [1000, 1006, 1011, 1015, 1020, 1029, 1038, 2024, 61026])
 def test_fuzz_seed(seed):
     assert one_iteration(seed, verbose=False)
+
+
+# a wider driver-observed slice of the hunt: 60 consecutive seeds (a third of them with a second chromosome and
+# per-read BreakDancer window clusters, scripts/fuzz_parity.py)
+@pytest.mark.parametrize("block", range(6))
+def test_fuzz_block(block):
+    for seed in range(3000 + 10 * block, 3010 + 10 * block):
+        assert one_iteration(seed, verbose=False), seed

@@ -350,3 +350,88 @@ def test_anchor_sweep_window_coincidences(engine_factory, small_ref):
     orc = run_oracle({}, small_ref, batch)
     assert (orc["close_cnt"] > 0).sum() > n // 3 and (orc["far_cnt"] > 0).sum() > n // 4
     compare_result(gpu, orc, batch.n)
+
+
+def test_iupac_and_lower_case_read_bases(engine_factory, small_ref):
+    """Read characters other than ACGTN (IUPAC codes, lower case) never match: the reference compares characters,
+    and Convert2RC4N maps everything but ACGTN to 0 (pindel.cpp:110, 966-970), so such a base is a mismatch in
+    every orientation.  The kernel's "other" plane and the oracle agree on that."""
+    eng = engine_factory()
+    eng.load_reference(small_ref)
+    batch = synth.make_reads(small_ref[0][1], 3000, seed=21)
+    rng = np.random.default_rng(3)
+    seq = batch.seq.copy()
+    hit = rng.random(len(seq)) < 0.01
+    seq[hit] = rng.choice(np.frombuffer(b"RYKMSWacgtn", dtype=np.uint8), int(hit.sum()))
+    batch.seq = seq
+    orc = run_oracle({}, small_ref, batch)
+    assert (orc["close_cnt"] > 0).sum() > 1500
+    compare_result(eng.search_batch(batch), orc, batch.n)
+
+
+def test_rejections_are_loud(engine_factory, small_ref, tmp_path):
+    """Everything outside what the device path handles is refused with a status code, never answered wrongly."""
+    import ctypes as C
+    import struct
+    from pindel_amd import binding, hostio
+    from pindel_amd.binding import PgError
+    E_INVALID, E_NO_REFERENCE, E_READ_TOO_LONG, E_UNSUPPORTED = -1, -4, -5, -6
+
+    def code(fn):
+        with pytest.raises(PgError) as e:
+            fn()
+        return e.value.code
+
+    # parameters outside the device path: -H > 64, negative -m
+    assert code(lambda: binding.Engine(min_close=65)) == E_UNSUPPORTED
+    assert code(lambda: binding.Engine(min_close=0)) == E_UNSUPPORTED
+    assert code(lambda: binding.Engine(min_perfect_match=65)) == E_UNSUPPORTED
+    # no reference yet
+    batch = synth.make_reads(small_ref[0][1], 50, seed=22)
+    assert code(lambda: engine_factory().search_batch(batch)) == E_NO_REFERENCE
+    eng = engine_factory()
+    eng.load_reference(small_ref)
+    # a 500-base read (g_maxMismatch has 500 entries)
+    long_read = hostio.batch_from_lists([b"A" * 500], [b"+"], [200000], [500], [0])
+    assert code(lambda: eng.search_batch(long_read)) == E_READ_TOO_LONG
+    ok_read = hostio.batch_from_lists([b"ACGT" * 25], [b"+"], [200000], [500], [0])
+    eng.search_batch(ok_read).free()
+    # unknown chromosome, anchor outside the padded chromosome
+    assert code(lambda: eng.search_batch(hostio.batch_from_lists([b"ACGT" * 25], [b"+"], [200000], [500], [3]))) == E_INVALID
+    assert code(lambda: eng.search_batch(hostio.batch_from_lists([b"ACGT" * 25], [b"+"], [5_000_000], [500], [0]))) == E_INVALID
+    # more than 16 mismatch levels for the longest read of the batch (-e 0.05 at 300 bp)
+    noisy = engine_factory(seq_error_rate=0.05)
+    noisy.load_reference(small_ref)
+    assert code(lambda: noisy.search_batch(synth.make_reads(small_ref[0][1], 20, seed=23, read_len=300))) == E_UNSUPPORTED
+    noisy.search_batch(synth.make_reads(small_ref[0][1], 20, seed=23, read_len=100)).free()
+    # BreakDancer clusters: more than 127 windows, a window of 2^26 bases, an unknown chromosome
+    db = eng.upload(batch)
+    off = np.zeros(batch.n + 1, dtype=np.uint64)
+    off[1:] = 128
+    win = np.zeros(128, dtype=binding.WINDOW_DTYPE)
+    win["start"], win["end"] = 100000, 100100
+    assert code(lambda: eng.set_windows(db, win, off)) == E_UNSUPPORTED
+    off[1:] = 1
+    big = np.zeros(1, dtype=binding.WINDOW_DTYPE)
+    big["start"], big["end"] = 0, 1 << 26
+    assert code(lambda: eng.set_windows(db, big, off)) == E_UNSUPPORTED
+    big["end"], big["chr_id"] = 1000, 7
+    assert code(lambda: eng.set_windows(db, big, off)) == E_INVALID
+    eng.free_device_batch(db)
+    # a chromosome of 2^31 bases or more: refused before a single base is read (positions are signed 32-bit)
+    L = binding.lib()
+    names = (C.c_char_p * 1)(b"huge")
+    buf = np.zeros(16, dtype=np.uint8)
+    ptrs = (C.c_void_p * 1)(buf.ctypes.data)
+    lens = (C.c_uint64 * 1)((1 << 31) + 5)
+    assert L.pg_load_reference(eng._h, 1, names, ptrs, lens) == E_UNSUPPORTED
+    assert b"2^31" in L.pg_last_error(eng._h)
+    # ... and in a packed reference file
+    path = tmp_path / "huge.pgref"
+    with open(path, "wb") as fh:
+        fh.write(b"PGREF01\0" + struct.pack("<II", 100000, 1) + struct.pack("<I", 4) + b"huge" +
+                 struct.pack("<QQ", (1 << 31) + 5, 64))
+    assert code(lambda: engine_factory().load_packed(path)) == E_INVALID
+    # the engine still works after all of that
+    eng.load_reference(small_ref)
+    compare_result(eng.search_batch(batch), run_oracle({}, small_ref, batch), batch.n)
