@@ -12,16 +12,62 @@
 // own command line.  They restore exactly the post-state the reference leaves behind:
 // UnmatchedSeq reverse-complemented when GetCloseEnd did so, UP_Close after CleanUniquePoints,
 // UP_Far untouched by any pruning.
+//
+// The per-read work either side of the GPU call (gathering the bases into one buffer, expanding the
+// run-length-encoded lists into UniquePoints) is spread over host threads in contiguous read ranges: it
+// is the part of the seam that scales with the number of points (~90 per read), not the search.
 #ifndef PG_ADAPTER_HPP
 #define PG_ADAPTER_HPP
 
+#include <algorithm>
 #include <cstdint>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pindel_pg.h"
 
 namespace pg_adapter {
+
+// fn(lo, hi) over [0, n) in contiguous ranges on up to `max_threads` threads
+template <class Fn>
+void parallel_ranges(size_t n, Fn fn, unsigned max_threads = 16)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw == 0) hw = 1;
+    const unsigned nt = (unsigned)std::min<size_t>(std::min(hw, max_threads), (n + 4095) / 4096);
+    if (nt <= 1) {
+        fn((size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++) th.emplace_back(fn, n * t / nt, n * (t + 1) / nt);
+    for (std::thread &x : th) x.join();
+}
+
+// Convert2RC4N (src/pindel.cpp:966-970): A<->T, C<->G, N->N, every other character -> 0
+inline char rc_char(char c)
+{
+    return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c == 'N' ? 'N' : 0;
+}
+
+inline void rc_in_place(std::string &s)
+{
+    const size_t n = s.size();
+    for (size_t i = 0; i < n / 2; i++) {
+        const char a = rc_char(s[i]), b = rc_char(s[n - 1 - i]);
+        s[i] = b;
+        s[n - 1 - i] = a;
+    }
+    if (n & 1) s[n / 2] = rc_char(s[n / 2]);
+}
+
+inline std::string rc(const std::string &s)
+{
+    std::string o(s);
+    rc_in_place(o);
+    return o;
+}
 
 struct Batch {
     std::vector<uint8_t> seq, strand;
@@ -42,43 +88,63 @@ struct Batch {
     }
 };
 
-// chr_of(read) -> index of read.FragName in the loaded reference
+// chr_of(read) -> index of read.FragName in the loaded reference.  un_rc (nullable): reads whose flag is set
+// are written reverse-complemented (pg_far_end_batch wants the ORIGINAL orientation; the rc flags travel in
+// the close result).
 template <class Read, class ChrOf>
-Batch make_batch(const std::vector<Read> &reads, ChrOf chr_of)
+Batch make_batch(const std::vector<Read> &reads, ChrOf chr_of, const uint8_t *un_rc = nullptr)
 {
     Batch b;
-    b.off.push_back(0);
-    for (const Read &r : reads) {
-        b.seq.insert(b.seq.end(), r.UnmatchedSeq.begin(), r.UnmatchedSeq.end());
-        b.off.push_back(b.seq.size());
-        b.strand.push_back((uint8_t)r.MatchedD);
-        b.pos.push_back((int32_t)r.MatchedRelPos);
-        b.isz.push_back((int16_t)r.InsertSize);
-        b.chr.push_back((int32_t)chr_of(r));
-    }
+    const size_t n = reads.size();
+    b.off.resize(n + 1);
+    b.off[0] = 0;
+    for (size_t i = 0; i < n; i++) b.off[i + 1] = b.off[i] + reads[i].UnmatchedSeq.size();
+    b.seq.resize(b.off[n]);
+    b.strand.resize(n);
+    b.pos.resize(n);
+    b.isz.resize(n);
+    b.chr.resize(n);
+    parallel_ranges(n, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) {
+            const Read &r = reads[i];
+            const std::string &s = r.UnmatchedSeq;
+            uint8_t *dst = b.seq.data() + b.off[i];
+            if (un_rc && un_rc[i])
+                for (size_t j = 0; j < s.size(); j++) dst[j] = (uint8_t)rc_char(s[s.size() - 1 - j]);
+            else
+                std::copy(s.begin(), s.end(), dst);
+            b.strand[i] = (uint8_t)r.MatchedD;
+            b.pos[i] = (int32_t)r.MatchedRelPos;
+            b.isz[i] = (int16_t)r.InsertSize;
+            b.chr[i] = (int32_t)chr_of(r);
+        }
+    });
     return b;
 }
 
-// make_point(pg_point) -> the read type's UniquePoint
+// make_point(pg_point) -> the read type's UniquePoint; the runs [lo, hi) are expanded in place
 template <class Points, class MakePoint>
 void fill_points(Points &dst, const pg_run *runs, uint64_t lo, uint64_t hi, MakePoint make_point)
 {
     dst.clear();
+    size_t total = 0;
+    for (uint64_t k = lo; k < hi; k++) total += (size_t)(runs[k].len_last - runs[k].len_first) + 1;
+    dst.reserve(total);
     for (uint64_t k = lo; k < hi; k++) {
-        pg_point p[512];
-        uint64_t n = pg_expand_runs(runs + k, 1, p);
-        for (uint64_t i = 0; i < n; i++) dst.push_back(make_point(p[i]));
+        const pg_run &r = runs[k];
+        const bool back = (r.flags & PG_RUN_BACKWARD) != 0;
+        pg_point p;
+        p.mismatches = r.mismatches;
+        p.chr_id = r.chr_id;
+        p.direction = back ? '-' : '+';
+        p.strand = (r.flags & PG_RUN_ANTISENSE) ? '-' : '+';
+        for (uint32_t L = r.len_first; L <= r.len_last; L++) {
+            const uint32_t d = L - r.len_first;
+            p.abs_loc = back ? r.abs_loc_first - d : r.abs_loc_first + d;
+            p.length = (int16_t)L;
+            dst.push_back(make_point(p));
+        }
     }
-}
-
-inline std::string rc(const std::string &s)
-{
-    std::string o(s.size(), 0);
-    for (size_t j = 0; j < s.size(); j++) {
-        char c = s[s.size() - 1 - j];
-        o[j] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c == 'N' ? 'N' : 0;
-    }
-    return o;
 }
 
 // Close end for a whole batch.  Returns the pg status; `result` keeps UP_Close summaries for the
@@ -93,10 +159,12 @@ int CloseEndBatch(pg_ctx *ctx, std::vector<Read> &reads, ChrOf chr_of, MakePoint
     if (rc_) return rc_;
     pg_result_view rv;
     pg_result_view_get(*result, &rv);
-    for (size_t i = 0; i < reads.size(); i++) {
-        if (rv.rc_flag[i]) reads[i].UnmatchedSeq = rc(reads[i].UnmatchedSeq);   // setUnmatchedSeq(RC), pindel.cpp:2545
-        fill_points(reads[i].UP_Close, rv.close_runs, rv.close_off[i], rv.close_off[i + 1], make_point);
-    }
+    parallel_ranges(reads.size(), [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) {
+            if (rv.rc_flag[i]) rc_in_place(reads[i].UnmatchedSeq);     // setUnmatchedSeq(RC), pindel.cpp:2545
+            fill_points(reads[i].UP_Close, rv.close_runs, rv.close_off[i], rv.close_off[i + 1], make_point);
+        }
+    });
     return PG_OK;
 }
 
@@ -105,30 +173,19 @@ template <class Read, class ChrOf, class MakePoint>
 int SearchFarEnds(pg_ctx *ctx, std::vector<Read> &reads, ChrOf chr_of, MakePoint make_point,
                   pg_result *close_result, const pg_windows *hints)
 {
-    // pg_far_end_batch wants the sequences in their ORIGINAL orientation (the rc flags travel in
-    // close_result); undo CloseEndBatch's flip for the upload only
-    std::vector<Read> &rs = reads;
     pg_result_view rv0;
     pg_result_view_get(close_result, &rv0);
-    const std::vector<uint8_t> was_rc(rv0.rc_flag, rv0.rc_flag + rs.size());
-    Batch b;
-    b.off.push_back(0);
-    for (size_t i = 0; i < rs.size(); i++) {
-        const std::string s = was_rc[i] ? rc(rs[i].UnmatchedSeq) : rs[i].UnmatchedSeq;
-        b.seq.insert(b.seq.end(), s.begin(), s.end());
-        b.off.push_back(b.seq.size());
-        b.strand.push_back((uint8_t)rs[i].MatchedD);
-        b.pos.push_back((int32_t)rs[i].MatchedRelPos);
-        b.isz.push_back((int16_t)rs[i].InsertSize);
-        b.chr.push_back((int32_t)chr_of(rs[i]));
-    }
+    // pg_far_end_batch wants the sequences in their ORIGINAL orientation: undo CloseEndBatch's flip for the upload only
+    Batch b = make_batch(reads, chr_of, rv0.rc_flag);
     pg_read_batch v = b.view();
     int rc_ = pg_far_end_batch(ctx, &v, close_result, hints);
     if (rc_) return rc_;
     pg_result_view rv;
     pg_result_view_get(close_result, &rv);
-    for (size_t i = 0; i < rs.size(); i++)
-        fill_points(rs[i].UP_Far, rv.far_runs, rv.far_off[i], rv.far_off[i + 1], make_point);
+    parallel_ranges(reads.size(), [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++)
+            fill_points(reads[i].UP_Far, rv.far_runs, rv.far_off[i], rv.far_off[i + 1], make_point);
+    });
     return PG_OK;
 }
 

@@ -38,43 +38,60 @@ int run_pipeline(const std::vector<Chromosome> &genome, const std::vector<unsign
 {
     Caller caller(S, &genome, prefix, true);
     const unsigned WINDOW = (unsigned)(S.window_mbp * 1000000);
+    // The Pindel-text reader rescans the whole file for every window and raises g_maxPos for EVERY read it
+    // passes (reader.cpp:224-226), so after the first window of a chromosome g_maxPos is the largest position
+    // in the file; the windows then run until they pass it.  Here the reads are bucketed once: per chromosome
+    // the indices of its reads by window, in input order (a stable counting sort), instead of one pass over
+    // all reads per window.
+    unsigned file_max_pos = 0;
+    std::vector<std::vector<uint32_t>> by_chr(genome.size());
+    for (uint32_t i = 0; i < all.size(); i++) {
+        file_max_pos = std::max(file_max_pos, all[i].MatchedRelPos);
+        if (all[i].chr_id >= 0 && all[i].chr_id < (int)genome.size()) by_chr[all[i].chr_id].push_back(i);
+    }
     for (size_t c = 0; c < genome.size(); c++) {
         const Chromosome &chrom = genome[c];
         const unsigned biol = (unsigned)(chrom.seq.size() - 2 * S.spacer);
         const unsigned bed_start = 1, bed_end = fai[c] ? fai[c] : biol;   // "-c ALL": one BED record per chromosome
         const unsigned global_end = std::min(biol, bed_end + 10000u);      // AROUND_REGION_BUFFER
-        unsigned g_max_pos = 0;                                            // reset per BED region, pindel.cpp:1798
-        unsigned ws = 0;
-        do {
-            const unsigned we = std::min(ws + WINDOW, global_end);
+        // windows that will be visited: ws = 0, W, 2W, ... while !(ws >= g_maxPos || ws > global_end), at least one
+        std::vector<unsigned> starts;
+        {
+            unsigned ws = 0;
+            do {
+                starts.push_back(ws);
+                ws += WINDOW;
+            } while (!(ws >= file_max_pos || ws > global_end));
+        }
+        std::vector<std::vector<uint32_t>> bins(starts.size());
+        for (uint32_t i : by_chr[c]) {
+            const size_t w = all[i].MatchedRelPos / WINDOW;
+            // a read is picked up by window w iff ws <= pos < min(ws + W, global_end)
+            if (w < starts.size() && all[i].MatchedRelPos < std::min(starts[w] + WINDOW, global_end)) bins[w].push_back(i);
+        }
+        for (size_t w = 0; w < starts.size(); w++) {
+            if (bins[w].empty()) continue;
+            const unsigned ws = starts[w], we = std::min(ws + WINDOW, global_end);
             std::vector<SplitRead> reads;
-            std::vector<uint32_t> index;
-            for (uint32_t i = 0; i < all.size(); i++) {
-                const SplitRead &src = all[i];
-                if (src.MatchedRelPos > g_max_pos) g_max_pos = src.MatchedRelPos;          // reader.cpp:224-226
-                if (src.chr_id != (int)c || !(src.MatchedRelPos >= ws && src.MatchedRelPos < we)) continue;
-                reads.push_back(src);
+            reads.reserve(bins[w].size());
+            for (uint32_t i : bins[w]) {
+                reads.push_back(all[i]);
                 if (reads.back().MatchedRelPos > biol) reads.back().MatchedRelPos = biol;   // reader.cpp:233-235
-                reads.back().MAX_SNP_ERROR = (short)S.max_mismatch[std::min<int>(src.ReadLength, 499)];
-                index.push_back(i);
+                reads.back().MAX_SNP_ERROR = (short)S.max_mismatch[std::min<int>(all[i].ReadLength, 499)];
             }
-            if (!reads.empty()) {
-                int rc = search(chrom, (int)c, reads, index);
-                if (rc) {
-                    err = "search step failed";
-                    return rc;
+            int rc = search(chrom, (int)c, reads, bins[w]);
+            if (rc) {
+                err = "search step failed";
+                return rc;
+            }
+            std::vector<SplitRead> kept;                                // reader.cpp:258-291
+            for (SplitRead &r : reads)
+                if (!r.UP_Close.empty()) {
+                    caller.note_close_mapped(r);
+                    kept.push_back(std::move(r));      // `reads` is not used after this loop
                 }
-                std::vector<SplitRead> kept;                                // reader.cpp:258-291
-                for (SplitRead &r : reads)
-                    if (!r.UP_Close.empty()) {
-                        caller.note_close_mapped(r);
-                        kept.push_back(std::move(r));      // `reads` is not used after this loop
-                    }
-                if (!kept.empty()) caller.process_window(chrom, kept, ws, we, bed_start, bed_end);
-            }
-            ws += WINDOW;
-            // LoopingSearchWindow::finished, pindel.cpp:464-471 (Pindel-text input shortcut)
-        } while (!(ws >= g_max_pos || ws > global_end));
+            if (!kept.empty()) caller.process_window(chrom, kept, ws, we, bed_start, bed_end);
+        }
     }
     return 0;
 }

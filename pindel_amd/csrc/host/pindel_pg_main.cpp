@@ -9,7 +9,10 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <algorithm>
+#include <iterator>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pg_adapter.hpp"
@@ -124,10 +127,24 @@ int main(int argc, char **argv)
         }
         // -T (threads: the search runs on the GPU), -n, -A, -L: accepted, no effect on this path
     }
-    if (!gpu_list.empty()) {
-        char *endp = nullptr;
-        prm.device = (int)strtol(gpu_list.c_str(), &endp, 10);
-        if (endp == gpu_list.c_str()) {
+    // -G 0,1,...: the reads of every bin are sharded over these devices in contiguous ranges (reads are
+    // independent: the loop of SearchFarEnds / ReadBuffer::flush, src/pindel.cpp:1115-1138), reference
+    // replicated per device, results concatenated in order -- identical reports for any device count
+    std::vector<int> devices;
+    if (gpu_list.empty()) devices.push_back(prm.device);
+    else {
+        const char *q = gpu_list.c_str();
+        while (*q) {
+            char *endp = nullptr;
+            const long d = strtol(q, &endp, 10);
+            if (endp == q || d < 0 || (*endp != 0 && *endp != ',')) {
+                fprintf(stderr, "pindel_pg: bad device list %s\n", gpu_list.c_str());
+                return 2;
+            }
+            devices.push_back((int)d);
+            q = *endp ? endp + 1 : endp;
+        }
+        if (devices.empty()) {
             fprintf(stderr, "pindel_pg: bad device list %s\n", gpu_list.c_str());
             return 2;
         }
@@ -147,12 +164,20 @@ int main(int argc, char **argv)
         fprintf(stderr, "pindel_pg: %s\n", err.c_str());
         return 1;
     }
-    pg_ctx *ctx = nullptr;
-    int rc = pg_create(&prm, &ctx);
-    if (rc) {
-        fprintf(stderr, "pindel_pg: pg_create failed (%d): no usable MI355X / HIP device\n", rc);
-        return 1;
+    std::vector<pg_ctx *> ctxs;
+    int rc = 0;
+    for (int d : devices) {
+        pg_params p = prm;
+        p.device = d;
+        pg_ctx *c = nullptr;
+        rc = pg_create(&p, &c);
+        if (rc) {
+            fprintf(stderr, "pindel_pg: pg_create failed (%d) on device %d: no usable MI355X / HIP device\n", rc, d);
+            return 1;
+        }
+        ctxs.push_back(c);
     }
+    pg_ctx *ctx = ctxs[0];
     {
         std::vector<const char *> names;
         std::vector<const uint8_t *> seqs;
@@ -162,10 +187,12 @@ int main(int argc, char **argv)
             seqs.push_back((const uint8_t *)c.seq.data());
             lens.push_back(c.seq.size());
         }
-        rc = pg_load_reference(ctx, (int32_t)genome.size(), names.data(), seqs.data(), lens.data());
-        if (rc) {
-            fprintf(stderr, "pindel_pg: pg_load_reference: %s\n", pg_last_error(ctx));
-            return 1;
+        for (pg_ctx *c : ctxs) {
+            rc = pg_load_reference(c, (int32_t)genome.size(), names.data(), seqs.data(), lens.data());
+            if (rc) {
+                fprintf(stderr, "pindel_pg: pg_load_reference: %s\n", pg_last_error(c));
+                return 1;
+            }
         }
     }
     S.spacer = prm.spacer;
@@ -200,30 +227,15 @@ int main(int argc, char **argv)
         printf("pindel_pg: BD events: %zu%s\n", bd.n_events(), use_bd ? "" : " (not used for Pindel-text input; --bd-hints on to use them)");
     }
     size_t n_close = 0, n_far = 0;
-    auto search = [&](const Chromosome &, int, std::vector<SplitRead> &reads, const std::vector<uint32_t> &) {
-        const double t0 = now_s();
+    // close end + far end of a contiguous range of a bin's reads on one device (ReadBuffer::flush, then SearchFarEnds)
+    auto search_shard = [&](pg_ctx *c, std::vector<SplitRead> &reads) {
         pg_result *res = nullptr;
-        int r = pg_adapter::CloseEndBatch(ctx, reads, chr_of, make_point, &res);      // ReadBuffer::flush
+        int r = pg_adapter::CloseEndBatch(c, reads, chr_of, make_point, &res);
         if (r) return r;
         std::vector<uint64_t> hoff;
         std::vector<pg_window> hwin;
         pg_windows hints = { nullptr, nullptr };
         if (use_bd && bd.n_events() && !reads.empty()) {
-            // the bin of these reads, as main() hands it to g_bdData.loadRegion (pindel.cpp:1828, 1853)
-            unsigned lo = reads[0].MatchedRelPos, hi = reads[0].MatchedRelPos;
-            for (const SplitRead &x : reads) {
-                lo = std::min(lo, x.MatchedRelPos);
-                hi = std::max(hi, x.MatchedRelPos);
-            }
-            const unsigned W = (unsigned)(S.window_mbp * 1000000);
-            const unsigned ws = lo / W * W, we = ws + W;
-            (void)hi;
-            std::string berr;
-            if (!bd.load_region(chr_names, reads[0].chr_id, ws + prm.spacer, we + prm.spacer, berr)) {
-                fprintf(stderr, "pindel_pg: %s\n", berr.c_str());
-                pg_result_free(res);
-                return (int)PG_E_INVALID;
-            }
             hoff.push_back(0);
             for (const SplitRead &x : reads) {
                 if (!x.UP_Close.empty())
@@ -236,8 +248,43 @@ int main(int argc, char **argv)
             hints.offset = hoff.data();
             hints.windows = hwin.empty() ? nullptr : hwin.data();
         }
-        r = pg_adapter::SearchFarEnds(ctx, reads, chr_of, make_point, res, hints.offset ? &hints : nullptr);   // SearchFarEnds
+        r = pg_adapter::SearchFarEnds(c, reads, chr_of, make_point, res, hints.offset ? &hints : nullptr);
         pg_result_free(res);
+        return r;
+    };
+    auto search = [&](const Chromosome &, int, std::vector<SplitRead> &reads, const std::vector<uint32_t> &) {
+        const double t0 = now_s();
+        if (use_bd && bd.n_events() && !reads.empty()) {
+            // the bin of these reads, as main() hands it to g_bdData.loadRegion (pindel.cpp:1828, 1853)
+            unsigned lo = reads[0].MatchedRelPos;
+            for (const SplitRead &x : reads) lo = std::min(lo, x.MatchedRelPos);
+            const unsigned W = (unsigned)(S.window_mbp * 1000000);
+            const unsigned ws = lo / W * W, we = ws + W;
+            std::string berr;
+            if (!bd.load_region(chr_names, reads[0].chr_id, ws + prm.spacer, we + prm.spacer, berr)) {
+                fprintf(stderr, "pindel_pg: %s\n", berr.c_str());
+                return (int)PG_E_INVALID;
+            }
+        }
+        int r = 0;
+        const size_t nd = ctxs.size(), n = reads.size();
+        if (nd == 1 || n < 2 * nd) r = search_shard(ctxs[0], reads);
+        else {
+            // contiguous shards, one host thread and one ctx per device; moved out and back: order is kept
+            std::vector<std::vector<SplitRead>> parts(nd);
+            std::vector<int> rcs(nd, 0);
+            for (size_t d = 0; d < nd; d++) {
+                const size_t lo = n * d / nd, hi = n * (d + 1) / nd;
+                parts[d].assign(std::make_move_iterator(reads.begin() + lo), std::make_move_iterator(reads.begin() + hi));
+            }
+            std::vector<std::thread> th;
+            for (size_t d = 0; d < nd; d++) th.emplace_back([&, d]() { rcs[d] = search_shard(ctxs[d], parts[d]); });
+            for (std::thread &x : th) x.join();
+            for (size_t d = 0; d < nd; d++) {
+                if (rcs[d]) r = rcs[d];
+                std::move(parts[d].begin(), parts[d].end(), reads.begin() + n * d / nd);
+            }
+        }
         for (const SplitRead &x : reads) {
             n_close += !x.UP_Close.empty();
             n_far += !x.UP_Far.empty();
@@ -253,6 +300,6 @@ int main(int argc, char **argv)
         printf("pindel_pg: loading %.2f s, split-read search (GPU, incl. adapters) %.2f s, classification + reports %.2f s\n",
                t_loaded - t_start, t_search, now_s() - t_loaded - t_search);
     }
-    pg_destroy(ctx);
+    for (pg_ctx *c : ctxs) pg_destroy(c);
     return rc ? 1 : 0;
 }

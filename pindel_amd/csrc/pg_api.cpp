@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -18,11 +19,117 @@
 #include "pg_device.h"
 #include "pindel_pg.h"
 
+#include <chrono>
 namespace {
 
-struct DevBuf {
-    void *p = nullptr;
-    size_t bytes = 0;
+double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+const bool g_host_timing = getenv("PG_HOST_TIMING") != nullptr;
+
+// Pinned host memory for results (device-to-host copies at PCIe speed, no staging through pageable pages).
+// Pinning is expensive, results are handed out and freed all the time (Pindel flushes a batch every 50 000
+// reads): freed blocks go to a small process-wide cache and are reused by the next result of similar size.
+struct PinnedCache {
+    std::mutex mu;
+    std::vector<std::pair<void *, size_t>> free_blocks;
+    size_t cached_bytes = 0;
+    static const size_t kMaxCached = (size_t)6 << 30;
+    void *get(size_t bytes, size_t *got)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            size_t best = free_blocks.size();
+            for (size_t i = 0; i < free_blocks.size(); i++)
+                if (free_blocks[i].second >= bytes && free_blocks[i].second <= 2 * bytes + 4096 &&
+                    (best == free_blocks.size() || free_blocks[i].second < free_blocks[best].second))
+                    best = i;
+            if (best != free_blocks.size()) {
+                void *p = free_blocks[best].first;
+                *got = free_blocks[best].second;
+                cached_bytes -= *got;
+                free_blocks.erase(free_blocks.begin() + best);
+                return p;
+            }
+        }
+        void *p = nullptr;
+        const size_t want = (bytes + 4095) & ~(size_t)4095;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+        *got = want;
+        return p;
+    }
+    void put(void *p, size_t bytes)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (cached_bytes + bytes <= kMaxCached) {
+                free_blocks.push_back(std::make_pair(p, bytes));
+                cached_bytes += bytes;
+                return;
+            }
+        }
+        (void)hipHostFree(p);
+    }
+};
+PinnedCache g_pinned;
+
+template <typename T>
+struct HostBuf {
+    T *p = nullptr;
+    size_t n = 0, cap_bytes = 0;
+    HostBuf() {}
+    HostBuf(const HostBuf &) = delete;
+    HostBuf &operator=(const HostBuf &) = delete;
+    ~HostBuf() { release(); }
+    void release()
+    {
+        if (p) g_pinned.put(p, cap_bytes);
+        p = nullptr;
+        n = cap_bytes = 0;
+    }
+    // contents are NOT initialised (they are about to be overwritten by a device-to-host copy)
+    bool resize(size_t count)
+    {
+        if (count * sizeof(T) > cap_bytes) {
+            release();
+            p = (T *)g_pinned.get(std::max<size_t>(count * sizeof(T), 64), &cap_bytes);
+            if (!p) return false;
+        }
+        n = count;
+        return true;
+    }
+    bool assign(size_t count, T v)
+    {
+        if (!resize(count)) return false;
+        for (size_t i = 0; i < count; i++) p[i] = v;
+        return true;
+    }
+    T *data() { return p; }
+    const T *data() const { return p; }
+    size_t size() const { return n; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+    void swap(HostBuf &o)
+    {
+        std::swap(p, o.p);
+        std::swap(n, o.n);
+        std::swap(cap_bytes, o.cap_bytes);
+    }
+};
+
+// Grow-only device arena of a ctx: the buffers of a host-path batch (pg_search_batch & co) are carved out of
+// it instead of ~25 hipMalloc / hipFree per call.
+struct DevArena {
+    char *base = nullptr;
+    size_t cap = 0, used = 0;
+    void *take(size_t bytes)
+    {
+        const size_t at = (used + 255) & ~(size_t)255;
+        if (at + bytes > cap) return nullptr;
+        used = at + bytes;
+        return base + at;
+    }
 };
 
 }  // namespace
@@ -48,6 +155,7 @@ struct pg_ctx {
     uint32_t *d_lo = nullptr, *d_hi = nullptr, *d_nn = nullptr;
     uint64_t *d_word_off = nullptr;
     uint32_t *d_chr_size = nullptr;
+    DevArena arena;                    // device memory of the host-path batches, reused across calls
     // stats of the last search
     double last_ms = 0.0;
     uint64_t last_runs = 0;
@@ -75,6 +183,8 @@ struct pg_device_batch {
     PgInRec *in_rec = nullptr;         // packed per-read records the kernel reads / writes (pg_device.h)
     PgOutRec *out_rec = nullptr;
     bool unpacked = true;              // the SoA output arrays reflect out_rec
+    bool in_arena = false;             // buffers belong to the ctx arena (not freed one by one)
+    bool pool_owned = false;           // ... except a run pool that had to be regrown
     pg_run *pool = nullptr;
     uint32_t pool_shard_cap = 0;       // runs per shard (PG_POOL_SHARDS shards)
     uint32_t *pool_used = nullptr;     // [PG_POOL_SHARDS * 16]
@@ -84,14 +194,19 @@ struct pg_device_batch {
 
 struct pg_result {
     uint32_t n = 0;
-    std::vector<uint64_t> close_off, far_off;
-    std::vector<pg_run> close_runs, far_runs;
-    std::vector<uint8_t> rc_flag;
-    std::vector<uint32_t> close_last;
-    std::vector<uint16_t> close_max;
+    HostBuf<uint64_t> close_off, far_off;
+    HostBuf<pg_run> close_runs, far_runs;
+    HostBuf<uint8_t> rc_flag;
+    HostBuf<uint32_t> close_last;
+    HostBuf<uint16_t> close_max;
+    HostBuf<uint32_t> csr32[2];        // staging of the device-built 32-bit offsets
 };
 
 namespace {
+
+// One ctx drives one device; a process may hold several (one host thread each): every entry point selects
+// its ctx's device for the calling thread first.
+void use_device(const pg_ctx *ctx);
 
 int fail(pg_ctx *ctx, int code, const std::string &msg)
 {
@@ -179,6 +294,11 @@ void free_reference(pg_ctx *ctx)
     ctx->h_nn.clear();
 }
 
+void use_device(const pg_ctx *ctx)
+{
+    if (ctx) (void)hipSetDevice(ctx->prm.device);
+}
+
 PgDevRef dev_ref(const pg_ctx *ctx)
 {
     PgDevRef r;
@@ -213,6 +333,15 @@ PgDevParams dev_params(const pg_ctx *ctx)
 
 void free_batch_buffers(pg_device_batch *b)
 {
+    if (b->in_arena) {
+        if (b->pool_owned && b->pool) (void)hipFree(b->pool);
+        if (b->bd_off) (void)hipFree(b->bd_off);          // window clusters are always allocated on their own
+        if (b->bd) (void)hipFree(b->bd);
+        b->pool = nullptr;
+        b->bd_off = nullptr;
+        b->bd = nullptr;
+        return;
+    }
     void *ptrs[] = { b->seq, b->seq_off, b->strand, b->pos, b->isz, b->chr, b->rc_flag,
                      b->close_last, b->close_max, b->bd_off, b->bd, b->close_off, b->close_cnt,
                      b->far_off, b->far_cnt, b->alg, b->pool, b->pool_used, b->in_rec, b->out_rec };
@@ -256,7 +385,9 @@ int validate_and_measure(pg_ctx *ctx, const pg_read_batch *reads, uint32_t *max_
 
 // Validates the batch and allocates its device buffers.  copy = true also copies the inputs
 // (synchronously); otherwise the caller streams them in (search_host).  off = read offsets rebased to 0.
-int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, std::vector<uint64_t> &off, pg_device_batch **out)
+// use_arena: carve the buffers out of the ctx arena (host-path calls: the batch dies with the call).
+int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, std::vector<uint64_t> &off, pg_device_batch **out,
+                bool use_arena = false)
 {
     uint32_t max_len = 0, levels = 0;
     int rc = validate_and_measure(ctx, reads, &max_len, &levels);
@@ -271,47 +402,62 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, std::vector<
     const uint64_t nseq = n ? reads->seq_off[n] - base0 : 0;
     off.resize(n + 1);
     for (size_t i = 0; i <= n; i++) off[i] = (n ? reads->seq_off[i] : 0) - base0;
-#define AL(field, cnt)                                                 \
-    if ((rc = dev_alloc(ctx, &b->field, cnt)) != PG_OK) {              \
-        free_batch_buffers(b);                                         \
-        delete b;                                                      \
-        return rc;                                                     \
-    }
-    AL(seq, (size_t)nseq);
-    AL(seq_off, n + 1);
-    AL(strand, n);
-    AL(pos, n);
-    AL(isz, n);
-    AL(chr, n);
-    AL(rc_flag, n);
-    AL(close_last, n);
-    AL(close_max, n);
-    AL(close_off, n);
-    AL(close_cnt, n + 1);            // + 1: the device-side CSR scan runs over n + 1 counts
-    AL(far_off, n);
-    AL(far_cnt, n + 1);
-    AL(alg, n);
-    AL(in_rec, n);
-    AL(out_rec, n);
-    AL(pool_used, PG_POOL_SHARDS * 16 + PG_WORK_CTRS * 16);     // run-pool cursors + the launch's read counters
     b->pool_shard_cap = (uint32_t)std::min<uint64_t>((3ull * n) / PG_POOL_SHARDS + 96ull, 0x7fffffffull / PG_POOL_SHARDS);
     if (getenv("PG_TEST_TINY_POOL")) b->pool_shard_cap = 1;      // tests: force the overflow/regrow path
-    AL(pool, (size_t)b->pool_shard_cap * PG_POOL_SHARDS);
-#undef AL
-    {
-        // the device-side CSR scan / gather trusts these counts: a failed memset must not go unnoticed
-        hipError_t e = hipMemset(b->close_cnt, 0, (n + 1) * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMemset(b->far_cnt, 0, (n + 1) * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMemset(b->close_off, 0, std::max<size_t>(n, 1) * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMemset(b->far_off, 0, std::max<size_t>(n, 1) * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMemset(b->rc_flag, 0, std::max<size_t>(n, 1));
-        if (e == hipSuccess) e = hipMemset(b->close_max, 0, std::max<size_t>(n, 1) * sizeof(uint16_t));
-        if (e == hipSuccess) e = hipMemset(b->alg, 0, std::max<size_t>(n, 1) * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMemset(b->out_rec, 0, std::max<size_t>(n, 1) * sizeof(PgOutRec));
-        if (e != hipSuccess) {
-            free_batch_buffers(b);
-            delete b;
-            return fail(ctx, PG_E_DEVICE, std::string("clearing the batch outputs: ") + hipGetErrorString(e));
+    const size_t n1 = std::max<size_t>(n, 1);
+    // (pointer, bytes) of every buffer; the zeroed block (outputs) is contiguous in the arena case
+    struct Item { void **p; size_t bytes; };
+    const Item items[] = {
+        { (void **)&b->seq, std::max<size_t>((size_t)nseq, 1) }, { (void **)&b->seq_off, (n + 1) * 8 },
+        { (void **)&b->strand, n1 }, { (void **)&b->pos, n1 * 4 }, { (void **)&b->isz, n1 * 2 }, { (void **)&b->chr, n1 * 4 },
+        { (void **)&b->in_rec, n1 * sizeof(PgInRec) },
+        { (void **)&b->pool, (size_t)b->pool_shard_cap * PG_POOL_SHARDS * sizeof(pg_run) },
+        // ---- zero-initialised from here
+        { (void **)&b->rc_flag, n1 }, { (void **)&b->close_last, n1 * 4 }, { (void **)&b->close_max, n1 * 2 },
+        { (void **)&b->close_off, n1 * 4 }, { (void **)&b->close_cnt, (n + 1) * 4 },   // + 1: the CSR scan runs over n + 1 counts
+        { (void **)&b->far_off, n1 * 4 }, { (void **)&b->far_cnt, (n + 1) * 4 }, { (void **)&b->alg, n1 * 4 },
+        { (void **)&b->out_rec, n1 * sizeof(PgOutRec) },
+        { (void **)&b->pool_used, (PG_POOL_SHARDS * 16 + PG_WORK_CTRS * 16) * 4 },  // run-pool cursors + the launch's read counters
+    };
+    const size_t n_items = sizeof items / sizeof items[0], first_zero = 8;
+    auto drop = [&](int code) {
+        free_batch_buffers(b);
+        delete b;
+        return code;
+    };
+    if (use_arena) {
+        size_t need = 4096;
+        for (const Item &it : items) need += ((it.bytes + 255) & ~(size_t)255) + 256;
+        // room for the download's temporaries too: CSR offsets, gathered runs, scan scratch
+        need += 2 * (((n + 1) * 4 + 511) & ~(size_t)255) + (size_t)b->pool_shard_cap * PG_POOL_SHARDS * sizeof(pg_run) +
+                pg_scan_tmp_bytes((uint32_t)n) + 4096;
+        if (need > ctx->arena.cap) {
+            if (ctx->arena.base) (void)hipFree(ctx->arena.base);
+            ctx->arena.base = nullptr;
+            ctx->arena.cap = 0;
+            const size_t want = need + need / 4;
+            hipError_t e = hipMalloc((void **)&ctx->arena.base, want);
+            if (e != hipSuccess) {
+                delete b;
+                return fail(ctx, PG_E_NOMEM, std::string("device arena: ") + hipGetErrorString(e));
+            }
+            ctx->arena.cap = want;
+        }
+        ctx->arena.used = 0;
+        b->in_arena = true;
+        for (const Item &it : items) *it.p = ctx->arena.take(it.bytes);
+        char *z0 = (char *)*items[first_zero].p;
+        char *z1 = (char *)*items[n_items - 1].p + items[n_items - 1].bytes;
+        hipError_t e = hipMemsetAsync(z0, 0, (size_t)(z1 - z0), ctx->stream);
+        if (e != hipSuccess) return drop(fail(ctx, PG_E_DEVICE, std::string("clearing the batch outputs: ") + hipGetErrorString(e)));
+    } else {
+        for (size_t k = 0; k < n_items; k++) {
+            hipError_t e = hipMalloc(items[k].p, items[k].bytes);
+            // the device-side CSR scan / gather trusts the counts: a failed memset must not go unnoticed
+            if (e == hipSuccess && k >= first_zero) e = hipMemset(*items[k].p, 0, items[k].bytes);
+            if (e != hipSuccess)
+                return drop(fail(ctx, e == hipErrorOutOfMemory ? PG_E_NOMEM : PG_E_DEVICE,
+                                 std::string("batch buffers: ") + hipGetErrorString(e)));
         }
     }
     if (copy && n) {
@@ -322,11 +468,7 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, std::vector<
         if (e == hipSuccess) e = hipMemcpy(b->pos, reads->anchor_pos, n * sizeof(int32_t), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(b->isz, reads->insert_size, n * sizeof(int16_t), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(b->chr, reads->chr_id, n * sizeof(int32_t), hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            free_batch_buffers(b);
-            delete b;
-            return fail(ctx, PG_E_DEVICE, std::string("input upload: ") + hipGetErrorString(e));
-        }
+        if (e != hipSuccess) return drop(fail(ctx, PG_E_DEVICE, std::string("input upload: ") + hipGetErrorString(e)));
     }
     *out = b;
     return PG_OK;
@@ -479,28 +621,30 @@ int run_search(pg_ctx *ctx, pg_device_batch *b, int mode)
         pg_run *npool = nullptr;
         rc = dev_alloc(ctx, &npool, (size_t)ncap * PG_POOL_SHARDS);
         if (rc) return rc;
-        (void)hipFree(b->pool);
+        if (!b->in_arena || b->pool_owned) (void)hipFree(b->pool);
         b->pool = npool;
+        b->pool_owned = true;
         b->pool_shard_cap = ncap;
     }
     return fail(ctx, PG_E_DEVICE, "run pool kept overflowing");
 }
 
 // Results to the host: the runs are gathered into read order on the device (prefix sums of the per-read
-// counts + one gather kernel per list), so only the compact CSR crosses PCIe.
+// counts + one gather kernel per list), so only the compact CSR crosses PCIe; the host buffers are pinned.
 int download(pg_ctx *ctx, pg_device_batch *b, pg_result *r)
 {
     const size_t n = b->n;
     r->n = b->n;
-    const bool has_close = b->modes_done & PG_MODE_CLOSE, has_far = b->modes_done & PG_MODE_FAR;
-    r->close_off.assign(n + 1, 0);
-    r->far_off.assign(n + 1, 0);
-    r->close_runs.clear();
-    r->far_runs.clear();
-    r->rc_flag.resize(n);
-    r->close_last.resize(n);
-    r->close_max.resize(n);
-    if (!n) return PG_OK;
+    const bool has[2] = { (b->modes_done & PG_MODE_CLOSE) != 0, (b->modes_done & PG_MODE_FAR) != 0 };
+    if (!r->close_off.resize(n + 1) || !r->far_off.resize(n + 1) || !r->rc_flag.resize(n) || !r->close_last.resize(n) ||
+        !r->close_max.resize(n) || !r->csr32[0].resize(n + 1) || !r->csr32[1].resize(n + 1))
+        return fail(ctx, PG_E_NOMEM, "pinned host memory for the result");
+    r->close_runs.resize(0);
+    r->far_runs.resize(0);
+    if (!n) {
+        r->close_off[0] = r->far_off[0] = 0;
+        return PG_OK;
+    }
     {
         int urc = unpack_results(ctx, b);
         if (urc) return urc;
@@ -508,12 +652,19 @@ int download(pg_ctx *ctx, pg_device_batch *b, pg_result *r)
     uint32_t *csr[2] = { nullptr, nullptr };
     pg_run *outp[2] = { nullptr, nullptr };
     void *tmp = nullptr;
-    auto cleanup = [&](int code) {
-        for (int k = 0; k < 2; k++) {
-            if (csr[k]) (void)hipFree(csr[k]);
-            if (outp[k]) (void)hipFree(outp[k]);
+    std::vector<void *> owned;                            // hipMalloc'd temporaries (none in the arena case)
+    auto dev_take = [&](size_t bytes) -> void * {
+        if (b->in_arena) {
+            void *p = ctx->arena.take(bytes);
+            if (p) return p;
         }
-        if (tmp) (void)hipFree(tmp);
+        void *p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(bytes, 16)) != hipSuccess) return nullptr;
+        owned.push_back(p);
+        return p;
+    };
+    auto cleanup = [&](int code) {
+        for (void *p : owned) (void)hipFree(p);
         return code;
     };
 #define TRY2(call)                                                                           \
@@ -523,37 +674,42 @@ int download(pg_ctx *ctx, pg_device_batch *b, pg_result *r)
             return cleanup(fail(ctx, e_ == hipErrorOutOfMemory ? PG_E_NOMEM : PG_E_DEVICE,   \
                                 std::string(#call) + ": " + hipGetErrorString(e_)));         \
     } while (0)
+    const size_t arena_mark = ctx->arena.used;
     const size_t tmp_bytes = pg_scan_tmp_bytes((uint32_t)n);
-    TRY2(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
+    if (!(tmp = dev_take(tmp_bytes))) return cleanup(fail(ctx, PG_E_NOMEM, "scan scratch"));
     const uint32_t *cnts[2] = { b->close_cnt, b->far_cnt }, *offs[2] = { b->close_off, b->far_off };
-    const bool has[2] = { has_close, has_far };
     uint32_t totals[2] = { 0, 0 };
     for (int k = 0; k < 2; k++) {
         if (!has[k]) continue;
-        TRY2(hipMalloc((void **)&csr[k], (n + 1) * sizeof(uint32_t)));
+        if (!(csr[k] = (uint32_t *)dev_take((n + 1) * sizeof(uint32_t)))) return cleanup(fail(ctx, PG_E_NOMEM, "CSR offsets"));
         TRY2((hipError_t)pg_compact_runs(nullptr, nullptr, cnts[k], csr[k], nullptr, (uint32_t)n, tmp, tmp_bytes, 0, ctx->stream));
-        TRY2(hipMemcpyAsync(&totals[k], csr[k] + n, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        TRY2(hipMemcpyAsync(r->csr32[k].data(), csr[k], (n + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     }
+    // the per-read summaries travel while the scans run
+    TRY2(hipMemcpyAsync(r->rc_flag.data(), b->rc_flag, n, hipMemcpyDeviceToHost, ctx->stream));
+    TRY2(hipMemcpyAsync(r->close_last.data(), b->close_last, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TRY2(hipMemcpyAsync(r->close_max.data(), b->close_max, n * 2, hipMemcpyDeviceToHost, ctx->stream));
     TRY2(hipStreamSynchronize(ctx->stream));
-    std::vector<uint32_t> h_csr(n + 1);
     for (int k = 0; k < 2; k++) {
-        if (!has[k]) continue;
-        std::vector<pg_run> &runs = k ? r->far_runs : r->close_runs;
-        std::vector<uint64_t> &off64 = k ? r->far_off : r->close_off;
-        runs.resize(totals[k]);
+        HostBuf<pg_run> &runs = k ? r->far_runs : r->close_runs;
+        HostBuf<uint64_t> &off64 = k ? r->far_off : r->close_off;
+        if (!has[k]) {
+            for (size_t i = 0; i <= n; i++) off64[i] = 0;
+            continue;
+        }
+        totals[k] = r->csr32[k][n];
+        if (!runs.resize(totals[k])) return cleanup(fail(ctx, PG_E_NOMEM, "pinned host memory for the runs"));
         if (totals[k]) {
-            TRY2(hipMalloc((void **)&outp[k], (size_t)totals[k] * sizeof(pg_run)));
+            if (!(outp[k] = (pg_run *)dev_take((size_t)totals[k] * sizeof(pg_run)))) return cleanup(fail(ctx, PG_E_NOMEM, "gathered runs"));
             TRY2((hipError_t)pg_compact_runs(b->pool, offs[k], cnts[k], csr[k], outp[k], (uint32_t)n, nullptr, 0, 1, ctx->stream));
             TRY2(hipMemcpyAsync(runs.data(), outp[k], (size_t)totals[k] * sizeof(pg_run), hipMemcpyDeviceToHost, ctx->stream));
         }
-        TRY2(hipMemcpyAsync(h_csr.data(), csr[k], (n + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        TRY2(hipStreamSynchronize(ctx->stream));
-        for (size_t i = 0; i <= n; i++) off64[i] = h_csr[i];
+        const uint32_t *c32 = r->csr32[k].data();
+        for (size_t i = 0; i <= n; i++) off64[i] = c32[i];       // widening while the runs are in flight
     }
-    TRY2(hipMemcpy(r->rc_flag.data(), b->rc_flag, n, hipMemcpyDeviceToHost));
-    TRY2(hipMemcpy(r->close_last.data(), b->close_last, n * 4, hipMemcpyDeviceToHost));
-    TRY2(hipMemcpy(r->close_max.data(), b->close_max, n * 2, hipMemcpyDeviceToHost));
+    TRY2(hipStreamSynchronize(ctx->stream));
 #undef TRY2
+    if (b->in_arena) ctx->arena.used = arena_mark;
     return cleanup(PG_OK);
 }
 
@@ -642,8 +798,10 @@ int pg_create(const pg_params *p, pg_ctx **out)
 
 void pg_destroy(pg_ctx *ctx)
 {
+    use_device(ctx);
     if (!ctx) return;
     free_reference(ctx);
+    if (ctx->arena.base) (void)hipFree(ctx->arena.base);
     if (ctx->d_thr) (void)hipFree(ctx->d_thr);
     if (ctx->d_mm) (void)hipFree(ctx->d_mm);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -665,6 +823,7 @@ int pg_get_max_mismatch(const pg_ctx *ctx, uint32_t *table500)
 int pg_load_reference(pg_ctx *ctx, int32_t n_chr, const char *const *names,
                       const uint8_t *const *seq_padded, const uint64_t *len_padded)
 {
+    use_device(ctx);
     if (!ctx || n_chr <= 0 || !seq_padded || !len_padded) return fail(ctx, PG_E_INVALID, "bad reference arguments");
     if (n_chr > 32767) return fail(ctx, PG_E_UNSUPPORTED, "more than 32767 chromosomes");
     free_reference(ctx);
@@ -754,6 +913,7 @@ int pg_reference_save_packed(const pg_ctx *ctx, const char *path)
 
 int pg_reference_load_packed(pg_ctx *ctx, const char *path)
 {
+    use_device(ctx);
     if (!ctx || !path) return fail(ctx, PG_E_INVALID, "bad packed-reference arguments");
     FILE *f = fopen(path, "rb");
     if (!f) return fail(ctx, PG_E_INVALID, std::string("cannot open ") + path);
@@ -881,6 +1041,7 @@ int pg_reference_fetch(const pg_ctx *ctx, int32_t c, uint64_t start, uint64_t n,
 // ---------------------------------------------------------------- device-resident
 int pg_device_batch_upload(pg_ctx *ctx, const pg_read_batch *reads, pg_device_batch **out)
 {
+    use_device(ctx);
     if (!ctx || !out) return PG_E_INVALID;
     *out = nullptr;
     return upload_batch(ctx, reads, out);
@@ -890,12 +1051,14 @@ static int attach_windows(pg_ctx *ctx, pg_device_batch *b, const pg_windows *bd_
 
 int pg_device_batch_set_windows(pg_ctx *ctx, pg_device_batch *b, const pg_windows *bd_hints)
 {
+    use_device(ctx);
     if (!ctx || !b) return PG_E_INVALID;
     return attach_windows(ctx, b, bd_hints);
 }
 
 int pg_device_batch_search(pg_ctx *ctx, pg_device_batch *b)
 {
+    use_device(ctx);
     if (!ctx || !b) return PG_E_INVALID;
     b->modes_done = 0;
     return run_search(ctx, b, PG_MODE_BOTH);
@@ -903,6 +1066,7 @@ int pg_device_batch_search(pg_ctx *ctx, pg_device_batch *b)
 
 int pg_device_batch_download(pg_ctx *ctx, pg_device_batch *b, pg_result **out)
 {
+    use_device(ctx);
     if (!ctx || !b || !out) return PG_E_INVALID;
     pg_result *r = new pg_result();
     int rc = download(ctx, b, r);
@@ -916,6 +1080,7 @@ int pg_device_batch_download(pg_ctx *ctx, pg_device_batch *b, pg_result **out)
 
 void pg_device_batch_free(pg_ctx *ctx, pg_device_batch *b)
 {
+    use_device(ctx);
     (void)ctx;
     if (!b) return;
     free_batch_buffers(b);
@@ -925,6 +1090,7 @@ void pg_device_batch_free(pg_ctx *ctx, pg_device_batch *b)
 // Diagnostics (not in the public header): raw per-read words of the alg-bytes array.
 int pg_debug_read_alg(pg_ctx *ctx, pg_device_batch *b, uint32_t *out, uint32_t n)
 {
+    use_device(ctx);
     if (!ctx || !b || !out || n > b->n) return PG_E_INVALID;
     {
         int urc = unpack_results(ctx, b);
@@ -945,6 +1111,7 @@ int pg_last_search_stats(const pg_ctx *ctx, double *kernel_ms, uint64_t *n_runs)
 // Diagnostics: candidates (survivors of the seed filter) the last search of this batch folded, in total.
 int pg_device_batch_candidates(pg_ctx *ctx, pg_device_batch *b, double *n_candidates)
 {
+    use_device(ctx);
     if (!ctx || !b || !n_candidates) return PG_E_INVALID;
     std::vector<PgOutRec> recs(b->n);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -957,6 +1124,7 @@ int pg_device_batch_candidates(pg_ctx *ctx, pg_device_batch *b, double *n_candid
 
 int pg_device_batch_algorithmic_bytes(pg_ctx *ctx, pg_device_batch *b, double *bytes)
 {
+    use_device(ctx);
     if (!ctx || !b || !bytes) return PG_E_INVALID;
     {
         int urc = unpack_results(ctx, b);
@@ -976,12 +1144,15 @@ int pg_device_batch_algorithmic_bytes(pg_ctx *ctx, pg_device_batch *b, double *b
 // results come back as device-built CSR.
 static int search_host(pg_ctx *ctx, const pg_read_batch *reads, int mode, pg_result **out)
 {
+    use_device(ctx);
     if (!ctx || !out) return PG_E_INVALID;
     *out = nullptr;
     pg_device_batch *b = nullptr;
     std::vector<uint64_t> off;
-    int rc = alloc_batch(ctx, reads, false, off, &b);
+    const double t_start = now_ms();
+    int rc = alloc_batch(ctx, reads, false, off, &b, true);
     if (rc) return rc;
+    const double t_alloc = now_ms();
     auto bail = [&](int code) {
         free_batch_buffers(b);
         delete b;
@@ -1046,8 +1217,12 @@ static int search_host(pg_ctx *ctx, const pg_read_batch *reads, int mode, pg_res
         b->modes_done |= mode;
     }
 #undef TRY3
+    const double t_search = now_ms();
     pg_result *r = new pg_result();
     rc = download(ctx, b, r);
+    if (g_host_timing)
+        fprintf(stderr, "pg_search_batch: %u reads: validate+alloc %.1f ms, copy+search %.1f ms, download %.1f ms\n",
+                b->n, t_alloc - t_start, t_search - t_alloc, now_ms() - t_search);
     if (rc) {
         delete r;
         return bail(rc);
@@ -1099,11 +1274,18 @@ static int attach_windows(pg_ctx *ctx, pg_device_batch *b, const pg_windows *bd_
 
 int pg_far_end_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_result *close, const pg_windows *bd_hints)
 {
+    use_device(ctx);
     if (!ctx || !reads || !close) return PG_E_INVALID;
     if (close->n != reads->n_reads) return fail(ctx, PG_E_INVALID, "close result does not belong to these reads");
     pg_device_batch *b = nullptr;
-    int rc = upload_batch(ctx, reads, &b);
+    std::vector<uint64_t> off0;
+    int rc = alloc_batch(ctx, reads, true, off0, &b, true);
     if (rc) return rc;
+    if ((rc = pack_reads(ctx, b, 0, b->n))) {
+        free_batch_buffers(b);
+        delete b;
+        return rc;
+    }
     const size_t n = b->n;
     auto bail = [&](int code) {
         free_batch_buffers(b);
@@ -1111,6 +1293,8 @@ int pg_far_end_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_result *close, 
         return code;
     };
     if (n) {
+        if (close->rc_flag.size() != n || close->close_last.size() != n || close->close_max.size() != n)
+            return bail(fail(ctx, PG_E_INVALID, "close result carries no close-end summary"));
         if (hipMemcpy(b->rc_flag, close->rc_flag.data(), n, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(b->close_last, close->close_last.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(b->close_max, close->close_max.data(), n * 2, hipMemcpyHostToDevice) != hipSuccess)

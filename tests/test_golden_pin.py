@@ -81,6 +81,60 @@ def test_command_line_reproduces_gold_reports(tmp_path):
 
 
 @pytest.mark.gpu
+def test_command_line_sharded_over_devices(tmp_path):
+    """`-G 0,0,0`: three contexts (here on the one visible GPU; on a node: `-G 0,1,...,7`), the reads of every
+    bin sharded over them in contiguous ranges by one host thread per context -- same reports as one device,
+    also with the reference's valueless switches on the command line and with BreakDancer hints."""
+    import filecmp
+    import os
+    import subprocess
+    from pindel_amd import binding
+    fa, reads_txt = gu.unpack(tmp_path)
+    exe = os.path.join(os.path.dirname(binding.LIB_PATH), "pindel_pg")
+    prefix = str(tmp_path / "multi")
+    out = subprocess.run([exe, "-f", fa, "-p", reads_txt, "-o", prefix, "-G", "0,0,0", "-k", "-s", "-l", "-T", "4"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "close end 14862, far end 10968" in out.stdout
+    gu.assert_reports_match_gold(prefix)
+    # flag errors are loud
+    bad = subprocess.run([exe, "-f", fa, "-p", reads_txt, "-o", prefix, "-x", "foo"], capture_output=True, text=True)
+    assert bad.returncode == 2 and "not a number" in bad.stderr
+    bad = subprocess.run([exe, "-f", fa, "-p", reads_txt, "-o", prefix, "-x"], capture_output=True, text=True)
+    assert bad.returncode == 2 and "lacking" in bad.stderr
+    bad = subprocess.run([exe, "-f", fa, "-p", reads_txt, "-o", prefix, "--no-such-flag", "1"], capture_output=True, text=True)
+    assert bad.returncode == 2 and "unknown argument" in bad.stderr
+
+
+@pytest.mark.gpu
+def test_two_contexts_over_two_shards_equal_the_whole_batch(engine_factory, tmp_path):
+    """What bench.py --scaling strong and `pindel_pg -G` rely on, through the C ABI: two contexts, each searching a
+    contiguous shard of ONE batch (ragged split), concatenated in order == the whole batch on one context."""
+    from pindel_amd import shard, synth
+    ref = [("chrS", synth.make_reference(1_200_000, seed=31))]
+    batch = synth.make_reads(ref[0][1], 20_001, seed=32)
+    a, b = engine_factory(), engine_factory()
+    a.load_reference(ref)
+    b.load_reference(ref)
+    whole = a.search_batch(batch)
+    cut = 7_123
+    parts = [shard.result_arrays(a.search_batch(batch.slice(0, cut))), shard.result_arrays(b.search_batch(batch.slice(cut, batch.n)))]
+    cat = shard.concat_results(parts)
+    w = shard.result_arrays(whole)
+    for k in ("close_off", "far_off", "rc_flag"):
+        assert np.array_equal(w[k], cat[k]), k
+    for k in ("close_runs", "far_runs"):
+        assert w[k].tobytes() == cat[k].tobytes(), k
+
+    class R:
+        pass
+    r = R()
+    for k, v in cat.items():
+        setattr(r, k, v)
+    assert shard.digest_hex(shard.read_digests(whole)) == shard.digest_hex(shard.read_digests(r))
+
+
+@pytest.mark.gpu
 def test_command_line_breakdancer_hints(tmp_path):
     """`-b file` alone changes nothing (what 0.2.5b9 does for Pindel-text input); with `--bd-hints on` the
     command line searches the events' windows before the ranges: same reports as the CPU oracle given the
