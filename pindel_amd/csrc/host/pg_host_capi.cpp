@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 
+#include "pg_bam.hpp"
 #include "pg_bdhints.hpp"
 #include "pg_host.hpp"
 #include "pg_host_priv.hpp"
@@ -116,6 +117,53 @@ int pgh_bd_query(const char *path, uint32_t spacer, int32_t n_chr, const char *c
     }
     return rc;
 }
+
+// BAM ingest (pg_bam.hpp): the split-read candidates of one window of one BAM file as the SoA batch of the C ABI.
+// Returns a handle (pgh_bam_ingest_free) or null (pgh_last_error).
+void *pgh_bam_ingest(const char *bam_path, const char *chr_name, int32_t chr_id, uint64_t chr_padded_size, int64_t win_start,
+                     int64_t win_end, int32_t insert_size, const char *tag, uint32_t min_anchor_quality, uint32_t spacer,
+                     int32_t use_index, uint64_t *n_reads, uint64_t *n_bases)
+{
+    pgh::BamFile bam;
+    if (!bam.open(bam_path, g_err, use_index != 0)) return nullptr;
+    pgh::BamIngestSettings st;
+    st.min_anchor_quality = min_anchor_quality;
+    st.spacer = spacer;
+    pgh::BamIngest ing(st);
+    pgh::IngestedReads *out = new pgh::IngestedReads();
+    out->clear();
+    if (!ing.read_window(bam, chr_name, chr_id, chr_padded_size, win_start, win_end, insert_size, tag ? tag : "", *out)) {
+        g_err = ing.error;
+        delete out;
+        return nullptr;
+    }
+    if (n_reads) *n_reads = out->size();
+    if (n_bases) *n_bases = out->batch.seq.size();
+    return out;
+}
+
+int pgh_bam_ingest_view(void *h, const uint8_t **seq, const uint64_t **off, const uint8_t **strand, const int32_t **pos,
+                        const int16_t **isz, const int32_t **chr, const int16_t **ms)
+{
+    if (!h) return -1;
+    pgh::IngestedReads *r = (pgh::IngestedReads *)h;
+    *seq = r->batch.seq.data();
+    *off = r->batch.off.data();
+    *strand = r->batch.strand.data();
+    *pos = r->batch.pos.data();
+    *isz = r->batch.isz.data();
+    *chr = r->batch.chr.data();
+    *ms = r->ms.data();
+    return 0;
+}
+
+const char *pgh_bam_ingest_name(void *h, uint64_t i)
+{
+    pgh::IngestedReads *r = (pgh::IngestedReads *)h;
+    return (r && i < r->names.size()) ? r->names[i].c_str() : nullptr;
+}
+
+void pgh_bam_ingest_free(void *h) { delete (pgh::IngestedReads *)h; }
 
 // Test hook (tests/test_cpu_suite.py): sorts indices 0..n-1 by keys[] with the reference's O(n^2)
 // exchange sort and with its fast equivalent; the two outputs must be identical.

@@ -10,6 +10,7 @@
 #include <utility>
 #include <vector>
 
+#include "pg_bam.hpp"
 #include "pg_host.hpp"
 
 namespace pgh {
@@ -89,6 +90,77 @@ int run_pipeline(const std::vector<Chromosome> &genome, const std::vector<unsign
                 if (!r.UP_Close.empty()) {
                     caller.note_close_mapped(r);
                     kept.push_back(std::move(r));      // `reads` is not used after this loop
+                }
+            if (!kept.empty()) caller.process_window(chrom, kept, ws, we, bed_start, bed_end);
+        }
+    }
+    return 0;
+}
+
+// BAM input (`-i config`): main()'s loop with get_SR_Reads per window (src/pindel.cpp:1816-1982,
+// src/reader.cpp:1427-1470).  Windows run from 0 in steps of the bin size while the start does not pass the
+// end of the chromosome (LoopingSearchWindow::finished without the Pindel-text shortcut); every window reads
+// its candidates from every BAM of the configuration through pg_bam.hpp, so only one window's reads are in
+// memory at a time (a coordinate-sorted BAM delivers them bin by bin).
+struct BamSource {
+    std::string path, tag;
+    int insert_size = 0;
+};
+
+template <class Search>
+int run_bam_pipeline(const std::vector<Chromosome> &genome, const std::vector<unsigned> &fai,
+                     const std::vector<BamSource> &bams, const BamIngestSettings &ingest, const Settings &S,
+                     const std::string &prefix, Search search, std::string &err, size_t *n_reads_total = nullptr)
+{
+    Caller caller(S, &genome, prefix, true);
+    const unsigned WINDOW = (unsigned)(S.window_mbp * 1000000);
+    std::vector<BamFile> files(bams.size());
+    for (size_t k = 0; k < bams.size(); k++)
+        if (!files[k].open(bams[k].path, err)) return -1;
+    for (size_t c = 0; c < genome.size(); c++) {
+        const Chromosome &chrom = genome[c];
+        const unsigned biol = (unsigned)(chrom.seq.size() - 2 * S.spacer);
+        const unsigned bed_start = 1, bed_end = fai[c] ? fai[c] : biol;
+        const unsigned global_end = std::min(biol, bed_end + 10000u);
+        for (unsigned ws = 0; !(ws > global_end); ws += WINDOW) {
+            const unsigned we = std::min(ws + WINDOW, global_end);
+            IngestedReads in;
+            in.clear();
+            BamIngest ing(ingest);
+            for (size_t k = 0; k < bams.size(); k++)
+                if (!ing.read_window(files[k], chrom.name, (int)c, chrom.seq.size(), ws, we, bams[k].insert_size, bams[k].tag, in)) {
+                    err = bams[k].path + ": " + ing.error;
+                    return -1;
+                }
+            if (n_reads_total) *n_reads_total += in.size();
+            if (in.size() == 0) continue;
+            std::vector<SplitRead> reads(in.size());
+            std::vector<uint32_t> index(in.size());
+            for (size_t i = 0; i < in.size(); i++) {
+                SplitRead &r = reads[i];
+                r.Name = in.names[i];
+                r.UnmatchedSeq.assign((const char *)in.batch.seq.data() + in.batch.off[i], (size_t)(in.batch.off[i + 1] - in.batch.off[i]));
+                r.ReadLength = (short)r.UnmatchedSeq.size();
+                r.MatchedD = (char)in.batch.strand[i];
+                r.MatchedRelPos = (unsigned)in.batch.pos[i];
+                r.MS = in.ms[i];
+                r.InsertSize = in.batch.isz[i];
+                r.Tag = in.tags[i];
+                r.FragName = chrom.name;
+                r.chr_id = (int)c;
+                r.MAX_SNP_ERROR = (short)S.max_mismatch[std::min<int>(r.ReadLength, 499)];
+                index[i] = (uint32_t)i;
+            }
+            int rc = search(chrom, (int)c, reads, index);
+            if (rc) {
+                err = "search step failed";
+                return rc;
+            }
+            std::vector<SplitRead> kept;
+            for (SplitRead &r : reads)
+                if (!r.UP_Close.empty()) {
+                    caller.note_close_mapped(r);
+                    kept.push_back(std::move(r));
                 }
             if (!kept.empty()) caller.process_window(chrom, kept, ws, we, bed_start, bed_end);
         }

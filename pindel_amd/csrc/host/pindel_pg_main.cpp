@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <fstream>
 #include <algorithm>
 #include <iterator>
 #include <string>
@@ -32,7 +33,8 @@ int main(int argc, char **argv)
 {
     const double t_start = now_s();
     double t_search = 0.0;
-    std::string fasta, reads_path, prefix, bd_path;
+    std::string fasta, reads_path, prefix, bd_path, bam_config;
+    unsigned min_anchor_quality = 0;
     bool use_bd = false;
     pg_params prm;
     pg_default_params(&prm);
@@ -43,7 +45,7 @@ int main(int argc, char **argv)
     // accepts them; anything else is an error, and so is a value that is not a number.
     struct Flag { const char *sh, *lg; char kind; };      // kind: i int, f float, s string, u unary
     static const Flag flags[] = {
-        { "-f", "--fasta", 's' }, { "-p", "--pindel-file", 's' }, { "-o", "--output-prefix", 's' },
+        { "-f", "--fasta", 's' }, { "-p", "--pindel-file", 's' }, { "-i", "--config-file", 's' }, { "-o", "--output-prefix", 's' },
         { "-x", "--max_range_index", 'i' }, { "-a", "--additional_mismatch", 'i' },
         { "-m", "--min_perfect_match_around_BP", 'i' }, { "-u", "--maximum_allowed_mismatch_rate", 'f' },
         { "-e", "--sequencing_error_rate", 'f' }, { "-E", "--sensitivity", 'f' }, { "-H", "--min_close", 'i' },
@@ -103,6 +105,8 @@ int main(int argc, char **argv)
         }
         if (key == "-f") fasta = v;
         else if (key == "-p") reads_path = v;
+        else if (key == "-i") bam_config = v;
+        else if (key == "-A") min_anchor_quality = (unsigned)iv;
         else if (key == "-o") prefix = v;
         else if (key == "-x") prm.max_range_index = (int)iv;
         else if (key == "-a") prm.additional_mismatch = (int)iv;
@@ -149,8 +153,8 @@ int main(int argc, char **argv)
             return 2;
         }
     }
-    if (fasta.empty() || reads_path.empty() || prefix.empty()) {
-        fprintf(stderr, "usage: pindel_pg -f ref.fa -p reads.txt -o prefix [options]\n");
+    if (fasta.empty() || (reads_path.empty() == bam_config.empty()) || prefix.empty()) {
+        fprintf(stderr, "usage: pindel_pg -f ref.fa (-p reads.txt | -i bam_config.txt) -o prefix [options]\n");
         return 2;
     }
     std::string err;
@@ -160,9 +164,30 @@ int main(int argc, char **argv)
         return 1;
     }
     std::vector<SplitRead> all;
-    if (load_pindel_text(reads_path, genome, all, err)) {
+    if (!reads_path.empty() && load_pindel_text(reads_path, genome, all, err)) {
         fprintf(stderr, "pindel_pg: %s\n", err.c_str());
         return 1;
+    }
+    // -i: one line per BAM: file, insert size, sample tag (readBamConfigFile, src/pindel.cpp)
+    std::vector<BamSource> bams;
+    if (!bam_config.empty()) {
+        std::ifstream cf(bam_config.c_str());
+        if (!cf) {
+            fprintf(stderr, "pindel_pg: cannot open %s\n", bam_config.c_str());
+            return 1;
+        }
+        BamSource b;
+        while (cf >> b.path >> b.insert_size >> b.tag) {
+            if (b.path[0] != '/') {                       // relative to the configuration file
+                const size_t sl = bam_config.rfind('/');
+                if (sl != std::string::npos) b.path = bam_config.substr(0, sl + 1) + b.path;
+            }
+            bams.push_back(b);
+        }
+        if (bams.empty()) {
+            fprintf(stderr, "pindel_pg: no BAM files in %s\n", bam_config.c_str());
+            return 1;
+        }
     }
     std::vector<pg_ctx *> ctxs;
     int rc = 0;
@@ -292,10 +317,17 @@ int main(int argc, char **argv)
         t_search += now_s() - t0;
         return r;
     };
-    rc = run_pipeline(genome, fai, all, S, prefix, search, err);
+    size_t n_bam_reads = 0;
+    if (!bams.empty()) {
+        BamIngestSettings ing;
+        ing.min_anchor_quality = min_anchor_quality;
+        ing.spacer = prm.spacer;
+        rc = run_bam_pipeline(genome, fai, bams, ing, S, prefix, search, err, &n_bam_reads);
+    } else
+        rc = run_pipeline(genome, fai, all, S, prefix, search, err);
     if (rc) fprintf(stderr, "pindel_pg: %s (%s)\n", err.c_str(), pg_last_error(ctx));
     else {
-        printf("pindel_pg: %zu reads, close end %zu, far end %zu\n", all.size(), n_close, n_far);
+        printf("pindel_pg: %zu reads, close end %zu, far end %zu\n", bams.empty() ? all.size() : n_bam_reads, n_close, n_far);
         // the phases the reference's Timer reports (pindel.cpp:1990-1996), wall-clock seconds
         printf("pindel_pg: loading %.2f s, split-read search (GPU, incl. adapters) %.2f s, classification + reports %.2f s\n",
                t_loaded - t_start, t_search, now_s() - t_loaded - t_search);
