@@ -191,7 +191,7 @@ struct Search {
     int win_lo, win_hi, wbase;
     int nsurv;           // candidates folded since the state was reset
     int nsurv_total;     // ... since the read started (diagnostics: survivors of the seed filter)
-    bool tierA;          // bps + 16 <= 32: the short-lived tier is usable
+    bool tierA;          // the short-lived tier is usable: bps + 16 <= 32 and CheckMismatches' "L > m" test cannot fail
     bool len_check;      // Min_Perfect_Match_Around_BP >= bps: the "L > m" test of CheckMismatches can fail
 };
 
@@ -246,20 +246,21 @@ __device__ __forceinline__ int max_mismatch_at(const u32 *mm_bp, int L)
 }
 
 // ---------------------------------------------------------------------------------
-// mismatch / strict-inequality words of one 64-base block
+// Mismatch word of one 64-base block, and the read's N word.  Matches(): read N matches any ACGT; reference N
+// matches nothing (searcher.cpp:36-44).  The exact character inequality CheckMismatches' perfect-match window
+// needs (BP_On_Read != BP_On_Ref, searcher.cpp:349-364) differs from it exactly where the read has an N
+// (N vs ACGT: match but unequal; N vs N: mismatch but equal): sne = mis ^ qnn.
 template <int NB>
 __device__ __forceinline__ void block_masks(const Query<NB> &Q, int b, bool comp,
-                                            u64 rlo, u64 rhi, u64 rnn, u64 &mis, u64 &sne)
+                                            u64 rlo, u64 rhi, u64 rnn, u64 &mis, u64 &qn)
 {
     const u64 qlo = q_lo<NB>(Q, b), qhi = q_hi<NB>(Q, b), qnn = q_nn<NB>(Q, b), qoo = q_oo<NB>(Q, b);
     u64 cm = comp ? ~0ull : 0ull;
     u64 x = rlo ^ qlo ^ cm;
     u64 y = rhi ^ qhi ^ cm;
     u64 d = x | y;
-    // Matches(): read N matches any ACGT; reference N matches nothing (searcher.cpp:36-44)
     mis = (d & ~qnn) | rnn | qoo;
-    // exact character inequality (BP_On_Read != BP_On_Ref, searcher.cpp:349-364)
-    sne = (d & ~(rnn | qnn)) | (rnn ^ qnn) | qoo;
+    qn = qnn;
 }
 
 // 64 reference bits of each plane starting at AbsLoc q, from the LDS window.
@@ -319,7 +320,7 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
             block_masks<NB>(Q, b, comp, rlo, rhi, rnn, m, s);
             const u64 lm = low_bits(S.len - 64 * b);
             m &= lm;
-            s &= lm;
+            s = (m ^ s) & lm;                             // exact inequality (the read's N bits flipped)
             S.bufB[lane * EW + 1 + b] = make_uint4((u32)m, (u32)(m >> 32), (u32)s, (u32)(s >> 32));
             cum += __popcll(m);
             if (b == 0) {
@@ -367,8 +368,7 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
             const uint4 e = S.bufA[idx];                               // bufA has 4 spare entries
             u32 k = (u32)__popc(e.x & mk);
             k = idx < nA ? k : PG_BIG;
-            u32 okc = (e.y & bpm) == 0u ? (e.w >> 31) : 0u;
-            if (S.len_check) okc = (u32)L >= ((e.w >> 8) & 0x7fu) ? okc : 0u;
+            const u32 okc = (e.y & bpm) == 0u ? (e.w >> 31) : 0u;    // (no "L > m" test: tier A is off when it can fail)
             const Id cid = sizeof(Id) == 8 ? (Id)((u64)e.z | ((u64)(e.w & 0xffu) << 32)) : (Id)e.z;
             fold<Id>(A.a1, A.a2, A.aid, A.aok, k, cid, okc);
         }
@@ -414,7 +414,7 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
                 if (b + 1 >= r) bad |= sn & BP[b];        // L - m >= 64 r - 64 (m <= 64 <= 64 + bps)
             }
             u32 okc = bad == 0ull ? (h.y >> 31) : 0u;
-            if (S.len_check) okc = (u32)L >= ((h.y >> 8) & 0x7fu) ? okc : 0u;
+            if (S.len_check) okc = (u32)L >= ((h.y >> 8) & 0x7fu) ? okc : 0u;   // uniform branch
             const Id cid = sizeof(Id) == 8 ? (Id)((u64)h.x | ((u64)(h.y & 0xffu) << 32)) : (Id)h.x;
             fold<Id>(m1, m2, wid, ok, k, cid, okc);
         }
@@ -518,6 +518,9 @@ __device__ __forceinline__ u32 seed_filter(const Search &S, const Query<NB> &Q,
     const u32 seed = ~((sx ^ ((lo & 1u) ? ~0u : 0u)) | (sy ^ ((hi & 1u) ? ~0u : 0u)) | sz);
     u32 c0 = 0u, c1 = 0u, c2 = 0u, c3 = 0u, ov = 0u;        // mismatch count per position, bit sliced
     u32 snap = 0u;
+    // kind F: base j is a funnel shift by j.  Kind B: by 32 - j; its base masks are bit-reversed below, so that
+    // base j sits at bit 31 - j and the shift is (31 - j) + 1: one scalar add per base either way
+    const int shift0 = kindB ? 1 : 0;
     if (T <= 8) {
         // counts up to 7 decide everything (cap0 <= T - 1 <= 7): three slices + overflow, 7 VALU per base
 #pragma unroll
@@ -525,10 +528,11 @@ __device__ __forceinline__ u32 seed_filter(const Search &S, const Query<NB> &Q,
             const int X = it >= 6 ? it - 6 : it;
             if (it == 6) snap = count_le(c0, c1, c2, 0u, ov, cap0);
             u32 pm = sym[X] & (it >= 6 ? (jmask & ~g0mask) : g0mask);
+            if (kindB) pm = __brev(pm);
             while (pm != 0u) {
                 const int j = __ffs((int)pm) - 1;
                 pm &= pm - 1u;
-                const u32 m = __builtin_amdgcn_alignbit(wh[X], wl[X], (u32)(kindB ? 32 - j : j));
+                const u32 m = __builtin_amdgcn_alignbit(wh[X], wl[X], (u32)(j + shift0));
                 u32 k0, k1;
                 asm("v_bfi_b32 %4, %6, 0, %0\n\t"          // k0 = ~m & c0
                     "v_xnor_b32 %0, %0, %6\n\t"            // c0 ^= ~m
@@ -547,10 +551,11 @@ __device__ __forceinline__ u32 seed_filter(const Search &S, const Query<NB> &Q,
         const int X = it >= 6 ? it - 6 : it;
         if (it == 6) snap = count_le(c0, c1, c2, c3, ov, cap0);
         u32 pm = sym[X] & (it >= 6 ? (jmask & ~g0mask) : g0mask);
+        if (kindB) pm = __brev(pm);
         while (pm != 0u) {
             const int j = __ffs((int)pm) - 1;
             pm &= pm - 1u;
-            const u32 m = __builtin_amdgcn_alignbit(wh[X], wl[X], (u32)(kindB ? 32 - j : j));
+            const u32 m = __builtin_amdgcn_alignbit(wh[X], wl[X], (u32)(j + shift0));
             // count += mismatch (= ~m), in place: 8 VALU instructions.  Written as asm because the
             // compiler's version of the same ripple rotates the counter through three extra v_mov.
             u32 k0, k1;
@@ -930,9 +935,18 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
         int close_bases = 0;
         if (len - 1 >= prm.min_close && (strand == '+' || strand == '-')) {
             S.bps = prm.min_close;
-            S.tierA = S.bps + 16 <= 32;
-            S.len_check = prm.min_perfect >= S.bps;
+            S.len_check = prm.min_perfect >= S.bps;        // Min_Perfect_Match_Around_BP >= the first evaluated length
+            S.tierA = S.bps + 16 <= 32 && !S.len_check;
             const u32 mm0 = mm_of(S, S.bps + lane);
+            // Attempt 0 (the one that succeeds for most reads) stages and filters exactly its own window.  The
+            // retries share work: the window of the attempts with R = 1 contains the one with R = 0, so from
+            // attempt 1 on the chunk grid is anchored at the R = 1 window, which is staged once; attempts 1 and 2
+            // use the same orientation of the read, so the seed-filter masks of the first chunk are computed
+            // once for both and attempt 2 only adds the flanks to attempt 1's state (the reduction is additive).
+            const int w1s = strand == '+' ? apos - isz : apos - 2 * isz, w1e = w1s + 3 * isz;
+            u32 cr0 = 0u, cr1 = 0u;                       // cached masks of the reverse-complemented read
+            bool vr = false;
+            int ps = 0, pe = 0, nsurv_eval = 0;
             for (int att = 0; att < 4; att++) {
                 const int Rg = att >> 1;
                 flipped = (att == 1 || att == 2) ? 1 : 0;
@@ -954,14 +968,22 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                 Q.antisenseB = false;     // CheckRight_Close: BACKWARD, SENSE
                 Q.first_ok = first_base_ok<NB>(Q);
                 close_bases = e1 > s1 ? e1 - s1 : 0;
-                A.reset();
-                S.nsurv = 0;
-                scan_range<NB, Id>(ref, S, Q, A, chr_wo, s1, s1, e1, e1, 0, 0, s1, 0u, opaque(lane), false,
-                                   unused0, unused1, unused_valid);
+                if (att != 2) {           // attempt 2 continues attempt 1's reduction
+                    A.reset();
+                    S.nsurv = 0;
+                    nsurv_eval = 0;
+                    ps = pe = 0;
+                }
+                // one call site: attempt 0 on its own grid, the retries on the grid of the R = 1 window
+                scan_range<NB, Id>(ref, S, Q, A, chr_wo, att == 0 ? s1 : w1s, s1, e1, att == 0 ? e1 : w1e, ps, pe, w1s, 0u,
+                                   opaque(lane), att == 1 || att == 2, cr0, cr1, vr);
+                ps = s1;
+                pe = e1;
 #if defined(PG_STOP) && PG_STOP == 2
                 if (A.m1 != 0x54321u) return;         // diagnostics: first attempt up to the end of its scan
 #endif
-                if (S.nsurv > 0) {
+                if (S.nsurv != nsurv_eval) {
+                    nsurv_eval = S.nsurv;
                     Eval<NB, Id> E;
                     evaluate<NB, Id>(S, A, mm0, E, opaque(lane));
                     close_max = uni(E.max_len);
@@ -969,10 +991,10 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                         u64 kept[NB];
                         n_close = uni(count_kept<NB, Id>(E, true, kept));
                         close_base = pool_alloc(B, n_close, lane, fits);
-                        if (fits) emit_runs<NB, Id>(S, true, false, chr, s1, nullptr, E, kept, B.pool + close_base, opaque(lane));
+                        if (fits) emit_runs<NB, Id>(S, true, false, chr, w1s, nullptr, E, kept, B.pool + close_base, opaque(lane));
                         // AbsLoc of the last point (getLastAbsLocCloseEnd)
                         const u64 idl = (u64)E.id_last;
-                        const int pl = s1 + (int)(u32)(idl & ((1ull << IdFmt<Id>::RB) - 1ull));
+                        const int pl = w1s + (int)(u32)(idl & ((1ull << IdFmt<Id>::RB) - 1ull));
                         close_last = ((idl >> IdFmt<Id>::RB) & 1ull) ? (u32)(pl - close_max + 1) : (u32)(pl + close_max - 1);
                         break;
                     }
@@ -1004,8 +1026,8 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     // "if (CurrentBase == 'N' || MaxLenCloseEnd() == 0) return;" (farend_searcher.cpp:60-66)
     if (do_far && close_max > 0 && len - 1 >= 10) {
         S.bps = 10;               // farend_searcher.cpp:90
-        S.tierA = true;
         S.len_check = prm.min_perfect >= 10;
+        S.tierA = !S.len_check;
         // cur = flipped ? RC(orig) : orig.  Plus strand consumes cur left to right, Minus strand
         // consumes complement(cur) walking the reference right to left.
         Query<NB> Q;
