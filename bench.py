@@ -136,7 +136,47 @@ def build_workload(args, rank, world, dev):
     bd = bd_off = None
     strong = args.scaling == "strong"
     read_seed = args.seed + 1 + (0 if strong else rank)
-    if args.workload == "grch38-150":
+    if args.workload == "wgs-bins":
+        # BASELINE configs[4]-shaped.  30x WGS: ~400 M one-end-anchored reads over 3.1 Gbp = 0.65 M per 5-Mbp bin; Pindel
+        # works bin by bin (src/pindel.cpp:1816-1982).  One rank's share here: --reads reads (default 13 M = 20 bins'
+        # worth) on the first chromosomes of the GRCh38-shaped reference, in coordinate order.
+        if args.read_len == 100:
+            args.read_len = 150
+        if args.reads == 10_000_000:
+            args.reads = 13_000_000
+        n_bins = max(1, int(round(args.reads / 650_000)))
+        lens = [max(400_000, int(L * args.genome_scale)) for L in synth.GRCH38_LENGTHS]
+        chroms = synth.make_genome(lens, synth.GRCH38_NAMES, seed=args.seed, device=dev)
+        # the reads of n_bins consecutive bins: the first n_bins x 5 Mbp of the genome, chromosome by chromosome
+        parts, left = [], n_bins * 5_000_000
+        for c, (_, s) in enumerate(chroms):
+            if left <= 0:
+                break
+            span = min(left, len(s) - 2 * synth.SPACER)
+            n_c = int(round(args.reads * span / (n_bins * 5_000_000)))
+            if n_c > 0 and span > 100_000:
+                parts.append(synth.make_reads(s[:span + 2 * synth.SPACER], n_c, seed=read_seed + 7 * c, chr_id=c, device=dev,
+                                              read_len=args.read_len))
+            left -= span
+        import numpy as _np
+        off = _np.concatenate([[0]] + [p_.seq_off[1:].astype(_np.uint64) + _np.uint64(b_) for p_, b_ in
+                                        zip(parts, _np.cumsum([0] + [len(p_.seq) for p_ in parts[:-1]]))]).astype(_np.uint64)
+        batch = type(parts[0])(seq=_np.concatenate([p_.seq for p_ in parts]), seq_off=off,
+                               anchor_strand=_np.concatenate([p_.anchor_strand for p_ in parts]),
+                               anchor_pos=_np.concatenate([p_.anchor_pos for p_ in parts]),
+                               insert_size=_np.concatenate([p_.insert_size for p_ in parts]),
+                               chr_id=_np.concatenate([p_.chr_id for p_ in parts]))
+        args.reads = batch.n
+        # coordinate order inside every chromosome (a sorted BAM)
+        order = np.lexsort((batch.anchor_pos, batch.chr_id))
+        L = args.read_len
+        batch = type(batch)(seq=batch.seq.reshape(batch.n, L)[order].reshape(-1), seq_off=batch.seq_off,
+                            anchor_strand=batch.anchor_strand[order], anchor_pos=batch.anchor_pos[order],
+                            insert_size=batch.insert_size[order], chr_id=batch.chr_id[order])
+        desc = (f"BASELINE configs[4]-shaped: {args.reads} x {args.read_len} bp reads per GPU in coordinate order on "
+                f"the first {n_bins} bins of the GRCh38-shaped reference (24 chromosomes, {sum(lens)} bp), searched 5-Mbp bin by bin "
+                f"(one launch per bin), all SV types")
+    elif args.workload == "grch38-150":
         # BASELINE configs[3]-shaped: 24 chromosomes, 3.1 Gbp, 150-bp reads; one rank's share of 100 M reads
         if args.read_len == 100:
             args.read_len = 150
@@ -200,10 +240,12 @@ def main():
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive pg_search_batch sample")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--genome-scale", type=float, default=1.0, help="grch38-150: scale every chromosome (tests)")
-    ap.add_argument("--workload", choices=["sv10m", "colo-bd", "grch38-150", "repeat-rich"], default="sv10m",
+    ap.add_argument("--workload", choices=["sv10m", "colo-bd", "grch38-150", "repeat-rich", "wgs-bins"], default="sv10m",
                     help="sv10m = BASELINE configs[2] (default); colo-bd = configs[1]-shaped; grch38-150 = configs[3]-shaped "
                          "(one rank's 12.5 M x 150 bp on a 3.1 Gbp 24-chromosome reference); repeat-rich = configs[2] on a "
-                         "reference that is 45 % diverged repeat copies")
+                         "reference that is 45 % diverged repeat copies; wgs-bins = configs[4]-shaped: 150-bp reads in "
+                         "coordinate order on the GRCh38-shaped reference, searched 5-Mbp bin by bin (one launch per bin, "
+                         "0.65 M reads per bin = 30x WGS with 400 M one-end-anchored reads), as main()'s loop does")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -238,9 +280,25 @@ def main():
     chroms, batch, bd, bd_off, desc, total_reads = build_workload(args, rank, world, dev)
     eng = binding.Engine(device=local_dev, **params_kw)
     eng.load_reference(chroms)
+    bins = None
+    if args.workload == "wgs-bins":
+        import numpy as np
+        key = batch.chr_id.astype(np.int64) * 100_000 + batch.anchor_pos // 5_000_000
+        cuts = np.concatenate([[0], np.nonzero(np.diff(key))[0] + 1, [batch.n]])
+        bins = [eng.upload(batch.slice(int(a), int(b))) for a, b in zip(cuts[:-1], cuts[1:])]
     dbatch = eng.upload(batch)           # inputs resident in HBM before the timed region
     if bd is not None:
         eng.set_windows(dbatch, bd, bd_off)
+
+    def one_step():
+        if bins is None:
+            eng.search_device(dbatch)    # synchronous: returns when the kernel finished
+            return eng.last_stats()[0]
+        ms = 0.0
+        for h in bins:                   # one launch per 5-Mbp bin
+            eng.search_device(h)
+            ms += eng.last_stats()[0]
+        return ms
 
     def barrier():
         torch.cuda.synchronize()
@@ -249,13 +307,12 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        eng.search_device(dbatch)
+        one_step()
     barrier()
     t0 = time.perf_counter()
     kernel_ms = []
     for _ in range(args.steps):
-        eng.search_device(dbatch)        # synchronous: returns when the kernel finished
-        kernel_ms.append(eng.last_stats()[0])
+        kernel_ms.append(one_step())
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -264,6 +321,8 @@ def main():
         elapsed = float(t.item())
 
     # ---- outside the timed region: accounting, result digests, the host-buffer seam, the CPU baseline
+    if bins is not None:
+        eng.search_device(dbatch)                 # the whole batch once, for the accounting below (same reads)
     alg_bytes = eng.algorithmic_bytes(dbatch)     # per launch
     n_runs = eng.last_stats()[1]
     n_cand = eng.candidates(dbatch)
@@ -310,6 +369,7 @@ def main():
                 "workload": desc + f", Pindel defaults -x {args.max_range_index} -a 1 -m 3 -u 0.02 -e 0.01 -E 0.95 -H 8",
                 "reads_per_gpu": batch.n, "reads_total": units, "read_len": args.read_len, "insert_size": 500,
                 "parallelism": f"reads sharded over {world} GPU(s) ({args.scaling} scaling), reference replicated, no collective",
+                "launches_per_step": 1 if bins is None else len(bins),
                 "reads_with_close_end": n_close, "reads_with_far_end": n_far, "runs_out": int(n_runs),
                 "candidates_per_read": n_cand / max(batch.n, 1),    # seed-filter survivors that went through the full comparison
                 "result_sha256": shard.digest_hex(digests),
@@ -327,6 +387,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(chroms, batch, params_kw, bd=bd, bd_off=bd_off)
         print(json.dumps(out), flush=True)
+    for h in bins or []:
+        eng.free_device_batch(h)
     eng.free_device_batch(dbatch)
     eng.close()
     if dist is not None:

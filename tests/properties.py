@@ -106,7 +106,7 @@ def check_workload(eng, chroms, batch, params_kw=None, bd=None, bd_off=None, n_s
     n = batch.n
     whole, again = search_device(eng, batch, bd, bd_off, twice=True)
     assert_same(whole, again, "second search of the same device batch")
-    cuts = [0] + [int(n * c) for c in shard_cuts] + [n]
+    cuts = [0] + [int(round(n * c)) for c in shard_cuts] + [n]
     parts = []
     for lo, hi in zip(cuts[:-1], cuts[1:]):
         w, wo = slice_windows(bd, bd_off, lo, hi)

@@ -12,6 +12,7 @@
               is synthetic, the event coordinates are the real ones.
   configs[3]  GRCh38-shaped reference (24 chromosomes, 3.1 Gbp; pg_load_reference + packed cache) and one rank's
               shard of the 100 M x 150 bp reads (12.5 M) through the properties + sampled oracle parity.
+  configs[4]  30x-WGS-shaped: coordinate-ordered 150-bp reads, 0.65 M per 5-Mbp bin, bin by bin on the same reference.
 """
 import ctypes as C
 import gzip
@@ -215,4 +216,24 @@ def test_config3_grch38_shaped_shard(engine_factory, tmp_path):
         assert eng2.reference_fetch(c, probe, 500) == chroms[c][1][probe:probe + 500]
     eng.close()
     n_close, n_far = check_workload(eng2, chroms, batch, n_sample=20_000)
+    assert n_close > 0.7 * batch.n and n_far > 0.5 * batch.n
+
+
+# ------------------------------------------------------------------------------------------ configs[4]
+def test_config4_wgs_bins(engine_factory):
+    """30x-WGS-shaped: 150-bp reads in coordinate order, 0.65 M per 5-Mbp bin, searched bin by bin on the full
+    GRCh38-shaped reference (4 bins here; bench.py --workload wgs-bins runs 20).  Bin-by-bin results concatenated ==
+    the whole batch (the shard cuts of the property check are the bin boundaries), sampled oracle parity."""
+    import torch
+    import bench
+    args = _bench_args(workload="wgs-bins", reads=2_600_000)
+    chroms, batch, bd, bd_off, desc, total = bench.build_workload(args, 0, 1, torch.device("cuda", 0))
+    assert "configs[4]" in desc and len(chroms) == 24 and abs(batch.n - 2_600_000) < 10
+    key = batch.chr_id.astype(np.int64) * 100_000 + batch.anchor_pos // 5_000_000
+    assert np.all(np.diff(key) >= 0)
+    cuts = (np.nonzero(np.diff(key))[0] + 1) / batch.n
+    assert len(cuts) == 3
+    eng = engine_factory()
+    eng.load_reference(chroms)
+    n_close, n_far = check_workload(eng, chroms, batch, n_sample=10_000, shard_cuts=tuple(float(c) for c in cuts))
     assert n_close > 0.7 * batch.n and n_far > 0.5 * batch.n
