@@ -69,8 +69,25 @@ public:
             events_.push_back(b);
         }
         std::sort(events_.begin(), events_.end(), first_less);
+        external_ = events_;
         return 0;
     }
+
+    // BDData::UpdateBD (src/bddata.cpp:646-649, 809): the events of this window = the external ones (-b file) + the
+    // read-pair events of the window (pg_rp.hpp), both directions, sorted on the first coordinate
+    struct RpSide { std::string chr; unsigned pos, pos2; };
+    void update_with_rp(const std::vector<std::pair<RpSide, RpSide>> &rp)
+    {
+        events_ = external_;
+        for (const auto &e : rp) {
+            Event a = { { e.first.chr, e.first.pos, e.first.pos2 }, { e.second.chr, e.second.pos, e.second.pos2 } };
+            Event b = { { e.second.chr, e.second.pos, e.second.pos2 }, { e.first.chr, e.first.pos, e.first.pos2 } };
+            events_.push_back(a);
+            events_.push_back(b);
+        }
+        std::sort(events_.begin(), events_.end(), first_less);
+    }
+    size_t n_events_total() const { return events_.size() / 2; }
 
     size_t n_events() const { return events_.size() / 2; }
 
@@ -251,7 +268,7 @@ private:
         return true;
     }
 
-    std::vector<Event> events_;
+    std::vector<Event> events_, external_;
     std::vector<unsigned> mask_;
     std::vector<std::vector<BDWindow>> clusters_;
     std::vector<BDWindow> empty_;

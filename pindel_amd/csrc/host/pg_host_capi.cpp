@@ -12,6 +12,7 @@
 #include "pg_host.hpp"
 #include "pg_host_priv.hpp"
 #include "pg_pipeline.hpp"
+#include "pg_rp.hpp"
 #include "pindel_pg.h"
 
 using namespace pgh;
@@ -164,6 +165,27 @@ const char *pgh_bam_ingest_name(void *h, uint64_t i)
 }
 
 void pgh_bam_ingest_free(void *h) { delete (pgh::IngestedReads *)h; }
+
+// Read-pair discovery (pg_rp.hpp): the BreakDancer-like events of one window of one BAM.  out receives 4 values per
+// event (pos1, pos1b, pos2, pos2b, Pindel coordinates); rp_path (nullable): the lines of <prefix>_RP.
+int64_t pgh_rp_events(const char *bam_path, const char *chr_name, int64_t win_start, int64_t win_end, int32_t insert_size,
+                      const char *tag, uint32_t min_anchor_quality, uint32_t spacer, const char *rp_path, uint32_t *out, uint64_t cap)
+{
+    pgh::BamFile bam;
+    if (!bam.open(bam_path, g_err)) return -1;
+    std::vector<pgh::RpRead> rp;
+    if (!pgh::rp_discover(bam, chr_name, win_start, win_end, insert_size, tag ? tag : "", min_anchor_quality, rp)) return -1;
+    std::ofstream f;
+    if (rp_path) f.open(rp_path, std::ios::trunc);
+    const std::vector<pgh::RpEvent> ev = pgh::rp_events(rp, spacer, rp_path ? &f : nullptr);
+    for (size_t i = 0; i < ev.size() && i < cap; i++) {
+        out[4 * i] = ev[i].pos1;
+        out[4 * i + 1] = ev[i].pos1b;
+        out[4 * i + 2] = ev[i].pos2;
+        out[4 * i + 3] = ev[i].pos2b;
+    }
+    return (int64_t)ev.size();
+}
 
 // Test hook (tests/test_cpu_suite.py): sorts indices 0..n-1 by keys[] with the reference's O(n^2)
 // exchange sort and with its fast equivalent; the two outputs must be identical.

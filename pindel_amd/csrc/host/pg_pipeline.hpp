@@ -11,7 +11,9 @@
 #include <vector>
 
 #include "pg_bam.hpp"
+#include "pg_bdhints.hpp"
 #include "pg_host.hpp"
+#include "pg_rp.hpp"
 
 namespace pgh {
 
@@ -107,12 +109,18 @@ struct BamSource {
     int insert_size = 0;
 };
 
+// bd != null && search_rp: before the reads of a window are taken, its discordant read pairs become BreakDancer-like
+// events (get_RP_Reads_Discovery + BDData::UpdateBD, src/pindel.cpp:1838-1848; -R, default on) next to the events of
+// a -b file; the search step then looks their windows up per read (loadRegion / getCorrespondingSearchWindowCluster).
 template <class Search>
 int run_bam_pipeline(const std::vector<Chromosome> &genome, const std::vector<unsigned> &fai,
                      const std::vector<BamSource> &bams, const BamIngestSettings &ingest, const Settings &S,
-                     const std::string &prefix, Search search, std::string &err, size_t *n_reads_total = nullptr)
+                     const std::string &prefix, Search search, std::string &err, size_t *n_reads_total = nullptr,
+                     BDHints *bd = nullptr, bool search_rp = false, size_t *n_rp_events = nullptr)
 {
     Caller caller(S, &genome, prefix, true);
+    std::ofstream rp_out;
+    if (bd && search_rp) rp_out.open((prefix + "_RP").c_str(), std::ios::trunc);
     const unsigned WINDOW = (unsigned)(S.window_mbp * 1000000);
     std::vector<BamFile> files(bams.size());
     for (size_t k = 0; k < bams.size(); k++)
@@ -124,6 +132,22 @@ int run_bam_pipeline(const std::vector<Chromosome> &genome, const std::vector<un
         const unsigned global_end = std::min(biol, bed_end + 10000u);
         for (unsigned ws = 0; !(ws > global_end); ws += WINDOW) {
             const unsigned we = std::min(ws + WINDOW, global_end);
+            if (bd && search_rp) {
+                std::vector<RpRead> rp;
+                for (size_t k = 0; k < bams.size(); k++)
+                    if (!rp_discover(files[k], chrom.name, ws, we, bams[k].insert_size, bams[k].tag, ingest.min_anchor_quality, rp)) {
+                        err = bams[k].path + ": BAM read failed";
+                        return -1;
+                    }
+                const std::vector<RpEvent> ev = rp_events(rp, S.spacer, &rp_out);
+                std::vector<std::pair<BDHints::RpSide, BDHints::RpSide>> sides;
+                for (const RpEvent &e : ev) {
+                    BDHints::RpSide a = { e.chr1, e.pos1, e.pos1b }, b = { e.chr2, e.pos2, e.pos2b };
+                    sides.push_back(std::make_pair(a, b));
+                }
+                bd->update_with_rp(sides);
+                if (n_rp_events) *n_rp_events += ev.size();
+            }
             IngestedReads in;
             in.clear();
             BamIngest ing(ingest);

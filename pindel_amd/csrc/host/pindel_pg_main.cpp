@@ -35,6 +35,7 @@ int main(int argc, char **argv)
     double t_search = 0.0;
     std::string fasta, reads_path, prefix, bd_path, bam_config;
     unsigned min_anchor_quality = 0;
+    bool search_rp = true;                 // -R: discordant read pairs as window hints (BAM input only; default true)
     bool use_bd = false;
     pg_params prm;
     pg_default_params(&prm);
@@ -78,7 +79,8 @@ int main(int argc, char **argv)
                 on = !(c0 == 'f' || c0 == '0');
                 i++;
             }
-            if (key == "-r") S.Analyze_INV = on;
+            if (key == "-R") search_rp = on;
+            else if (key == "-r") S.Analyze_INV = on;
             else if (key == "-t") S.Analyze_TD = on;
             // the other switches select reports (LI, BP, CloseEndMapped, INT ...) outside this program's scope
             continue;
@@ -317,12 +319,16 @@ int main(int argc, char **argv)
         t_search += now_s() - t0;
         return r;
     };
-    size_t n_bam_reads = 0;
+    size_t n_bam_reads = 0, n_rp_events = 0;
     if (!bams.empty()) {
         BamIngestSettings ing;
         ing.min_anchor_quality = min_anchor_quality;
         ing.spacer = prm.spacer;
-        rc = run_bam_pipeline(genome, fai, bams, ing, S, prefix, search, err, &n_bam_reads);
+        // BAM input: with -R (default) the window hints are live -- the events of a -b file plus the read-pair events of
+        // every window; without -R the reference never hands any event to the search (UpdateBD is not called)
+        use_bd = search_rp;
+        rc = run_bam_pipeline(genome, fai, bams, ing, S, prefix, search, err, &n_bam_reads, &bd, search_rp, &n_rp_events);
+        if (search_rp) printf("pindel_pg: read-pair events added as window hints: %zu\n", n_rp_events);
     } else
         rc = run_pipeline(genome, fai, all, S, prefix, search, err);
     if (rc) fprintf(stderr, "pindel_pg: %s (%s)\n", err.c_str(), pg_last_error(ctx));

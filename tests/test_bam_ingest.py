@@ -262,3 +262,269 @@ def test_command_line_bam_input_reproduces_gold_reports(tmp_path):
     assert out.returncode == 0, out.stderr
     assert "14862 reads, close end 14862, far end 10968" in out.stdout
     gu.assert_reports_match_gold(prefix)
+
+
+# ------------------------------------------------------------------------------------------ read-pair discovery (-R)
+def _rp_restated(records, tid, ws, we, isz, min_q, spacer):
+    """Independent restatement of build_record_RP_Discovery + UpdateBD / ModifyRP / Summarize (src/reader.cpp:925-1097,
+    src/bddata.cpp:138-812) for same-chromosome pairs.  Positions within a test are unique, so no sort has ties."""
+    def i32(x):
+        x &= 0xffffffff
+        return x - (1 << 32) if x >= (1 << 31) else x
+
+    def uabs(a, b):
+        return abs(i32(a - b))
+
+    rp = []
+    for r in records:
+        if r["tid"] != tid or not (r["pos"] < we and (r["pos"] + max(1, sum(n for op, n in r["cigar"] if op in (0, 2, 3)))) > ws):
+            continue
+        f = r["flag"]
+        if not f & F["PAIRED"] or r.get("mapq", 0) < min_q or f & F["UNMAP"] or f & F["MUNMAP"]:
+            continue
+        rev, mrev = bool(f & F["REVERSE"]), bool(f & F["MREVERSE"])
+        if not (abs(r.get("tlen", 0)) > 3 * isz + 1000 or rev == mrev) or r.get("mtid", tid) != tid:
+            continue
+        d = dict(DA="-" if rev else "+", DB="-" if mrev else "+", PosA=r["pos"], PosB=r["mpos"], L=len(r["seq"]), IS=isz, n=0,
+                 visited=False, report=False)
+        if not d["PosA"] < d["PosB"]:
+            d["DA"], d["DB"], d["PosA"], d["PosB"] = d["DB"], d["DA"], d["PosB"], d["PosA"]
+        d["OA"], d["OB"] = d["PosA"], d["PosB"]
+        rp.append(d)
+    rp.sort(key=lambda d: (d["PosA"], d["PosB"]))
+    rp.sort(key=lambda d: (-d["OA"], -d["OB"]))
+    for d in rp:
+        D, L = d["IS"], d["L"]
+        if d["DA"] == "+":
+            d["PosA"] = d["PosA"] - 2 * L if d["PosA"] > 2 * L else 1
+            d["A1"] = d["PosA"] + D + 2 * L
+        else:
+            d["PosA"] = d["PosA"] - D if d["PosA"] > D else 1
+            d["A1"] = d["PosA"] + D + L
+        if d["DB"] == "+":
+            d["PosB"] = d["PosB"] - 2 * L if d["PosB"] > 2 * L else 1
+        else:
+            d["PosB"] = d["PosB"] - D if d["PosB"] > D else 1
+        d["B1"] = d["PosB"] + D + L
+
+    def overlap(a, b):
+        if max(uabs(a["PosA"], a["A1"]), uabs(a["PosB"], a["B1"]), uabs(b["PosA"], b["A1"]), uabs(b["PosB"], b["B1"])) > 1000:
+            return False
+        fa, fb = sorted(((a["PosA"] + a["A1"]) // 2, (a["PosB"] + a["B1"]) // 2))
+        sa, sb = sorted(((b["PosA"] + b["A1"]) // 2, (b["PosB"] + b["B1"]) // 2))
+        if a["DA"] != b["DA"] or a["DB"] != b["DB"] or fa > sb + 200 or fb + 200 < sa:
+            return False
+        c = 0.9
+        if fa <= sa and sb <= fb and (sb - sa) / (fb - fa) >= c:
+            return True
+        if sa <= fa and fb <= sb and (fb - fa) / (sb - sa) >= c:
+            return True
+        if fa <= sa <= fb <= sb and (fb - sa) / (fb - fa) >= c and (fb - sa) / (sb - sa) >= c:
+            return True
+        if sa <= fa <= sb <= fb and (sb - fa) / (fb - fa) >= c and (sb - fa) / (sb - sa) >= c:
+            return True
+        return False
+
+    for a in rp:
+        for b in rp:
+            if a is b or not overlap(a, b):
+                continue
+            if b["A1"] - b["PosA"] > 10000 or b["B1"] - b["PosB"] > 10000:
+                continue
+            if (a["DA"] == "+" and a["PosA"] < b["PosA"] < a["A1"] < b["A1"]) or \
+                    (a["DA"] == "-" and a["PosA"] < b["A1"] < a["A1"] and b["PosA"] < a["PosA"]):
+                a["PosA"], a["A1"] = b["PosA"], b["A1"]
+            if (a["DB"] == "+" and a["PosB"] < b["PosB"] < a["B1"] < b["B1"]) or \
+                    (a["DB"] == "-" and b["PosB"] < a["PosB"] < b["B1"] < a["B1"]):
+                a["PosB"], a["B1"] = b["PosB"], b["B1"]
+    for d in rp:
+        if d["DA"] == "+":
+            d["PosA"] += d["L"]
+            d["A1"] += d["L"]
+        if d["DB"] == "+":
+            d["PosB"] += d["L"]
+            d["B1"] += d["L"]
+        if uabs(d["PosA"], d["PosB"]) < 500:
+            d["visited"] = True
+    box = lambda d: (d["PosA"], d["PosB"], d["A1"], d["B1"], d["DA"], d["DB"])
+    events = []
+    if len(rp) >= 5:
+        good = []
+        for i in range(len(rp) - 1):
+            if rp[i]["visited"]:
+                continue
+            rp[i]["n"] = 1
+            for j in range(i + 1, len(rp)):
+                if not rp[j]["visited"] and box(rp[i]) == box(rp[j]):
+                    rp[i]["n"] += 1
+                    rp[j]["visited"] = True
+            good.append(i)
+        if len(good) == 1:
+            rp[good[0]]["report"] = rp[good[0]]["n"] >= 5
+        else:
+            for a in range(len(good) - 1):
+                ra = rp[good[a]]
+                if ra["visited"]:
+                    continue
+                for b in range(a + 1, len(good)):
+                    rb = rp[good[b]]
+                    if not rb["visited"] and box(ra) == box(rb):
+                        ra["n"] += rb["n"]
+                        rb["visited"] = True
+                ra["report"] = ra["n"] >= 5
+    for d in rp:
+        if not d["report"]:
+            continue
+        sh = d["IS"]
+        f1, f2 = sorted((d["PosA"] + spacer, d["A1"] + spacer))
+        if d["DA"] == "+" and f1 > sh:
+            f1 -= sh
+        elif sh * 2 < spacer:
+            f2 += sh
+        s1, s2 = sorted((d["PosB"] + spacer, d["B1"] + spacer))
+        if d["DB"] == "+" and s1 > sh:
+            s1 -= sh
+        events.append((f1, f2, s1, s2, d["n"]))
+    return events
+
+
+def test_read_pair_discovery_matches_the_restatement(tmp_path):
+    rng = np.random.default_rng(77)
+    ref_len, isz, L = 3_000_000, 400, 100
+    recs, used = [], set()
+
+    def uniq(p):
+        while p in used:
+            p += 1
+        used.add(p)
+        return p
+
+    k = 0
+    for c in range(40):                                               # clusters of discordant pairs: deletions, inversions
+        a0 = int(rng.integers(20_000, ref_len - 200_000))
+        span = int(rng.integers(3000, 60_000))
+        kind = int(rng.integers(0, 3))
+        for _ in range(int(rng.integers(2, 14))):
+            pa = uniq(a0 + int(rng.integers(0, 250)))
+            pb = uniq(a0 + span + int(rng.integers(0, 250)))
+            ra, rb = (False, True) if kind == 0 else (False, False) if kind == 1 else (True, True)   # FR far apart / FF / RR
+            common = dict(qname=f"p{k}", tid=0, mtid=0, mapq=int(rng.choice([20, 40, 60])), cigar=[(0, L)], seq="ACGT" * 25)
+            recs.append(dict(common, flag=F["PAIRED"] | F["READ1"] | (F["REVERSE"] if ra else 0) | (F["MREVERSE"] if rb else 0),
+                             pos=pa, mpos=pb, tlen=pb - pa + L))
+            recs.append(dict(common, flag=F["PAIRED"] | F["READ2"] | (F["REVERSE"] if rb else 0) | (F["MREVERSE"] if ra else 0),
+                             pos=pb, mpos=pa, tlen=-(pb - pa + L)))
+            k += 1
+    for _ in range(3000):                                             # concordant pairs: ignored
+        pa = uniq(int(rng.integers(1000, ref_len - 2000)))
+        pb = uniq(pa + int(rng.integers(150, 320)))
+        common = dict(qname=f"p{k}", tid=0, mtid=0, mapq=60, cigar=[(0, L)], seq="ACGT" * 25)
+        recs.append(dict(common, flag=F["PAIRED"] | F["PROPER"] | F["READ1"] | F["MREVERSE"], pos=pa, mpos=pb, tlen=pb - pa + L))
+        recs.append(dict(common, flag=F["PAIRED"] | F["PROPER"] | F["READ2"] | F["REVERSE"], pos=pb, mpos=pa, tlen=-(pb - pa + L)))
+        k += 1
+    recs.sort(key=lambda r: r["pos"])
+    bam = tmp_path / "pairs.bam"
+    bw.write_bam(str(bam), [("chrP", ref_len)], recs, with_index=True)
+    L_ = hostlib.lib()
+    L_.pgh_rp_events.restype = C.c_int64
+    L_.pgh_rp_events.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int32, C.c_char_p, C.c_uint32, C.c_uint32,
+                                 C.c_char_p, C.c_void_p, C.c_uint64]
+    total = 0
+    for ws, we, min_q in ((0, 1_500_000, 0), (1_500_000, 3_000_000, 0), (0, 3_000_000, 30)):
+        out = np.zeros(4 * 4096, dtype=np.uint32)
+        rp_path = tmp_path / f"rp_{ws}_{min_q}.txt"
+        n = L_.pgh_rp_events(str(bam).encode(), b"chrP", ws, we, isz, b"S1", min_q, 100000, str(rp_path).encode(), out.ctypes.data, 4096)
+        want = _rp_restated(recs, 0, ws, we, isz, min_q, 100000)
+        assert n == len(want), (n, len(want))
+        got = sorted(tuple(int(v) for v in out[4 * i:4 * i + 4]) for i in range(n))
+        assert got == sorted(w[:4] for w in want)
+        lines = rp_path.read_text().splitlines()
+        assert len(lines) == n and all(l.startswith("chrP\t") and "Support: " in l and l.endswith("S1 " + l.split("Support: ")[1].split("\t")[0]) for l in lines)
+        total += n
+    assert total >= 10
+
+
+@pytest.mark.gpu
+def test_command_line_read_pair_hints_find_large_deletions(tmp_path):
+    """pindel_pg -i with -R (the reference's default for BAM input): discordant pairs around 8-30 kb deletions become
+    window hints, so the split reads across those deletions get their far ends (out of reach of the ranges at -x 2)
+    and the deletions are called; with `-R false` they are not.  Sharding over contexts does not change a byte."""
+    import filecmp
+    import subprocess
+    from pindel_amd import binding, synth
+    rng = np.random.default_rng(5)
+    ref = synth.make_reference(600_000, seed=91)
+    biol = np.frombuffer(ref, dtype=np.uint8)[100000:-100000]
+    fa = tmp_path / "ref.fa"
+    with open(fa, "wb") as fh:
+        fh.write(b">chrD\n")
+        for i in range(0, len(biol), 60):
+            fh.write(biol[i:i + 60].tobytes() + b"\n")
+    (tmp_path / "ref.fa.fai").write_text(f"chrD\t{len(biol)}\t6\t60\t61\n")
+    L, isz, recs, dels, used, k = 100, 400, [], [], set(), 0
+
+    def uniq(p):
+        while p in used:
+            p += 1
+        used.add(p)
+        return p
+
+    for d in range(12):
+        a = 30_000 + 45_000 * d + int(rng.integers(0, 2000))          # deletion of [a, b)
+        b = a + int(rng.integers(8_000, 30_000))
+        dels.append((a, b))
+        for _ in range(8):                                            # discordant pairs: mates on both sides, far apart
+            pa, pb = uniq(a - 350 + int(rng.integers(0, 200))), uniq(b + 50 + int(rng.integers(0, 200)))
+            common = dict(qname=f"d{k}", tid=0, mtid=0, mapq=60, cigar=[(0, L)])
+            recs.append(dict(common, flag=F["PAIRED"] | F["READ1"] | F["MREVERSE"], pos=pa, mpos=pb, tlen=pb - pa + L,
+                             seq=biol[pa:pa + L].tobytes().decode()))
+            recs.append(dict(common, flag=F["PAIRED"] | F["READ2"] | F["REVERSE"], pos=pb, mpos=pa, tlen=-(pb - pa + L),
+                             seq=biol[pb:pb + L].tobytes().decode()))
+            k += 1
+        for _ in range(10):                                           # split reads: anchor upstream, mate across the deletion
+            sp = int(rng.integers(30, 70))
+            read = np.concatenate([biol[a - sp:a], biol[b:b + L - sp]])
+            apos = uniq(a - sp - int(rng.integers(120, 250)))
+            comp = np.zeros(256, np.uint8)
+            for x, y in zip(b"ACGTN", b"TGCAN"):
+                comp[x] = y
+            recs.append(dict(qname=f"s{k}", flag=F["PAIRED"] | F["READ1"] | F["MUNMAP"], tid=0, mtid=0, pos=apos, mpos=apos, mapq=60,
+                             cigar=[(0, L)], seq=biol[apos:apos + L].tobytes().decode(), tlen=0))
+            recs.append(dict(qname=f"s{k}", flag=F["PAIRED"] | F["READ2"] | F["UNMAP"], tid=0, mtid=0, pos=apos, mpos=apos, mapq=0,
+                             cigar=[], seq=comp[read[::-1]].tobytes().decode(), tlen=0))
+            k += 1
+    recs.sort(key=lambda r: r["pos"])
+    bw.write_bam(str(tmp_path / "rp.bam"), [("chrD", len(biol))], recs, with_index=True)
+    (tmp_path / "cfg.txt").write_text(f"rp.bam\t{isz}\tTUMOR\n")
+    exe = os.path.join(os.path.dirname(binding.LIB_PATH), "pindel_pg")
+
+    def run(prefix, *extra):
+        out = subprocess.run([exe, "-f", str(fa), "-i", str(tmp_path / "cfg.txt"), "-o", str(tmp_path / prefix), *extra],
+                             capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        return out.stdout
+
+    so = run("hinted")
+    # 12 clusters of 8 pairs, 11 events: Summarize never sets Report for the LAST group it looks at
+    # (`index_a < GoodIndex.size() - 1`, src/bddata.cpp:514-551) -- after the descending sort that is the cluster
+    # with the smallest coordinate
+    assert "read-pair events added as window hints: 11" in so
+    rp_lines = (tmp_path / "hinted_RP").read_text().splitlines()
+    assert len(rp_lines) == 11 and all("TUMOR 16" in l for l in rp_lines)    # both mates of a pair lie in the window
+    so_plain = run("plain", "-R", "false")
+
+    def called(prefix):
+        sizes = []
+        for line in open(tmp_path / (prefix + "_D")):
+            f = line.split("\t")
+            if len(f) > 5 and f[1].startswith("D "):
+                sizes.append(int(f[1].split()[1]))
+        return sizes
+
+    want = sorted(b - a for a, b in dels[1:])              # every deletion but the one whose event is never reported
+    assert sorted(called("hinted")) == want
+    assert called("plain") == []
+    far = lambda s: int(s.split("far end ")[1].split()[0])
+    assert far(so) == 110 and far(so_plain) <= 5          # (a couple of chance far ends inside the 2 kb ranges)
+    run("sharded", "-G", "0,0")
+    for sfx in ("_D", "_SI", "_TD", "_INV", "_RP"):
+        assert filecmp.cmp(tmp_path / ("hinted" + sfx), tmp_path / ("sharded" + sfx), shallow=False), sfx
