@@ -35,10 +35,10 @@ TRAFFIC_FILE = "hbm_traffic.json"
 PMC_FILE = "pmc_sq.txt"
 
 
-def cpu_baseline(chroms, batch, params_kw, budget_s=12.0, bd=None, bd_off=None, thread_points=True):
-    """Time the CPU restatement (oracle, OpenMP over reads) on a bounded sample of the same reads, at all host
-    cores and -- on a smaller sample -- at 1/32/128 threads (the restatement is a faithful list-per-level
-    port, slower per core than the reference binary: SURVEY.md section 6 has the reference's own numbers)."""
+def cpu_baseline(chroms, batch, params_kw, budget_s=10.0, bd=None, bd_off=None, thread_points=True):
+    """Time the CPU restatement (oracle, OpenMP over reads) on bounded samples of the same reads at several thread
+    counts and report the best one (the restatement keeps the reference's list-per-level data flow; SURVEY.md
+    section 6 has the reference binary's own numbers: about 6.5 k reads/s per core)."""
     from oracle import pyoracle
     cores = os.cpu_count() or 1
     p = pyoracle.make_params(**params_kw)
@@ -54,23 +54,35 @@ def cpu_baseline(chroms, batch, params_kw, budget_s=12.0, bd=None, bd_off=None, 
 
     n0 = min(batch.n, 20000)
     run(n0, cores)                       # warms the pages and the OpenMP pool
-    n1 = min(batch.n, 200000)
-    t1 = run(n1, cores)                  # calibrates the rate at a size where all threads are busy
-    n2 = int(min(batch.n, max(n1, n1 / max(t1, 1e-6) * budget_s)))
-    if n2 > n1:
-        n1, t1 = n2, run(n2, cores)
-    out = {"value": n1 / t1, "unit": "reads/s", "cores": cores, "kind": "port",
-           "sample": f"first {n1} reads of the rank-0 batch, close+far end, OpenMP {cores} threads, {t1:.1f} s"}
-    if thread_points:
-        pts = {}
-        for th in (1, 32, 128):
-            if th >= cores:
-                continue
-            n = int(min(batch.n, max(2000, out["value"] * th / cores * 2.0)))     # ~2 s each
-            pts[str(th)] = n / run(n, th)
-        pts[str(cores)] = out["value"]
-        out["reads_per_s_by_threads"] = pts
-    return out
+    # The restatement allocates per read: it stops scaling (and then slows down) well before all hardware threads
+    # of a 256-thread host are in use.  Measure a few thread counts on ~2 s samples and report the BEST as the baseline.
+    rate = {}
+    for th in sorted({1, 16, 32, 64, 128, cores}):
+        if th > cores:
+            continue
+        guess = 25_000.0 * min(th, 32)                       # reads/s, first guess for the sample size
+        n = int(min(batch.n, max(2000, guess * 1.0)))
+        t = run(n, th)
+        if thread_points and t < 1.0 and n < batch.n:        # too short to mean much: once more on a 2 s sample
+            n = int(min(batch.n, max(n, n / max(t, 1e-6) * 2.0)))
+            t = run(n, th)
+        rate[th] = n / t
+    quota = cores
+    try:                                                     # a container may own fewer CPUs than it sees (cgroup v2 quota)
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(round(int(q) / int(per))))
+    except Exception:
+        pass
+    best = max(rate, key=lambda k: rate[k])
+    n1 = int(min(batch.n, max(20000, rate[best] * budget_s)))
+    t1 = run(n1, best)
+    rate[best] = max(rate[best], n1 / t1)
+    return {"value": n1 / t1, "unit": "reads/s", "cores": min(best, quota), "kind": "port", "threads": best,
+            "host_threads_visible": cores, "cpu_quota_cores": quota,
+            "sample": f"first {n1} reads of the rank-0 batch, close+far end, OpenMP {best} threads (the best of "
+                      f"{sorted(rate)}; the host shows {cores} threads, the container's CPU quota is {quota} cores), {t1:.1f} s",
+            "reads_per_s_by_threads": {str(k): rate[k] for k in sorted(rate)}}
 
 
 def default_workload(args):
@@ -345,13 +357,21 @@ def main():
         host_path = None
         if world == 1 and not args.no_host_path:
             # the seam a Pindel maintainer calls: host buffers in, host CSR out (PCIe both ways) -- never `value`
+            import ctypes as C
             nb = min(batch.n, 4_000_000)
-            sub = batch.slice(0, nb)
-            eng.search_batch(sub).free()
-            th = time.perf_counter()
-            r2 = eng.search_batch(sub)
-            host_path = nb / (time.perf_counter() - th)
-            r2.free()
+            st, keep = binding._batch_struct(batch.slice(0, nb))
+            L = binding.lib()
+            best_t = None
+            for _ in range(3):                        # the first call pins the result buffers / grows the device arena
+                h = C.c_void_p()
+                th = time.perf_counter()
+                rc = L.pg_search_batch(eng._h, C.byref(st), C.byref(h))
+                dt = time.perf_counter() - th
+                if rc:
+                    raise SystemExit(f"pg_search_batch failed: {rc}")
+                L.pg_result_free(h)
+                best_t = dt if best_t is None else min(best_t, dt)
+            host_path = nb / best_t
         out = {
             "metric": "one-end-anchored reads/sec through split-read search (close end + far end)",
             "value": units * args.steps / elapsed,

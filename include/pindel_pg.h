@@ -170,6 +170,12 @@ int  pg_far_end_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_result *close,
                       const pg_windows *bd_hints /* nullable */);
 int  pg_search_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_result **out);
 
+/* Multi-GPU form of pg_search_batch: the reads are split into n_ctx contiguous ranges (reads are independent:
+ * the loop of ReadBuffer::flush / SearchFarEnds, src/read_buffer.cpp:36-101, src/pindel.cpp:1115-1138), context k
+ * (one GPU each, the same reference loaded in all of them) searches range k on its own host thread, and the
+ * results are concatenated in order: identical to pg_search_batch on one context.  No collective between GPUs. */
+int  pg_search_batch_multi(pg_ctx *const *ctxs, int32_t n_ctx, const pg_read_batch *reads, pg_result **out);
+
 int  pg_result_view_get(const pg_result *r, pg_result_view *view);
 void pg_result_free(pg_result *r);
 /* Expand runs to UniquePoints; returns the number of points (call with out = NULL to count). */

@@ -64,7 +64,7 @@ EXPORTS = [
     "pg_default_params", "pg_create", "pg_destroy", "pg_last_error", "pg_get_max_mismatch",
     "pg_load_reference", "pg_load_fasta", "pg_reference_save_packed", "pg_reference_load_packed", "pg_reference_n_chr", "pg_reference_name",
     "pg_reference_comp_size", "pg_reference_fetch", "pg_close_end_batch", "pg_far_end_batch",
-    "pg_search_batch", "pg_result_view_get", "pg_result_free", "pg_expand_runs",
+    "pg_search_batch", "pg_search_batch_multi", "pg_result_view_get", "pg_result_free", "pg_expand_runs",
     "pg_device_batch_upload", "pg_device_batch_set_windows", "pg_device_batch_search", "pg_device_batch_download",
     "pg_device_batch_free", "pg_last_search_stats", "pg_device_batch_algorithmic_bytes",
     "pg_device_batch_candidates"]
@@ -125,6 +125,7 @@ def lib():
     L.pg_close_end_batch.argtypes = [vp, C.POINTER(PgReadBatch), C.POINTER(vp)]
     L.pg_far_end_batch.argtypes = [vp, C.POINTER(PgReadBatch), vp, C.POINTER(PgWindows)]
     L.pg_search_batch.argtypes = [vp, C.POINTER(PgReadBatch), C.POINTER(vp)]
+    L.pg_search_batch_multi.argtypes = [C.POINTER(vp), i32, C.POINTER(PgReadBatch), C.POINTER(vp)]
     L.pg_result_view_get.argtypes = [vp, C.POINTER(PgResultView)]
     L.pg_result_free.argtypes = [vp]
     L.pg_result_free.restype = None
@@ -309,6 +310,17 @@ class Engine:
         h = C.c_void_p()
         self._check(self._L.pg_search_batch(self._h, C.byref(s), C.byref(h)))
         return Result(h, self)
+
+    @staticmethod
+    def search_batch_multi(engines, batch) -> "Result":
+        """pg_search_batch_multi: contiguous shards of one batch on several contexts (one GPU each), concatenated."""
+        s, keep = _batch_struct(batch)
+        hs = (C.c_void_p * len(engines))(*[e._h for e in engines])
+        h = C.c_void_p()
+        rc = lib().pg_search_batch_multi(hs, len(engines), C.byref(s), C.byref(h))
+        if rc:
+            raise PgError(rc, (lib().pg_last_error(engines[0]._h) or b"").decode())
+        return Result(h, engines[0])
 
     # ---- device resident
     def upload(self, batch):

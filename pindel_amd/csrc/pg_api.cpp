@@ -1241,6 +1241,78 @@ int pg_search_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_result **out)
     return search_host(ctx, reads, PG_MODE_BOTH, out);
 }
 
+int pg_search_batch_multi(pg_ctx *const *ctxs, int32_t n_ctx, const pg_read_batch *reads, pg_result **out)
+{
+    if (!ctxs || n_ctx <= 0 || !reads || !out) return PG_E_INVALID;
+    for (int k = 0; k < n_ctx; k++)
+        if (!ctxs[k]) return PG_E_INVALID;
+    *out = nullptr;
+    const uint32_t n = reads->n_reads;
+    if (n_ctx == 1 || n < 2u * (uint32_t)n_ctx) return search_host(ctxs[0], reads, PG_MODE_BOTH, out);
+    // contiguous ranges, one host thread per context; the offsets of a sub-batch need not start at 0
+    std::vector<pg_result *> parts((size_t)n_ctx, nullptr);
+    std::vector<int> rcs((size_t)n_ctx, PG_OK);
+    std::vector<std::thread> th;
+    for (int k = 0; k < n_ctx; k++)
+        th.emplace_back([&, k]() {
+            const uint32_t lo = (uint32_t)((uint64_t)n * k / n_ctx), hi = (uint32_t)((uint64_t)n * (k + 1) / n_ctx);
+            pg_read_batch sub = *reads;
+            sub.n_reads = hi - lo;
+            sub.seq_off += lo;
+            sub.anchor_strand += lo;
+            sub.anchor_pos += lo;
+            sub.insert_size += lo;
+            sub.chr_id += lo;
+            rcs[(size_t)k] = search_host(ctxs[k], &sub, PG_MODE_BOTH, &parts[(size_t)k]);
+        });
+    for (std::thread &t : th) t.join();
+    int rc = PG_OK;
+    for (int k = 0; k < n_ctx; k++)
+        if (rcs[(size_t)k]) rc = rcs[(size_t)k];
+    pg_result *r = nullptr;
+    if (rc == PG_OK) {
+        r = new pg_result();
+        r->n = n;
+        uint64_t tc = 0, tf = 0;
+        for (pg_result *p : parts) {
+            tc += p->close_runs.size();
+            tf += p->far_runs.size();
+        }
+        if (!r->close_off.resize((size_t)n + 1) || !r->far_off.resize((size_t)n + 1) || !r->rc_flag.resize(n) ||
+            !r->close_last.resize(n) || !r->close_max.resize(n) || !r->close_runs.resize(tc) || !r->far_runs.resize(tf)) {
+            delete r;
+            r = nullptr;
+            rc = fail(ctxs[0], PG_E_NOMEM, "pinned host memory for the merged result");
+        }
+    }
+    if (r) {
+        uint64_t bc = 0, bf = 0;
+        size_t at = 0;
+        for (pg_result *p : parts) {
+            const size_t m = p->n;
+            for (size_t i = 0; i < m; i++) {
+                r->close_off[at + i] = bc + p->close_off[i];
+                r->far_off[at + i] = bf + p->far_off[i];
+            }
+            if (m) {
+                memcpy(r->rc_flag.data() + at, p->rc_flag.data(), m);
+                memcpy(r->close_last.data() + at, p->close_last.data(), m * 4);
+                memcpy(r->close_max.data() + at, p->close_max.data(), m * 2);
+            }
+            if (p->close_runs.size()) memcpy(r->close_runs.data() + bc, p->close_runs.data(), p->close_runs.size() * sizeof(pg_run));
+            if (p->far_runs.size()) memcpy(r->far_runs.data() + bf, p->far_runs.data(), p->far_runs.size() * sizeof(pg_run));
+            bc += p->close_runs.size();
+            bf += p->far_runs.size();
+            at += m;
+        }
+        r->close_off[n] = bc;
+        r->far_off[n] = bf;
+    }
+    for (pg_result *p : parts) delete p;
+    *out = r;
+    return rc;
+}
+
 // Validates per-read window clusters and uploads them to the batch (replacing earlier ones).
 static int attach_windows(pg_ctx *ctx, pg_device_batch *b, const pg_windows *bd_hints)
 {

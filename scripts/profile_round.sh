@@ -18,7 +18,7 @@ tail -c 600 "$out/bench_default.json"
 cd /tmp || exit 1
 rm -rf /tmp/rp_stats /tmp/rp_sq /tmp/rp_fetch /tmp/rp_write /tmp/rp_calib
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stats -- \
-    python "$root/bench.py" --reads "$reads" --steps 3 --warmup 1 --no-cpu-baseline > "$out/bench_under_rocprof.json" 2> /tmp/rp_stats.err
+    python "$root/bench.py" --reads "$reads" --steps 3 --warmup 1 --no-cpu-baseline --no-host-path > "$out/bench_under_rocprof.json" 2> /tmp/rp_stats.err
 f=$(find /tmp/rp_stats -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && head -12 "$f" > "$out/kernel_stats.csv"
 

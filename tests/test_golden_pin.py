@@ -132,6 +132,15 @@ def test_two_contexts_over_two_shards_equal_the_whole_batch(engine_factory, tmp_
     for k, v in cat.items():
         setattr(r, k, v)
     assert shard.digest_hex(shard.read_digests(whole)) == shard.digest_hex(shard.read_digests(r))
+    # the same behind the C ABI: pg_search_batch_multi over three contexts (one host thread each)
+    from pindel_amd import binding
+    c = engine_factory()
+    c.load_reference(ref)
+    multi = shard.result_arrays(binding.Engine.search_batch_multi([a, b, c], batch))
+    for k in ("close_off", "far_off", "rc_flag"):
+        assert np.array_equal(w[k], multi[k]), k
+    for k in ("close_runs", "far_runs"):
+        assert w[k].tobytes() == multi[k].tobytes(), k
 
 
 @pytest.mark.gpu
