@@ -483,6 +483,15 @@ void Caller::search_variant(Ctx &c, int kind)
         if (bp_sum > 1000000000u) bp_sum -= 1000000000u;
     }
     far_end_checksum = bp_sum;
+    if (S.log_counts) {
+        // the reference's own cross-check lines (search_variant.cpp:67-69): a maintainer can diff them
+        unsigned used = 0, far = 0;
+        for (const SplitRead &r : reads) {
+            used += r.Used ? 1u : 0u;
+            far += r.UP_Far.empty() ? 0u : 1u;
+        }
+        printf("Reads already used: %u\nFar ends already mapped %u\nChecksum of far ends: %u\n", used, far, bp_sum);
+    }
 
     for (unsigned ri = 0; ri < reads.size(); ri++) {
         SplitRead &r = reads[ri];

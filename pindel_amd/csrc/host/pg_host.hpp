@@ -69,6 +69,7 @@ struct Settings {                 // the flags the downstream steps read (src/fn
     bool Analyze_TD = true, Analyze_INV = true;   // -t, -r
     double window_mbp = 5.0;             // -w
     unsigned max_mismatch[500] = {0};    // g_maxMismatch
+    bool log_counts = false;             // print the reference's cross-check lines (far-end counts and checksum)
 };
 
 int load_fasta(const std::string &path, std::vector<Chromosome> &out, unsigned spacer, std::string &err);

@@ -223,6 +223,7 @@ int main(int argc, char **argv)
         }
     }
     S.spacer = prm.spacer;
+    S.log_counts = true;
     pg_get_max_mismatch(ctx, S.max_mismatch);
     std::vector<unsigned> fai = read_fai(fasta, genome);
     const double t_loaded = now_s();
@@ -312,10 +313,16 @@ int main(int argc, char **argv)
                 std::move(parts[d].begin(), parts[d].end(), reads.begin() + n * d / nd);
             }
         }
+        size_t bin_close = 0, bin_far = 0;
         for (const SplitRead &x : reads) {
-            n_close += !x.UP_Close.empty();
-            n_far += !x.UP_Far.empty();
+            bin_close += !x.UP_Close.empty();
+            bin_far += !x.UP_Far.empty();
         }
+        n_close += bin_close;
+        n_far += bin_far;
+        // ReportCloseAndFarEndCounts (src/pindel.cpp:1094-1113), over the reads that kept a close end
+        printf("Total: %zu;\tClose_end_found %zu;\tFar_end_found %zu;\tUsed\t0.\n\nFor LI and BP: %zu\n\n", bin_close, bin_close,
+               bin_far, bin_close - bin_far);
         t_search += now_s() - t0;
         return r;
     };

@@ -77,6 +77,9 @@ def test_command_line_reproduces_gold_reports(tmp_path):
     out = subprocess.run([exe, "-f", fa, "-p", reads_txt, "-o", prefix, "-T", "1"], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     assert "close end 14862, far end 10968" in out.stdout
+    # the reference's own cross-check lines (ReportCloseAndFarEndCounts, "Checksum of far ends")
+    assert "Total: 14862;\tClose_end_found 14862;\tFar_end_found 10968;" in out.stdout
+    assert "Far ends already mapped 10968" in out.stdout and "Checksum of far ends: " in out.stdout
     gu.assert_reports_match_gold(prefix)
 
 
