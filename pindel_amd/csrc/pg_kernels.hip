@@ -191,6 +191,8 @@ struct Search {
     int win_lo, win_hi, wbase;
     int nsurv;           // candidates folded since the state was reset
     int nsurv_total;     // ... since the read started (diagnostics: survivors of the seed filter)
+    int cap_state;       // state-dependent relevance bound for seeds (see evaluate); T - 1 = none
+    bool want_cap;       // more window chunks will be filtered after the next evaluation: keep cap_state up to date
     bool tierA;          // the short-lived tier is usable: bps + 16 <= 32 and CheckMismatches' "L > m" test cannot fail
     bool len_check;      // Min_Perfect_Match_Around_BP >= bps: the "L > m" test of CheckMismatches can fail
 };
@@ -501,6 +503,10 @@ __device__ __forceinline__ u32 seed_filter(const Search &S, const Query<NB> &Q,
     const u32 jmask = bits32(1, J), g0mask = bits32(1, jb);
     int cap0 = uni(max_mismatch_at(S.mm_bp, J)) + S.add_mm;        // min(T-1, g_maxMismatch[J] + ADD)
     if (cap0 > T - 1) cap0 = T - 1;
+    // ... and, once candidates have been folded, min with the state's bound: a seed whose level at bps exceeds
+    // (lowest level present at L) + ADD for every L in [bps, J] cannot be the lowest there nor within ADD of it
+    // (levels only grow with L); later lengths are covered by the "alive after J bases" test
+    if (cap0 > S.cap_state) cap0 = S.cap_state;
     const int a = 2 * NB + lane - (kindB ? 1 : 0);         // LDS word holding the low half of the pair
     // read symbols: A C G T N other; bases [1, jb) first, snapshot, then bases [jb, J)
     const u32 sym[6] = { ~lo & ~hi & acgt, lo & ~hi & acgt, ~lo & hi & acgt, lo & hi & acgt, nn, oo };
@@ -717,7 +723,7 @@ __device__ __forceinline__ u32 mm_of(const Search &S, int L)
 // CheckMismatches (already folded into the state).  mm0 = g_maxMismatch[bps + lane] (round 0).  The
 // reduction itself is not modified.
 template <int NB, typename Id>
-__device__ __forceinline__ void evaluate(const Search &S, const Acc<NB, Id> &A, u32 mm0, Eval<NB, Id> &E, int lane)
+__device__ __forceinline__ void evaluate(Search &S, const Acc<NB, Id> &A, u32 mm0, Eval<NB, Id> &E, int lane)
 {
     E.n_runs = 0;
     E.max_len = 0;
@@ -741,6 +747,24 @@ __device__ __forceinline__ void evaluate(const Search &S, const Acc<NB, Id> &A, 
         }
         merge<Id>(t1, t2, tid, tok, a1, a2, aid, aok);
         __syncthreads();
+    }
+    if (S.want_cap) {
+        // max over L in [bps, J] of the lowest level present (none present: no bound), + ADD; J as in seed_filter
+        int J = S.len - 1 < 32 ? S.len - 1 : 32;
+        if (J > PG_SEED_J(S.T)) J = PG_SEED_J(S.T);
+        u32 v = (S.bps + lane <= J) ? t1 : 0u;
+        // (each shift is taken once, outside the select: a DPP read under a diverged EXEC mask sees 0 in the
+        // lanes that are switched off)
+        u32 o;
+        o = row_shr<1>(v); v = v > o ? v : o;
+        o = row_shr<2>(v); v = v > o ? v : o;
+        o = row_shr<4>(v); v = v > o ? v : o;
+        o = row_shr<8>(v); v = v > o ? v : o;
+        u32 mx = read_lane(v, 15);
+        const u32 m2_ = read_lane(v, 31);               // (J - bps < 32: rows 0 and 1 hold every lane of interest)
+        mx = mx > m2_ ? mx : m2_;
+        const int cap = (int)mx + S.add_mm;
+        S.cap_state = cap < S.T - 1 ? cap : S.T - 1;
     }
     bool aborted = false;
 #pragma unroll
@@ -901,6 +925,8 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     S.win_wo = -1;
     S.win_hi = S.wbase = 0;
     S.nsurv_total = 0;
+    S.cap_state = 255;
+    S.want_cap = false;
     // the read's packed record (rid is wave-uniform)
     const uint4 *rp = (const uint4 *)(B.in + rid);
     const uint4 r0 = rp[0], r1 = rp[1];
@@ -970,6 +996,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                 close_bases = e1 > s1 ? e1 - s1 : 0;
                 if (att != 2) {           // attempt 2 continues attempt 1's reduction
                     A.reset();
+                    S.cap_state = 255;
                     S.nsurv = 0;
                     nsurv_eval = 0;
                     ps = pe = 0;
@@ -1064,6 +1091,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                 const int nbd = uni((int)r1.z);
                 const pg_window *bd = B.bd + uni((int)r1.w);
                 A.reset();
+                S.cap_state = 255;
                 S.nsurv = 0;
                 for (int w = 0; w < nbd; w++) {
                     const pg_window bw = bd[w];
@@ -1093,6 +1121,8 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                 bool cache_valid = false;
                 int ps = 0, pe = 0, span = 64, nsurv_eval = 0;
                 A.reset();
+                S.cap_state = 255;
+                S.want_cap = prm.max_range_index >= 3;     // ranges beyond the cached innermost chunk will be filtered
                 S.nsurv = 0;
                 for (int r = 0; r <= prm.max_range_index; r++, span *= 4) {
                     int s, e;
