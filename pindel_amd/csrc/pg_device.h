@@ -110,7 +110,7 @@ struct PgSoaOut {
 #define PG_CHUNK_SHIFT 11
 #define PG_EQ_ROWS 5u
 // LDS window capacity in 32-base words: chunk + overhang of nb 64-base blocks on both sides + slack
-#define PG_WIN_WORDS(nb) ((PG_CHUNK + 2u * (64u * (nb))) / 32u + 6u)
+#define PG_WIN_WORDS(nb) ((2u * PG_CHUNK + 2u * (64u * (nb))) / 32u + 6u)
 
 #ifdef __cplusplus
 extern "C" {

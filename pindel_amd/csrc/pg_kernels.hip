@@ -170,7 +170,8 @@ template <int NB>
 struct Lds {
     uint4 win[PG_WIN_WORDS(NB)];              // staged window: code planes (lo, hi, N)
     uint4 bufA[68];                           // tier A entries {mis0 lo, sne0 lo, id lo, meta}; scratch for the quarter merge
-    uint4 bufB[64 * (1 + NB)];                // tier B entries {id lo, meta, -, -} + NB x {mis lo, mis hi, sne lo, sne hi}
+    uint4 bufB[64 * NB];                      // tier B entries: NB x {mis lo, mis hi, sne lo, sne hi} per candidate
+    uint2 hdrB[64];                           // ... and their {id lo, meta}
     uint4 accB[NB > 1 ? 64 * (NB - 1) : 1];   // reduction state of the rounds >= 1 {m1, m2 | ok << 16, id lo, id hi}
     u64 qp[2 * 4 * NB];                       // the read's bit planes, two orientations
     uint16_t queue[64];                       // survivors of the prefilter for one candidate pass: (window position << 1) | kind
@@ -183,6 +184,7 @@ struct Search {
     uint4 *win;
     uint4 *bufA;
     uint4 *bufB;
+    uint2 *hdrB;
     uint4 *accB;
     const u32 *mm_bp;    // LDS copy of PgDevParams::mm_bp
     // what the LDS window currently holds: bases [win_lo, win_hi) of the chromosome whose AbsLoc 0 is
@@ -292,7 +294,7 @@ template <int NB, typename Id, bool MIXED>
 __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB> &Q, Acc<NB, Id> &A, int wbase,
                                                 int origin, u32 region, int n, int lane)
 {
-    constexpr int EW = 1 + NB;                            // uint4 words per tier B entry
+    constexpr int EW = NB;                                // uint4 words per tier B entry
     bool valid = lane < n;
     int p = 0;
     bool isB = MIXED ? false : Q.allowB;
@@ -323,7 +325,7 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
             const u64 lm = low_bits(S.len - 64 * b);
             m &= lm;
             s = (m ^ s) & lm;                             // exact inequality (the read's N bits flipped)
-            S.bufB[lane * EW + 1 + b] = make_uint4((u32)m, (u32)(m >> 32), (u32)s, (u32)(s >> 32));
+            S.bufB[lane * EW + b] = make_uint4((u32)m, (u32)(m >> 32), (u32)s, (u32)(s >> 32));
             cum += __popcll(m);
             if (b == 0) {
                 lvl0 = __popcll(m & low_bits(S.bps));
@@ -356,7 +358,7 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
         const int rank = __popcll(shortm & low_bits(lane));
         S.bufA[rank] = make_uint4(m0lo, s0lo, (u32)id, meta);
     }
-    if (lng) S.bufB[lane * EW] = make_uint4((u32)id, meta, 0u, 0u);
+    if (lng) S.hdrB[lane] = make_uint2((u32)id, meta);
     __syncthreads();
     // ---- tier A
     const int nA = __popcll(shortm);
@@ -404,13 +406,13 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
             const int i = __ffsll((long long)mask) - 1;
             mask &= mask - 1ull;
             const uint4 *e = S.bufB + i * EW;
-            const uint4 h = e[0];
+            const uint2 h = S.hdrB[i];
             u32 k = 0u;
             u64 bad = 0ull;
 #pragma unroll
             for (int b = 0; b < NB; b++) {
                 if (b > r + 1) continue;                  // L <= bps + 64 r + 63 < 64 (r + 2)
-                const uint4 w = e[1 + b];
+                const uint4 w = e[b];
                 const u64 m = (u64)w.x | ((u64)w.y << 32), sn = (u64)w.z | ((u64)w.w << 32);
                 k += (u32)__popcll(b < r ? m : (m & Mk[b]));
                 if (b + 1 >= r) bad |= sn & BP[b];        // L - m >= 64 r - 64 (m <= 64 <= 64 + bps)
@@ -463,6 +465,9 @@ __device__ __forceinline__ u32 bits32(int lo, int hi)      // bits [lo,hi), clam
 #ifndef PG_SEED_J
 #define PG_SEED_J(T) (2 * (T) + 4)     // consumed bases the seed filter looks at
 #endif
+#ifndef PG_SEED_J_WIDE
+#define PG_SEED_J_WIDE 2
+#endif
 
 // positions whose bit-sliced mismatch count (c3 c2 c1 c0, ov = overflowed) is <= thr (wave-uniform)
 __device__ __forceinline__ u32 count_le(u32 c0, u32 c1, u32 c2, u32 c3, u32 ov, int thr)
@@ -478,6 +483,112 @@ __device__ __forceinline__ u32 count_le(u32 c0, u32 c1, u32 c2, u32 c3, u32 ov, 
     return thr >= 15 ? ~ov : (lt | eq);
 }
 
+// Bit-sliced mismatch counter of the seed filter: NS slices + a sticky overflow bit per position.  Bases are
+// added one, two or three at a time (carry-save: the sum bits of two or three match masks first, then one
+// ripple through the slices -- 7, 4.5 and 3.7 VALU instructions per base).  m* are MATCH masks.  Written as asm
+// because the compiler's version of the same ripple rotates the counter through extra v_mov.
+template <int NS>
+struct Counter {
+    u32 c0, c1, c2, c3, ov;
+    __device__ __forceinline__ void reset() { c0 = c1 = c2 = c3 = ov = 0u; }
+    __device__ __forceinline__ u32 le(int thr) const
+    {
+        return thr < 0 ? 0u : count_le(c0, c1, c2, NS == 4 ? c3 : 0u, ov, thr);
+    }
+    // the carry out of slice 1 (k1) through the upper slices
+    __device__ __forceinline__ void upper(u32 k1)
+    {
+        if (NS == 3) {
+            asm("v_and_or_b32 %1, %0, %2, %1\n\t"        // ov |= c2 & k1
+                "v_xor_b32 %0, %0, %2"                      // c2 ^= k1
+                : "+v"(c2), "+v"(ov) : "v"(k1));
+        } else {
+            u32 k2;
+            asm("v_and_b32 %3, %0, %4\n\t"                // k2 = c2 & k1
+                "v_xor_b32 %0, %0, %4\n\t"                // c2 ^= k1
+                "v_and_or_b32 %2, %1, %3, %2\n\t"         // ov |= c3 & k2
+                "v_xor_b32 %1, %1, %3"                      // c3 ^= k2
+                : "+v"(c2), "+v"(c3), "+v"(ov), "=&v"(k2) : "v"(k1));
+        }
+    }
+    __device__ __forceinline__ void add1(u32 m)
+    {
+        u32 k0, k1;
+        asm("v_bfi_b32 %2, %4, 0, %0\n\t"                 // k0 = ~m & c0
+            "v_xnor_b32 %0, %0, %4\n\t"                   // c0 ^= ~m
+            "v_and_b32 %3, %1, %2\n\t"                    // k1 = c1 & k0
+            "v_xor_b32 %1, %1, %2"                          // c1 ^= k0
+            : "+v"(c0), "+v"(c1), "=&v"(k0), "=&v"(k1) : "v"(m));
+        upper(k1);
+    }
+    __device__ __forceinline__ void add2(u32 ma, u32 mb)
+    {
+        // sum of the two mismatch bits: low bit ma ^ mb, high bit ~(ma | mb); the high bit and the carry out of
+        // slice 0 exclude each other, so slice 1 adds t = high | carry
+        u32 k0, t, k1;
+        asm("v_bitop3_b32 %2, %0, %5, %6 bitop3:0x60\n\t" // k0 = c0 & (ma ^ mb)
+            "v_bitop3_b32 %0, %0, %5, %6 bitop3:0x96\n\t" // c0 ^= ma ^ mb
+            "v_bitop3_b32 %3, %5, %6, %2 bitop3:0xab\n\t" // t = ~(ma | mb) | k0
+            "v_and_b32 %4, %1, %3\n\t"                    // k1 = c1 & t
+            "v_xor_b32 %1, %1, %3"                          // c1 ^= t
+            : "+v"(c0), "+v"(c1), "=&v"(k0), "=&v"(t), "=&v"(k1) : "v"(ma), "v"(mb));
+        upper(k1);
+    }
+    __device__ __forceinline__ void add3(u32 ma, u32 mb, u32 mc)
+    {
+        u32 s0, s1, k0, k1;
+        asm("v_bitop3_b32 %2, %6, %7, %8 bitop3:0x69\n\t" // s0 = ~(ma ^ mb ^ mc): low bit of the mismatch sum
+            "v_bitop3_b32 %3, %6, %7, %8 bitop3:0x17\n\t" // s1 = ~maj(ma, mb, mc): high bit
+            "v_and_b32 %4, %0, %2\n\t"                    // k0 = c0 & s0
+            "v_xor_b32 %0, %0, %2\n\t"                    // c0 ^= s0
+            "v_bitop3_b32 %5, %1, %3, %4 bitop3:0xe8\n\t" // k1 = maj(c1, s1, k0)
+            "v_bitop3_b32 %1, %1, %3, %4 bitop3:0x96"       // c1 ^= s1 ^ k0
+            : "+v"(c0), "+v"(c1), "=&v"(s0), "=&v"(s1), "=&v"(k0), "=&v"(k1)
+            : "v"(ma), "v"(mb), "v"(mc));
+        upper(k1);
+    }
+    // lowest set bit of the wave-uniform set pm, removed from it: two scalar instructions
+    static __device__ __forceinline__ u32 take(u32 &pm)
+    {
+        u32 j;
+        asm("s_ff1_i32_b32 %0, %1\n\ts_bitset0_b32 %1, %0" : "=&s"(j), "+s"(pm));
+        return j;
+    }
+};
+
+// Every base of the (wave-uniform) set pm goes into the counter(s).  Kind F: the base at bit j reads the pair
+// (own word, next word) shifted by j.  Kind B: the pair (previous word, own word) shifted by 32 - j.  DUAL: both
+// kinds in one loop (the scalar bookkeeping is shared; the caller passes kind B's planes of the complementary
+// symbol).  revB (single kind B): pm arrives bit-reversed and moved up one bit, so that its bit IS the shift.
+// group: three or two bases at a time (not for the rare N bases, to keep the code small).
+template <int NS, bool DUAL>
+__device__ __forceinline__ void add_bases(bool group, u32 pm, Counter<NS> &C, u32 lo, u32 hi,
+                                          Counter<NS> &C2, u32 lo2, u32 hi2)
+{
+    if (group) {
+        int n = __popc(pm);
+        while (n >= 3) {
+            const u32 ja = Counter<NS>::take(pm), jb = Counter<NS>::take(pm), jc = Counter<NS>::take(pm);
+            C.add3(__builtin_amdgcn_alignbit(hi, lo, ja), __builtin_amdgcn_alignbit(hi, lo, jb),
+                   __builtin_amdgcn_alignbit(hi, lo, jc));
+            if (DUAL)
+                C2.add3(__builtin_amdgcn_alignbit(hi2, lo2, 32u - ja), __builtin_amdgcn_alignbit(hi2, lo2, 32u - jb),
+                        __builtin_amdgcn_alignbit(hi2, lo2, 32u - jc));
+            n -= 3;
+        }
+        if (n == 2) {
+            const u32 ja = Counter<NS>::take(pm), jb = Counter<NS>::take(pm);
+            C.add2(__builtin_amdgcn_alignbit(hi, lo, ja), __builtin_amdgcn_alignbit(hi, lo, jb));
+            if (DUAL) C2.add2(__builtin_amdgcn_alignbit(hi2, lo2, 32u - ja), __builtin_amdgcn_alignbit(hi2, lo2, 32u - jb));
+        }
+    }
+    while (pm != 0u) {
+        const u32 j = Counter<NS>::take(pm);
+        C.add1(__builtin_amdgcn_alignbit(hi, lo, j));
+        if (DUAL) C2.add1(__builtin_amdgcn_alignbit(hi2, lo2, 32u - j));
+    }
+}
+
 // SEED FILTER, bit sliced: the lane owns the 32 window positions of word `lane` of the chunk and returns
 // the mask of positions whose candidate (of kind F or B) can matter.  Position bit i, consumed base j
 // reads reference base p+j (F) / p-j (B): one alignbit of the one-hot plane of read base j.  Mismatch
@@ -488,96 +599,96 @@ __device__ __forceinline__ u32 count_le(u32 c0, u32 c1, u32 c2, u32 c3, u32 ov, 
 // without it.  With J > bps bases inspected: relevant at some L in [bps, J] implies
 // c(bps) <= g_maxMismatch[J] + ADD (the table is monotone); relevant later implies alive after J bases,
 // c(J) <= T-1.  With J <= bps only the second test applies.  Anything kept beyond that is harmless.
-template <int NB>
-__device__ __forceinline__ u32 seed_filter(const Search &S, const Query<NB> &Q,
-                                           bool kindB, int lane)
+// DUAL (far end, both kinds wanted, kind B reading the complement of what kind F reads): one pass yields
+// both masks (mF, mB).  Otherwise the mask of the one kind (kindB) comes back in mF.
+template <int NB, int NS, bool DUAL>
+__device__ __forceinline__ void seed_filter_run(const Search &S, const Query<NB> &Q, bool kindB, int lane,
+                                                int J, int jb, int cap0, u32 &mF, u32 &mB)
 {
     u32 lo = (u32)uni((int)(u32)q_lo<NB>(Q, 0)), hi = (u32)uni((int)(u32)q_hi<NB>(Q, 0));
     const u32 nn = (u32)uni((int)(u32)q_nn<NB>(Q, 0)), oo = (u32)uni((int)(u32)q_oo<NB>(Q, 0));
-    if (kindB ? Q.cB : Q.cF) { lo = ~lo; hi = ~hi; }
+    if (DUAL ? Q.cF : (kindB ? Q.cB : Q.cF)) { lo = ~lo; hi = ~hi; }
     const u32 acgt = ~(nn | oo);
-    const int T = S.T;
-    int J = S.len - 1 < 32 ? S.len - 1 : 32;
-    if (J > PG_SEED_J(T)) J = PG_SEED_J(T);
-    const int jb = S.bps < J ? S.bps : J;
     const u32 jmask = bits32(1, J), g0mask = bits32(1, jb);
+    // read symbols A C G T N (in the orientation of the single kind / of kind F); bases [1, jb) first,
+    // snapshot, then bases [jb, J)
+    const u32 sym[5] = { ~lo & ~hi & acgt, lo & ~hi & acgt, ~lo & hi & acgt, lo & hi & acgt, nn };
+    // one-hot planes (is-A, is-C, is-G, is-T, is-not-N) of the lane's window words, from the code planes:
+    // w0 = the word of the lane's 32 positions, w1 = the next one (kind F), wm = the previous one (kind B)
+    const int a = 2 * NB + lane;
+    const bool useF = DUAL || !kindB, useB = DUAL || kindB;
+    const uint4 p0 = S.win[a];
+    u32 w0[5], w1[5], wm[5];
+    w0[0] = ~(p0.x | p0.y | p0.z);
+    w0[1] = p0.x & ~(p0.y | p0.z);
+    w0[2] = p0.y & ~(p0.x | p0.z);
+    w0[3] = p0.x & p0.y & ~p0.z;
+    w0[4] = ~p0.z;
+#pragma unroll
+    for (int X = 0; X < 5; X++) w1[X] = wm[X] = 0u;
+    if (useF) {
+        const uint4 p1 = S.win[a + 1];
+        w1[0] = ~(p1.x | p1.y | p1.z);
+        w1[1] = p1.x & ~(p1.y | p1.z);
+        w1[2] = p1.y & ~(p1.x | p1.z);
+        w1[3] = p1.x & p1.y & ~p1.z;
+        w1[4] = ~p1.z;
+    }
+    if (useB) {
+        const uint4 pm1 = S.win[a - 1];
+        wm[0] = ~(pm1.x | pm1.y | pm1.z);
+        wm[1] = pm1.x & ~(pm1.y | pm1.z);
+        wm[2] = pm1.y & ~(pm1.x | pm1.z);
+        wm[3] = pm1.x & pm1.y & ~pm1.z;
+        wm[4] = ~pm1.z;
+    }
+    // the seed: the position's own base equals the first read base (first_ok: it is one of ACGT)
+    const u32 l0 = (lo & 1u) ? ~0u : 0u, h0 = (hi & 1u) ? ~0u : 0u;
+    const u32 seed = ~((p0.x ^ l0) | (p0.y ^ h0) | p0.z);
+    const u32 seed2 = ~((p0.x ^ ~l0) | (p0.y ^ ~h0) | p0.z);          // DUAL: kind B reads the complement
+    // a read base that is none of ACGTN matches nothing: a constant for every position, taken off the thresholds
+    const int o_pre = __popc(oo & g0mask), o_all = __popc(oo & jmask);
+    Counter<NS> C, C2;
+    C.reset();
+    C2.reset();
+    u32 snap = 0u, snap2 = 0u;
+#pragma unroll
+    for (int it = 0; it < 10; it++) {
+        const int X = it >= 5 ? it - 5 : it;
+        const int X2 = X < 4 ? 3 - X : X;                              // the complementary symbol
+        if (it == 5) {
+            snap = C.le(cap0 - o_pre);
+            if (DUAL) snap2 = C2.le(cap0 - o_pre);
+        }
+        u32 pm = sym[X] & (it >= 5 ? (jmask & ~g0mask) : g0mask);
+        if (DUAL) add_bases<NS, true>(X < 4, pm, C, w0[X], w1[X], C2, wm[X2], w0[X2]);
+        else if (kindB) add_bases<NS, false>(X < 4, __brev(pm) << 1, C, wm[X], w0[X], C2, 0u, 0u);
+        else add_bases<NS, false>(X < 4, pm, C, w0[X], w1[X], C2, 0u, 0u);
+    }
+    mF = seed & (snap | C.le(S.T - 1 - o_all));
+    if (DUAL) mB = seed2 & (snap2 | C2.le(S.T - 1 - o_all));
+}
+
+template <int NB, bool DUAL>
+__device__ __forceinline__ void seed_filter(const Search &S, const Query<NB> &Q, bool kindB, bool wide, int lane,
+                                            u32 &mF, u32 &mB)
+{
+    const int T = S.T;
+    // bases inspected: two more in the chunks of wide far-end windows, where survivors cost a whole pass of
+    // fold_candidates for a handful of candidates (measured: -4 % time at -x 5, +2 % if used everywhere)
+    int J = S.len - 1 < 32 ? S.len - 1 : 32;
+    const int jt = PG_SEED_J(T) + (wide ? PG_SEED_J_WIDE : 0);
+    if (J > jt) J = jt;
+    const int jb = S.bps < J ? S.bps : J;
     int cap0 = uni(max_mismatch_at(S.mm_bp, J)) + S.add_mm;        // min(T-1, g_maxMismatch[J] + ADD)
     if (cap0 > T - 1) cap0 = T - 1;
     // ... and, once candidates have been folded, min with the state's bound: a seed whose level at bps exceeds
     // (lowest level present at L) + ADD for every L in [bps, J] cannot be the lowest there nor within ADD of it
     // (levels only grow with L); later lengths are covered by the "alive after J bases" test
     if (cap0 > S.cap_state) cap0 = S.cap_state;
-    const int a = 2 * NB + lane - (kindB ? 1 : 0);         // LDS word holding the low half of the pair
-    // read symbols: A C G T N other; bases [1, jb) first, snapshot, then bases [jb, J)
-    const u32 sym[6] = { ~lo & ~hi & acgt, lo & ~hi & acgt, ~lo & hi & acgt, lo & hi & acgt, nn, oo };
-    // one-hot planes (is-A, is-C, is-G, is-T, is-not-N) of the lane's two window words, from the code planes
-    const uint4 pa = S.win[a], pb = S.win[a + 1];
-    u32 wl[6], wh[6];
-    wl[0] = ~(pa.x | pa.y | pa.z); wh[0] = ~(pb.x | pb.y | pb.z);
-    wl[1] = pa.x & ~(pa.y | pa.z); wh[1] = pb.x & ~(pb.y | pb.z);
-    wl[2] = pa.y & ~(pa.x | pa.z); wh[2] = pb.y & ~(pb.x | pb.z);
-    wl[3] = pa.x & pa.y & ~pa.z;   wh[3] = pb.x & pb.y & ~pb.z;
-    wl[4] = ~pa.z;                 wh[4] = ~pb.z;
-    wl[5] = wh[5] = 0u;                                     // symbol 5 (not ACGTN) never matches
-    // the seed: position's own base equals the first read base (first_ok: it is one of ACGT)
-    const u32 sx = kindB ? pb.x : pa.x, sy = kindB ? pb.y : pa.y, sz = kindB ? pb.z : pa.z;
-    const u32 seed = ~((sx ^ ((lo & 1u) ? ~0u : 0u)) | (sy ^ ((hi & 1u) ? ~0u : 0u)) | sz);
-    u32 c0 = 0u, c1 = 0u, c2 = 0u, c3 = 0u, ov = 0u;        // mismatch count per position, bit sliced
-    u32 snap = 0u;
-    // kind F: base j is a funnel shift by j.  Kind B: by 32 - j; its base masks are bit-reversed below, so that
-    // base j sits at bit 31 - j and the shift is (31 - j) + 1: one scalar add per base either way
-    const int shift0 = kindB ? 1 : 0;
-    if (T <= 8) {
-        // counts up to 7 decide everything (cap0 <= T - 1 <= 7): three slices + overflow, 7 VALU per base
-#pragma unroll
-        for (int it = 0; it < 12; it++) {
-            const int X = it >= 6 ? it - 6 : it;
-            if (it == 6) snap = count_le(c0, c1, c2, 0u, ov, cap0);
-            u32 pm = sym[X] & (it >= 6 ? (jmask & ~g0mask) : g0mask);
-            if (kindB) pm = __brev(pm);
-            while (pm != 0u) {
-                const int j = __ffs((int)pm) - 1;
-                pm &= pm - 1u;
-                const u32 m = __builtin_amdgcn_alignbit(wh[X], wl[X], (u32)(j + shift0));
-                u32 k0, k1;
-                asm("v_bfi_b32 %4, %6, 0, %0\n\t"          // k0 = ~m & c0
-                    "v_xnor_b32 %0, %0, %6\n\t"            // c0 ^= ~m
-                    "v_and_b32 %5, %1, %4\n\t"             // k1 = c1 & k0
-                    "v_xor_b32 %1, %1, %4\n\t"             // c1 ^= k0
-                    "v_and_or_b32 %3, %2, %5, %3\n\t"      // ov |= c2 & k1
-                    "v_xor_b32 %2, %2, %5"                   // c2 ^= k1
-                    : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(ov), "=&v"(k0), "=&v"(k1)
-                    : "v"(m));
-            }
-        }
-        return seed & (snap | count_le(c0, c1, c2, 0u, ov, T - 1));
-    }
-#pragma unroll
-    for (int it = 0; it < 12; it++) {
-        const int X = it >= 6 ? it - 6 : it;
-        if (it == 6) snap = count_le(c0, c1, c2, c3, ov, cap0);
-        u32 pm = sym[X] & (it >= 6 ? (jmask & ~g0mask) : g0mask);
-        if (kindB) pm = __brev(pm);
-        while (pm != 0u) {
-            const int j = __ffs((int)pm) - 1;
-            pm &= pm - 1u;
-            const u32 m = __builtin_amdgcn_alignbit(wh[X], wl[X], (u32)(j + shift0));
-            // count += mismatch (= ~m), in place: 8 VALU instructions.  Written as asm because the
-            // compiler's version of the same ripple rotates the counter through three extra v_mov.
-            u32 k0, k1;
-            asm("v_bfi_b32 %5, %7, 0, %0\n\t"          // k0 = ~m & c0
-                "v_xnor_b32 %0, %0, %7\n\t"            // c0 ^= ~m
-                "v_and_b32 %6, %1, %5\n\t"             // k1 = c1 & k0
-                "v_xor_b32 %1, %1, %5\n\t"             // c1 ^= k0
-                "v_and_b32 %5, %2, %6\n\t"             // k2 = c2 & k1
-                "v_xor_b32 %2, %2, %6\n\t"             // c2 ^= k1
-                "v_and_or_b32 %4, %3, %5, %4\n\t"      // ov |= c3 & k2
-                "v_xor_b32 %3, %3, %5"                   // c3 ^= k2
-                : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(ov), "=&v"(k0), "=&v"(k1)
-                : "v"(m));
-        }
-    }
-    return seed & (snap | count_le(c0, c1, c2, c3, ov, T - 1));
+    // counts up to 7 decide everything when T <= 8 (cap0 <= T - 1 <= 7): three slices + overflow
+    if (T <= 8) seed_filter_run<NB, 3, DUAL>(S, Q, kindB, lane, J, jb, cap0, mF, mB);
+    else seed_filter_run<NB, 4, DUAL>(S, Q, kindB, lane, J, jb, cap0, mF, mB);
 }
 
 // Scan the positions of [s, e) outside [xs, xe) (wo = word index of AbsLoc 0 of the chromosome).
@@ -597,9 +708,80 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
     for (int k = k0; k <= k1; k++) {
         const int cs = g0 + (k << PG_CHUNK_SHIFT);
         const int ns = s > cs ? s : cs;
-        const int ne = e < cs + (int)PG_CHUNK ? e : cs + (int)PG_CHUNK;
-        if (ns >= xs && ne <= xe) continue;                 // nothing new in this chunk
+        {
+            const int ne = e < cs + (int)PG_CHUNK ? e : cs + (int)PG_CHUNK;
+            if (ns >= xs && ne <= xe) continue;             // nothing new in this chunk
+        }
         const int wb = cs - 64 * NB;
+        if (MIXED && !(use_cache && k == 0)) {
+            // WIDE FAR-END WINDOWS (every chunk but the cached innermost one).  Two chunks at a time when the next
+            // one has work too: one LDS fill and, more importantly, one pass of fold_candidates for the handful
+            // of survivors of both.  (Its own loop: kept apart from the common path below, which it slowed down.)
+            int nh = 1;
+            if (k + 1 <= k1 && !(use_cache && k + 1 == 0)) {
+                const int c1 = cs + (int)PG_CHUNK;
+                const int ns1 = s > c1 ? s : c1, ne1 = e < c1 + (int)PG_CHUNK ? e : c1 + (int)PG_CHUNK;
+                if (!(ns1 >= xs && ne1 <= xe)) nh = 2;
+            }
+            const int ce = cs + nh * (int)PG_CHUNK;
+            const int ne = e < ce ? e : ce;
+            const int se = e_max < ce ? e_max : ce;
+            if (!(wo == S.win_wo && S.wbase == wb && se + 64 * NB <= S.win_hi))
+                stage_window<NB>(ref, S, wo, wb, se + 64 * NB, lane);
+            // a half's survivors get queue slots behind what is already waiting; a full queue is folded at once,
+            // the rest after the last half
+            int h = 0, end = 0, slot = 0;
+            u32 mF = 0u, mB = 0u, pos0 = 0u;
+            for (;;) {
+                while (mF != 0u && slot < WAVE) {
+                    const int bit = __ffs((int)mF) - 1;
+                    mF &= mF - 1u;
+                    S.queue[slot] = (uint16_t)((pos0 + (u32)bit) << 1);
+                    slot++;
+                }
+                while (mF == 0u && mB != 0u && slot < WAVE) {
+                    const int bit = __ffs((int)mB) - 1;
+                    mB &= mB - 1u;
+                    S.queue[slot] = (uint16_t)(((pos0 + (u32)bit) << 1) | 1u);
+                    slot++;
+                }
+                int n;
+                if (end >= WAVE) n = WAVE;
+                else if (h < nh) {                            // every survivor so far is queued: the next half
+                    const int word = 64 * h + lane;
+                    const int pbase = cs + 32 * word;
+                    seed_filter<NB, true>(S, Q, false, true, word, mF, mB);
+#if defined(PG_DUP) && PG_DUP == 3
+                    u32 dF, dB;
+                    seed_filter<NB, true>(S, Q, false, true, opaque(word), dF, dB);
+                    mF &= dF | (u32)opaque(0);
+                    mB &= dB | (u32)opaque(0);
+#endif
+                    const u32 rmask = bits32(ns - pbase, ne - pbase) & ~bits32(xs - pbase, xe - pbase);
+                    mF &= rmask;
+                    mB &= rmask;
+                    const u32 cnt = (u32)(__popc(mF) + __popc(mB));
+                    const u32 incl = wave_scan(cnt);
+                    slot = end + (int)(incl - cnt);
+                    end += (int)read_lane(incl, 63);
+                    pos0 = (u32)(64 * NB + 32 * word);
+                    h++;
+                    continue;
+                }
+                else if (end > 0) n = end;
+                else break;
+                S.nsurv += n;
+                S.nsurv_total += n;
+                __syncthreads();
+                fold_candidates<NB, Id, MIXED>(S, Q, A, wb, origin, region, n, lane);
+                slot -= n;
+                end -= n;
+                if (end == 0 && h == nh) break;
+            }
+            k += nh - 1;
+            continue;
+        }
+        const int ne = e < cs + (int)PG_CHUNK ? e : cs + (int)PG_CHUNK;
         // The chunk must be resident up to e_max, not just up to this call's end: the filter masks of the
         // innermost far-end chunk are computed once for all nested ranges, and an earlier fill with the same
         // base (a close-end window that happens to start where this chunk starts) may be shorter.
@@ -615,28 +797,27 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
         const u32 rmask = bits32(ns - pbase, ne - pbase) & ~bits32(xs - pbase, xe - pbase);
         const bool cached = use_cache && k == 0 && cache_valid;
         u32 mF = 0u, mB = 0u;
-        if (Q.allowF) {
-            if (cached) mF = cacheF;
-            else {
-                mF = seed_filter<NB>(S, Q, false, lane);
+        if (cached) {
+            mF = cacheF;
+            mB = cacheB;
+        } else {
+            if (MIXED) {
+                // far end: kind B reads the complement of what kind F reads (cF != cB), both kinds in one pass
+                seed_filter<NB, true>(S, Q, false, false, lane, mF, mB);
+            } else {
+                u32 unused;
+                if (Q.allowF) seed_filter<NB, false>(S, Q, false, false, lane, mF, unused);
+                if (Q.allowB) seed_filter<NB, false>(S, Q, true, false, lane, mB, unused);
 #if defined(PG_DUP) && PG_DUP == 3
-                mF &= seed_filter<NB>(S, Q, false, opaque(lane)) | (u32)opaque(0);
+                u32 d = 0u;
+                if (Q.allowF) { seed_filter<NB, false>(S, Q, false, false, opaque(lane), d, unused); mF &= d | (u32)opaque(0); }
+                if (Q.allowB) { seed_filter<NB, false>(S, Q, true, false, opaque(lane), d, unused); mB &= d | (u32)opaque(0); }
 #endif
-                if (use_cache && k == 0) cacheF = mF;
             }
-            mF &= rmask;
+            if (use_cache && k == 0) { cacheF = mF; cacheB = mB; }
         }
-        if (Q.allowB) {
-            if (cached) mB = cacheB;
-            else {
-                mB = seed_filter<NB>(S, Q, true, lane);
-#if defined(PG_DUP) && PG_DUP == 3
-                mB &= seed_filter<NB>(S, Q, true, opaque(lane)) | (u32)opaque(0);
-#endif
-                if (use_cache && k == 0) cacheB = mB;
-            }
-            mB &= rmask;
-        }
+        mF &= rmask;
+        mB &= rmask;
         if (use_cache && k == 0) cache_valid = true;
         // queue slots: exclusive prefix sum of the per-lane survivor counts (a lane's F survivors first)
         const u32 cnt = (u32)(__popc(mF) + __popc(mB));
@@ -750,8 +931,9 @@ __device__ __forceinline__ void evaluate(Search &S, const Acc<NB, Id> &A, u32 mm
     }
     if (S.want_cap) {
         // max over L in [bps, J] of the lowest level present (none present: no bound), + ADD; J as in seed_filter
+        // for the chunks of wide windows (the only ones filtered after an evaluation)
         int J = S.len - 1 < 32 ? S.len - 1 : 32;
-        if (J > PG_SEED_J(S.T)) J = PG_SEED_J(S.T);
+        if (J > PG_SEED_J(S.T) + PG_SEED_J_WIDE) J = PG_SEED_J(S.T) + PG_SEED_J_WIDE;
         u32 v = (S.bps + lane <= J) ? t1 : 0u;
         // (each shift is taken once, outside the select: a DPP read under a diverged EXEC mask sees 0 in the
         // lanes that are switched off)
@@ -1190,6 +1372,7 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
     S.win = lds.win;
     S.bufA = lds.bufA;
     S.bufB = lds.bufB;
+    S.hdrB = lds.hdrB;
     S.accB = lds.accB;
     S.mm_bp = lds.mm_bp;
     S.add_mm = prm.add_mm;
