@@ -166,13 +166,42 @@ template <int NB> __device__ __forceinline__ u64 q_oo(const Query<NB> &Q, int b)
 
 // Static LDS of a workgroup (one wave).  Static, not dynamic: every address below is a compile-time constant,
 // which keeps the five base pointers out of the scalar registers the kernel is short of.
-template <int NB>
+// The reduction state of one length in LDS (rounds >= 1): 8 bytes with 32-bit ids -- m1 | min(m2, 0x7fff) << 16 |
+// ok << 31, id (levels are mismatch counts <= the read length; PG_BIG only means "none") -- 16 bytes with 64-bit ids.
+template <typename Id> struct AccB;
+template <> struct AccB<u32> {
+    typedef uint2 T;
+    static __device__ __forceinline__ void load(const void *base, int i, u32 &m1, u32 &m2, u32 &ok, u32 &id)
+    {
+        const uint2 st = ((const uint2 *)base)[i];
+        m1 = st.x & 0xffffu; m2 = (st.x >> 16) & 0x7fffu; ok = st.x >> 31; id = st.y;
+    }
+    static __device__ __forceinline__ void store(void *base, int i, u32 m1, u32 m2, u32 ok, u32 id)
+    {
+        const u32 c2 = m2 < 0x7fffu ? m2 : 0x7fffu;
+        ((uint2 *)base)[i] = make_uint2(m1 | (c2 << 16) | (ok << 31), id);
+    }
+};
+template <> struct AccB<u64> {
+    typedef uint4 T;
+    static __device__ __forceinline__ void load(const void *base, int i, u32 &m1, u32 &m2, u32 &ok, u64 &id)
+    {
+        const uint4 st = ((const uint4 *)base)[i];
+        m1 = st.x; m2 = st.y & 0xffffu; ok = st.y >> 16; id = (u64)st.z | ((u64)st.w << 32);
+    }
+    static __device__ __forceinline__ void store(void *base, int i, u32 m1, u32 m2, u32 ok, u64 id)
+    {
+        ((uint4 *)base)[i] = make_uint4(m1, m2 | (ok << 16), (u32)id, (u32)(id >> 32));
+    }
+};
+
+template <int NB, typename Id>
 struct Lds {
     uint4 win[PG_WIN_WORDS(NB)];              // staged window: code planes (lo, hi, N)
     uint4 bufA[68];                           // tier A entries {mis0 lo, sne0 lo, id lo, meta}; scratch for the quarter merge
     uint4 bufB[64 * NB];                      // tier B entries: NB x {mis lo, mis hi, sne lo, sne hi} per candidate
     uint2 hdrB[64];                           // ... and their {id lo, meta}
-    uint4 accB[NB > 1 ? 64 * (NB - 1) : 1];   // reduction state of the rounds >= 1 {m1, m2 | ok << 16, id lo, id hi}
+    typename AccB<Id>::T accB[NB > 1 ? 64 * (NB - 1) : 1];   // reduction state of the rounds >= 1 (AccB)
     u64 qp[2 * 4 * NB];                       // the read's bit planes, two orientations
     uint16_t queue[64];                       // survivors of the prefilter for one candidate pass: (window position << 1) | kind
     u32 mm_bp[PG_MM_BREAKS];                  // breakpoints of g_maxMismatch (copied from the kernel arguments)
@@ -185,7 +214,7 @@ struct Search {
     uint4 *bufA;
     uint4 *bufB;
     uint2 *hdrB;
-    uint4 *accB;
+    void *accB;
     const u32 *mm_bp;    // LDS copy of PgDevParams::mm_bp
     // what the LDS window currently holds: bases [win_lo, win_hi) of the chromosome whose AbsLoc 0 is
     // at word index win_wo; the first staged base is wbase = win_lo (any alignment)
@@ -397,9 +426,7 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
         if (r > 0) {
             m1 = m2 = PG_BIG; ok = 0u; wid = 0;
             if ((A.dirty >> r) & 1u) {
-                const uint4 st = S.accB[(r - 1) * 64 + lB];
-                m1 = st.x; m2 = st.y & 0xffffu; ok = st.y >> 16;
-                wid = sizeof(Id) == 8 ? (Id)((u64)st.z | ((u64)st.w << 32)) : (Id)st.z;
+                AccB<Id>::load(S.accB, (r - 1) * 64 + lB, m1, m2, ok, wid);
             }
         }
         while (mask != 0ull) {
@@ -424,7 +451,7 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
         }
         if (r == 0) { A.m1 = m1; A.m2 = m2; A.ok = ok; A.id = wid; }
         else {
-            S.accB[(r - 1) * 64 + lB] = make_uint4(m1, m2 | (ok << 16), (u32)wid, (u32)((u64)wid >> 32));
+            AccB<Id>::store(S.accB, (r - 1) * 64 + lB, m1, m2, ok, wid);
             A.dirty |= 1u << r;
         }
     }
@@ -714,11 +741,11 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
         }
         const int wb = cs - 64 * NB;
         if (MIXED && !(use_cache && k == 0)) {
-            // WIDE FAR-END WINDOWS (every chunk but the cached innermost one).  Two chunks at a time when the next
-            // one has work too: one LDS fill and, more importantly, one pass of fold_candidates for the handful
+            // WIDE FAR-END WINDOWS (every chunk but the cached innermost one).  Two chunks at a time (PG_PAIR_CHUNKS)
+            // when the next one has work too: one LDS fill and, more importantly, one pass of fold_candidates for the handful
             // of survivors of both.  (Its own loop: kept apart from the common path below, which it slowed down.)
             int nh = 1;
-            if (k + 1 <= k1 && !(use_cache && k + 1 == 0)) {
+            if (PG_PAIR_CHUNKS(NB) && k + 1 <= k1 && !(use_cache && k + 1 == 0)) {
                 const int c1 = cs + (int)PG_CHUNK;
                 const int ns1 = s > c1 ? s : c1, ne1 = e < c1 + (int)PG_CHUNK ? e : c1 + (int)PG_CHUNK;
                 if (!(ns1 >= xs && ne1 <= xe)) nh = 2;
@@ -965,9 +992,7 @@ __device__ __forceinline__ void evaluate(Search &S, const Acc<NB, Id> &A, u32 mm
             m1 = m2 = PG_BIG; ok = 0u; wid = 0;
             mmL = mm_of(S, L);
             if ((A.dirty >> r) & 1u) {                    // uniform
-                const uint4 st = S.accB[(r - 1) * 64 + lane];
-                m1 = st.x; m2 = st.y & 0xffffu; ok = st.y >> 16;
-                wid = sizeof(Id) == 8 ? (Id)((u64)st.z | ((u64)st.w << 32)) : (Id)st.z;
+                AccB<Id>::load(S.accB, (r - 1) * 64 + lane, m1, m2, ok, wid);
             }
         }
         const u32 lo = m1 <= (u32)S.M ? m1 : (u32)S.M + 1u;
@@ -1196,6 +1221,10 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                     Eval<NB, Id> E;
                     evaluate<NB, Id>(S, A, mm0, E, opaque(lane));
                     close_max = uni(E.max_len);
+#if defined(PG_STOP) && PG_STOP == 6
+                    if (lane == 0) B.out[rid].alg = (u32)(close_max + E.n_runs);   // diagnostics: first attempt incl. its evaluation
+                    return;
+#endif
                     if (uni(E.n_runs) > 0) {
                         u64 kept[NB];
                         n_close = uni(count_kept<NB, Id>(E, true, kept));
@@ -1205,12 +1234,15 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                         const u64 idl = (u64)E.id_last;
                         const int pl = w1s + (int)(u32)(idl & ((1ull << IdFmt<Id>::RB) - 1ull));
                         close_last = ((idl >> IdFmt<Id>::RB) & 1ull) ? (u32)(pl - close_max + 1) : (u32)(pl + close_max - 1);
+#if defined(PG_STOP) && PG_STOP == 7
+                        if (lane == 0) B.out[rid].alg = (u32)(n_close + close_max + close_last);   // diagnostics: + emission
+                        return;
+#endif
                         break;
                     }
                 }
-#if defined(PG_STOP) && PG_STOP == 6
-                if (lane == 0) B.out[rid].alg = (u32)(n_close + close_max + close_last);   // diagnostics: first attempt incl. evaluation
-                return;
+#if defined(PG_STOP) && (PG_STOP == 6 || PG_STOP == 7)
+                return;                                   // diagnostics: the first attempt found nothing
 #endif
             }
         }
@@ -1363,7 +1395,7 @@ template <int NB, typename Id, int mode>
 __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevRef ref, PgDevParams prm,
                                                          PgDevBatch B, uint32_t max_len, uint32_t levels)
 {
-    __shared__ Lds<NB> lds;
+    __shared__ Lds<NB, Id> lds;
     const int lane = threadIdx.x;
     if (lane < PG_MM_BREAKS) lds.mm_bp[lane] = prm.mm_bp[lane];
     __syncthreads();
@@ -1567,7 +1599,7 @@ extern "C" int pg_debug_occupancy(uint32_t max_len, uint32_t levels, int small_i
 {
     (void)max_len;
     (void)levels;
-    *lds_bytes = (unsigned)sizeof(Lds<2>);
+    *lds_bytes = (unsigned)sizeof(Lds<2, u32>);
     hipError_t e1, e2;
     if (small_ids) {
         e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(close_blocks, pg_search_kernel<2, u32, PG_MODE_CLOSE>, WAVE, 0);

@@ -36,3 +36,37 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/rp_write -
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/rp_calib -- python "$root/scripts/calib_fetch.py" > /tmp/rp_calib.log 2>&1
 python "$root/scripts/traffic_summary.py" /tmp/rp_fetch /tmp/rp_write /tmp/rp_calib "$reads" "$out/bench_under_rocprof.json" > "$out/hbm_traffic.json"
 cat "$out/hbm_traffic.json"
+
+# per-phase instruction counts: cumulative SQ_INSTS_* per read of builds that return early (-DPG_STOP=k, built
+# here by scripts/build_variant.sh stop$k -DPG_STOP=$k before the gpurun call)
+cd "$root" || exit 1
+{
+    echo "# cumulative instructions per read of builds that stop early (bench workload, $reads reads)"
+    echo "# stop1 = read planes loaded; stop2 = + close end, first attempt up to the end of its scan; stop6 = + its evaluation;"
+    echo "# stop7 = + emission of its points; stop3 = whole close end (retries included); stop4 = + far end up to the end of"
+    echo "# the first range's scan; stop5 = + its evaluation; full = the shipped kernel"
+    for k in 1 2 6 7 3 4 5; do
+        [ -f pindel_amd/libpindel_pg_stop$k.so ] || continue
+        echo "stop$k"
+        bash scripts/pmc_pass.sh pindel_amd/libpindel_pg_stop$k.so "$reads" | grep -E "VALU|SALU|INSTS_LDS|VMEM"
+    done
+    echo "full"
+    bash scripts/pmc_pass.sh pindel_amd/libpindel_pg.so "$reads" | grep -E "VALU|SALU|INSTS_LDS|VMEM"
+} > "$out/phase_instruction_counts.txt"
+
+# the other workloads and parameter points quoted in DESIGN.md section 8 (one bench line each)
+{
+    for w in colo-bd repeat-rich wgs-bins grch38-150; do
+        python bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-host-path 2>/dev/null | tail -1
+    done
+    python bench.py --steps 3 --warmup 1 --max-range-index 5 --reads 2000000 --no-cpu-baseline --no-host-path 2>/dev/null | tail -1
+    python bench.py --steps 3 --warmup 1 --read-len 150 --no-cpu-baseline --no-host-path 2>/dev/null | tail -1
+    python bench.py --steps 3 --warmup 1 --read-len 250 --reads 4000000 --no-cpu-baseline --no-host-path 2>/dev/null | tail -1
+} > "$out/bench_workloads.jsonl"
+python - "$out/bench_workloads.jsonl" <<'PY'
+import json, sys
+for l in open(sys.argv[1]):
+    if l.startswith("{"):
+        d = json.loads(l)
+        print(d["config"]["workload"][:70], "|", round(d["value"] / 1e6, 1), "M reads/s | cand/read", round(d["config"].get("candidates_per_read", 0), 1))
+PY
