@@ -9,7 +9,10 @@ pytestmark = pytest.mark.gpu
 
 # 61026: a close-end window (R = 1) that starts exactly where the innermost far-end chunk starts -- the chunk
 # must be re-staged to its full extent before the filter masks of all nested ranges are computed
-@pytest.mark.parametrize("seed", [1000, 1006, 1011, 1015, 1020, 1029, 1038, 2024, 61026])
+# 5002 / 5015 / 5027: -x 3 / 4, the state-dependent bound of the seed filter (a DPP shift under a diverged EXEC mask
+# once made it too tight); 1011 / 8018 / 200203: more than 64 survivors in the first of two paired chunks of a wide
+# far-end window (the rest of the first half must be queued before the second half is filtered)
+@pytest.mark.parametrize("seed", [1000, 1006, 1011, 1015, 1020, 1029, 1038, 2024, 61026, 5002, 5015, 5027, 8018, 200203])
 def test_fuzz_seed(seed):
     assert one_iteration(seed, verbose=False)
 
@@ -19,4 +22,11 @@ def test_fuzz_seed(seed):
 @pytest.mark.parametrize("block", range(6))
 def test_fuzz_block(block):
     for seed in range(3000 + 10 * block, 3010 + 10 * block):
+        assert one_iteration(seed, verbose=False), seed
+
+
+# ... and 20 seeds of the wide stream (-x up to 6, more insert sizes: scripts/fuzz_parity.py, seeds >= 200000)
+@pytest.mark.parametrize("block", range(2))
+def test_fuzz_block_wide(block):
+    for seed in range(200400 + 10 * block, 200410 + 10 * block):
         assert one_iteration(seed, verbose=False), seed
