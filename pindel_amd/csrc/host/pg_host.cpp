@@ -108,6 +108,26 @@ Caller::Caller(const Settings &s, const std::vector<Chromosome> *g, const std::s
     }
 }
 
+Caller::~Caller() { flush_reports(); }
+
+std::ofstream &Caller::report(int which)
+{
+    static const char *suffixes[REP_N] = { "_D", "_SI", "_TD", "_INV" };
+    std::ofstream &f = rep_[which];
+    if (!f.is_open()) {
+        rep_buf_[which].resize(4u << 20);
+        f.rdbuf()->pubsetbuf(rep_buf_[which].data(), (std::streamsize)rep_buf_[which].size());
+        f.open((prefix + suffixes[which]).c_str(), std::ios::app);
+    }
+    return f;
+}
+
+void Caller::flush_reports()
+{
+    for (int i = 0; i < REP_N; i++)
+        if (rep_[i].is_open()) rep_[i].flush();
+}
+
 void Caller::note_close_mapped(SplitRead &r)
 {
     // ReadInRead, src/reader.cpp:262-288
@@ -194,16 +214,16 @@ std::string Caller::support_columns(const std::vector<SplitRead> &ev, unsigned s
 // OutputDeletions, src/reporter.cpp:271-444
 void Caller::output_deletion(Ctx &c, std::vector<SplitRead> &g, unsigned s, unsigned e, unsigned rs, unsigned re)
 {
-    std::ofstream out((prefix + "_D").c_str(), std::ios::app);
+    std::ofstream &out = report(REP_D);
     const std::string &ref = c.chrom->seq;
     const SplitRead &f = g[s];
     unsigned n_reads = 0;
     std::string sup = support_columns(g, s, e, f.BPLeft, f.BPRight, n_reads);
     short gap = f.IndelSize < 14 ? (short)f.IndelSize : (short)(13 + (int)log10((double)(f.IndelSize - 10)));
-    out << HASHES << std::endl;
+    out << HASHES << '\n';
     out << (d_template + d_nontemplate) << "\tD " << f.IndelSize << "\tNT " << f.NT_size << " \"" << f.NT_str
         << "\"\tChrID " << f.FragName << "\tBP " << f.BPLeft + 1 << "\t" << f.BPRight + 1 << "\tBP_range "
-        << rs + 1 << "\t" << re + 1 << sup << std::endl;
+        << rs + 1 << "\t" << re + 1 << sup << '\n';
     const long rl = g_reportLength;
     out << sub(ref, (long)f.Left - rl + f.BP + 1, rl);
     if (f.IndelSize >= 14) {
@@ -212,7 +232,7 @@ void Caller::output_deletion(Ctx &c, std::vector<SplitRead> &g, unsigned s, unsi
     } else {
         out << cap2low(sub(ref, (long)f.Left + f.BP + 1, gap));
     }
-    out << sub(ref, (long)f.Left + f.BP + 1 + f.IndelSize, rl - gap) << std::endl;
+    out << sub(ref, (long)f.Left + f.BP + 1 + f.IndelSize, rl - gap) << '\n';
     for (unsigned i = s; i <= e; i++) {
         const SplitRead &r = g[i];
         short before = (short)(rl - r.BP - 1);
@@ -221,31 +241,31 @@ void Caller::output_deletion(Ctx &c, std::vector<SplitRead> &g, unsigned s, unsi
         const std::string seq = r.MatchedD == '-' ? r.UnmatchedSeq : reverse_complement(r.UnmatchedSeq);
         out << sub(seq, 0, r.BP + 1) << std::string(gap > 0 ? gap : 0, ' ')
             << sub(seq, r.BP + 1, r.getReadLength() - r.BP);
-        out << std::string(after > 0 ? after : 0, ' ') << read_tail(r) << std::endl;
+        out << std::string(after > 0 ? after : 0, ' ') << read_tail(r) << '\n';
     }
 }
 
 // OutputDI, src/reporter.cpp:757-872
 void Caller::output_di(Ctx &c, std::vector<SplitRead> &g, unsigned s, unsigned e)
 {
-    std::ofstream out((prefix + "_D").c_str(), std::ios::app);
+    std::ofstream &out = report(REP_D);
     const std::string &ref = c.chrom->seq;
     const SplitRead &f = g[s];
     unsigned n_reads = 0;
     std::string sup = support_columns(g, s, e, f.BPLeft, f.BPRight, n_reads);
-    out << HASHES << std::endl;
+    out << HASHES << '\n';
     out << (d_template + d_nontemplate) << "\tD " << f.IndelSize << "\tNT " << f.NT_size << " \"" << f.NT_str
         << "\"\tChrID " << f.FragName << "\tBP " << f.BPLeft + 1 << "\t" << f.BPRight + 1 << "\tBP_range "
-        << f.BPLeft + 1 << "\t" << f.BPRight + 1 << sup << std::endl;
+        << f.BPLeft + 1 << "\t" << f.BPRight + 1 << sup << '\n';
     const long rl = g_reportLength;
     out << sub(ref, (long)f.Left - rl + f.BP + 1, rl) << std::string(f.NT_size, ' ')
-        << sub(ref, (long)f.Left + f.BP + 1 + f.IndelSize, rl) << std::endl;
+        << sub(ref, (long)f.Left + f.BP + 1 + f.IndelSize, rl) << '\n';
     for (unsigned i = s; i <= e; i++) {
         const SplitRead &r = g[i];
         short before = (short)(rl - r.BP - 1);
         out << std::string(before > 0 ? before : 0, ' ');
         out << (r.MatchedD == '-' ? r.UnmatchedSeq : reverse_complement(r.UnmatchedSeq)) << "\t";
-        out << read_tail(r) << std::endl;
+        out << read_tail(r) << '\n';
     }
 }
 
@@ -267,25 +287,25 @@ static std::string consensus_inserted(const std::vector<SplitRead> &g, unsigned 
 // OutputSIs, src/reporter.cpp:630-755
 void Caller::output_si(Ctx &c, std::vector<SplitRead> &g, unsigned s, unsigned e, unsigned rs, unsigned re)
 {
-    std::ofstream out((prefix + "_SI").c_str(), std::ios::app);
+    std::ofstream &out = report(REP_SI);
     const std::string &ref = c.chrom->seq;
     const SplitRead &f = g[s];
     unsigned n_reads = 0;
     std::string sup = support_columns(g, s, e, f.BPLeft, f.BPRight, n_reads);
-    out << HASHES << std::endl;
+    out << HASHES << '\n';
     out << n_si << "\tI " << f.IndelSize << "\tNT " << f.IndelSize << " \"" << consensus_inserted(g, s, e)
         << "\"\tChrID " << f.FragName << "\tBP " << f.BPLeft + 1 << "\t" << f.BPRight + 1 << "\tBP_range "
-        << rs + 1 << "\t" << re + 1 << sup << std::endl;
+        << rs + 1 << "\t" << re + 1 << sup << '\n';
     const long rl = g_reportLength;
     out << sub(ref, (long)f.Left - rl + f.BP + 1, rl) << std::string(f.IndelSize, ' ')
-        << sub(ref, (long)f.Left + f.BP + 1, rl) << std::endl;
+        << sub(ref, (long)f.Left + f.BP + 1, rl) << '\n';
     for (unsigned i = s; i <= e; i++) {
         const SplitRead &r = g[i];
         short before = (short)(rl - r.BP - 1);
         out << std::string(before > 0 ? before : 0, ' ');
         out << (r.MatchedD == '-' ? r.UnmatchedSeq : reverse_complement(r.UnmatchedSeq));
         short after = (short)(rl + rl - before - r.getReadLength());
-        out << std::string(after > 0 ? after : 0, ' ') << read_tail(r) << std::endl;
+        out << std::string(after > 0 ? after : 0, ' ') << read_tail(r) << '\n';
     }
     n_si++;
 }
@@ -695,6 +715,8 @@ void Caller::process_window(const Chromosome &chrom, std::vector<SplitRead> &rea
     }
     search_variant(c, 1);
     lap("short insertions");
+    flush_reports();
+    lap("flush");
 }
 
 }  // namespace pgh

@@ -19,6 +19,7 @@
 #include <cstdint>
 #include <map>
 #include <set>
+#include <fstream>
 #include <string>
 #include <vector>
 
@@ -96,8 +97,16 @@ public:
     // g_reportLength, sample names.  Call once per read that has a close end.
     void note_close_mapped(SplitRead &r);
     unsigned long far_end_checksum = 0;
+    ~Caller();
 
 private:
+    // The four report files, opened once (append) with a large buffer and flushed at the end of every window.
+    // (The reference re-opens the file for every event and flushes every line; the bytes are the same.)
+    enum { REP_D = 0, REP_SI, REP_TD, REP_INV, REP_N };
+    std::ofstream rep_[REP_N];
+    std::vector<char> rep_buf_[REP_N];
+    std::ofstream &report(int which);
+    void flush_reports();
     Settings S;
     const std::vector<Chromosome> *genome;
     std::string prefix;

@@ -164,24 +164,24 @@ void Caller::search_tandem_dup_nt(Ctx &c)
 // OutputTDs, src/reporter.cpp:157-269
 void Caller::output_td(Ctx &c, std::vector<SplitRead> &g, unsigned s, unsigned e, unsigned, unsigned)
 {
-    std::ofstream out((prefix + "_TD").c_str(), std::ios::app);
+    std::ofstream &out = report(REP_TD);
     const std::string &ref = c.chrom->seq;
     const SplitRead &f = g[s];
     unsigned n_reads = 0;
     std::string sup = support_columns(g, s, e, f.BPLeft - 1, f.BPRight + 1, n_reads);
-    out << HASHES << std::endl;
+    out << HASHES << '\n';
     out << n_td << "\tTD " << f.IndelSize << "\tNT " << f.NT_size << " \"" << f.NT_str << "\"\tChrID "
         << f.FragName << "\tBP " << f.BPLeft << "\t" << f.BPRight + 2 << "\tBP_range " << f.BPLeft << "\t"
-        << f.BPRight + 2 << sup << std::endl;
+        << f.BPRight + 2 << sup << '\n';
     const long rl = g_reportLength;
     out << sub(ref, (long)f.BPRight + S.spacer - rl + 1, rl) << std::string(f.NT_size, ' ')
-        << cap2low(sub(ref, (long)f.BPLeft + S.spacer, rl)) << std::endl;
+        << cap2low(sub(ref, (long)f.BPLeft + S.spacer, rl)) << '\n';
     for (unsigned i = s; i <= e; i++) {
         const SplitRead &r = g[i];
         short before = (short)(rl - r.BP - 1);
         out << std::string(before > 0 ? before : 0, ' ');
-        out << (r.MatchedD == '-' ? r.UnmatchedSeq : reverse_complement(r.UnmatchedSeq)) << std::endl;
-        out << read_tail(r) << std::endl;
+        out << (r.MatchedD == '-' ? r.UnmatchedSeq : reverse_complement(r.UnmatchedSeq)) << '\n';
+        out << read_tail(r) << '\n';
     }
 }
 
@@ -415,7 +415,7 @@ void Caller::search_inversions_nt(Ctx &c)
 // OutputInversions, src/reporter.cpp:446-628
 void Caller::output_inv(Ctx &c, std::vector<SplitRead> &g, unsigned s, unsigned e, unsigned, unsigned)
 {
-    std::ofstream out((prefix + "_INV").c_str(), std::ios::app);
+    std::ofstream &out = report(REP_INV);
     const std::string &ref = c.chrom->seq;
     const SplitRead &f = g[s];
     short lnt = 0, rnt = 0;
@@ -434,13 +434,13 @@ void Caller::output_inv(Ctx &c, std::vector<SplitRead> &g, unsigned s, unsigned 
         }
     unsigned n_reads = 0;
     std::string sup = support_columns(g, s, e, f.BPLeft - 1, f.BPRight + 1, n_reads);
-    out << HASHES << std::endl;
+    out << HASHES << '\n';
     out << n_inv++ << "\tINV " << f.IndelSize << "\tNT " << lnt << ":" << rnt << " \"" << lstr << "\":\"" << rstr
         << "\"\tChrID " << f.FragName << "\tBP " << f.BPLeft + 1 - 1 << "\t" << f.BPRight + 1 + 1 << "\tBP_range "
-        << f.BPLeft + 1 - 1 << "\t" << f.BPRight + 1 + 1 << sup << std::endl;
+        << f.BPLeft + 1 - 1 << "\t" << f.BPRight + 1 + 1 << sup << '\n';
     const long rl = g_reportLength;
     out << sub(ref, (long)f.BPLeft + S.spacer - rl, rl) << std::string(lnt > 0 ? lnt : 0, ' ')
-        << cap2low(reverse_complement(sub(ref, (long)f.BPRight + 1 + S.spacer - rl, rl))) << std::endl;
+        << cap2low(reverse_complement(sub(ref, (long)f.BPRight + 1 + S.spacer - rl, rl))) << '\n';
     for (unsigned i = s; i <= e; i++) {
         const SplitRead &r = g[i];
         if (r.MatchedD != '+') continue;
@@ -450,11 +450,11 @@ void Caller::output_inv(Ctx &c, std::vector<SplitRead> &g, unsigned s, unsigned 
             out << reverse_complement(r.UnmatchedSeq) << std::string(r.BP > 0 ? r.BP : 0, ' ');
         else
             out << r.UnmatchedSeq;
-        out << read_tail(r) << std::endl;
+        out << read_tail(r) << '\n';
     }
-    out << DASHES << std::endl;
+    out << DASHES << '\n';
     out << cap2low(reverse_complement(sub(ref, (long)f.BPLeft + S.spacer, rl))) << std::string(rnt > 0 ? rnt : 0, ' ')
-        << sub(ref, (long)f.BPRight + 1 + S.spacer, rl) << std::endl;
+        << sub(ref, (long)f.BPRight + 1 + S.spacer, rl) << '\n';
     for (unsigned i = s; i <= e; i++) {
         const SplitRead &r = g[i];
         if (r.MatchedD != '-') continue;
@@ -464,32 +464,32 @@ void Caller::output_inv(Ctx &c, std::vector<SplitRead> &g, unsigned s, unsigned 
             out << r.UnmatchedSeq << std::string(r.BP > 0 ? r.BP : 0, ' ');
         else
             out << reverse_complement(r.UnmatchedSeq);
-        out << read_tail(r) << std::endl;
+        out << read_tail(r) << '\n';
     }
 }
 
 // OutputShortInversion, src/reporter.cpp:1588-1696
 void Caller::output_short_inv(Ctx &c, std::vector<SplitRead> &g, unsigned s, unsigned e)
 {
-    std::ofstream out((prefix + "_INV").c_str(), std::ios::app);
+    std::ofstream &out = report(REP_INV);
     const std::string &ref = c.chrom->seq;
     const SplitRead &f = g[s];
     unsigned n_reads = 0;
     std::string sup = support_columns(g, s, e, f.BPLeft, f.BPRight, n_reads);
-    out << HASHES << std::endl;
+    out << HASHES << '\n';
     out << n_inv++ << "\tINV " << f.IndelSize << "\tNT " << f.NT_size << " \"" << f.NT_str << "\"\tChrID "
         << f.FragName << "\tBP " << f.BPLeft + 1 << "\t" << f.BPRight + 1 << "\tBP_range " << f.BPLeft + 1 << "\t"
-        << f.BPRight + 1 << sup << std::endl;
+        << f.BPRight + 1 << sup << '\n';
     const long rl = g_reportLength;
     out << sub(ref, (long)f.Left - rl + f.BP + 1, rl)
         << cap2low(reverse_complement(sub(ref, (long)f.Left + f.BP + 1, f.NT_size)))
-        << sub(ref, (long)f.Left + f.BP + 1 + f.IndelSize, rl) << std::endl;
+        << sub(ref, (long)f.Left + f.BP + 1 + f.IndelSize, rl) << '\n';
     for (unsigned i = s; i <= e; i++) {
         const SplitRead &r = g[i];
         short before = (short)(rl - r.BP - 1);
         out << std::string(before > 0 ? before : 0, ' ');
         out << (r.MatchedD == '-' ? r.UnmatchedSeq : reverse_complement(r.UnmatchedSeq)) << "\t";
-        out << read_tail(r) << std::endl;
+        out << read_tail(r) << '\n';
     }
 }
 
