@@ -414,6 +414,15 @@ private:
 struct BamIngestSettings {
     unsigned min_anchor_quality = 0;   // -A  minimalAnchorQuality
     unsigned spacer = 100000;
+    int nm = 2;                        // -n  NM (isRefRead)
+    double max_mismatch_rate = 0.02;   // -u  MaximumAllowedMismatchRate (isRefRead)
+};
+
+// A read that supports the reference allele (REF_READ, pindel.h:199-212): what UpdateRefReadCoverage needs of it
+struct RefRead {
+    uint32_t pos;       // leftmost position of the read (BAM, 0-based)
+    uint16_t length;    // l_qseq
+    uint16_t tag;       // index into IngestedReads::ref_tags
 };
 
 // One window's split-read candidates of one or more BAM files: the SoA batch + what the reporters print.
@@ -422,6 +431,8 @@ struct IngestedReads {
     std::vector<std::string> names;    // "@qname/1"
     std::vector<int16_t> ms;           // mapping quality of the anchor
     std::vector<std::string> tags;     // sample tag of the BAM
+    std::vector<RefRead> ref_reads;    // RefSupportingReads of the window
+    std::vector<std::string> ref_tags; // their sample tags (RefRead::tag indexes this)
     size_t size() const { return names.size(); }
     void clear()
     {
@@ -430,6 +441,8 @@ struct IngestedReads {
         names.clear();
         ms.clear();
         tags.clear();
+        ref_reads.clear();
+        ref_tags.clear();
     }
 };
 
@@ -460,7 +473,9 @@ public:
             waiting.erase(it);
             if (is_weird(b2)) ok = ok && build_record(bam, b2, b2, chr_id, chr_padded_size, insert_size, tag, out);
             if (is_good_anchor(b1) && is_weird(b2)) ok = ok && build_record(bam, b1, b2, chr_id, chr_padded_size, insert_size, tag, out);
+            if (is_good_anchor(b1) && is_ref_read(b2)) add_ref_read(b2, tag, out);
             if (is_good_anchor(b2) && is_weird(b1)) ok = ok && build_record(bam, b2, b1, chr_id, chr_padded_size, insert_size, tag, out);
+            if (is_good_anchor(b2) && is_ref_read(b1)) add_ref_read(b1, tag, out);
         });
         if (!q) error = "BAM read failed";
         return q && ok;
@@ -499,6 +514,33 @@ private:
         const int nm = nm_of(b);
         if (nm) return true;
         return nm + cigar_mismatch(b) > 0;
+    }
+
+    // isRefRead (reader.cpp:620-656): a primary, non-duplicate, QC-passing mapped read with few edits (the NM tag
+    // against -n and against int(length * -u) + 1 when present; NM <= 2, <= 2 non-M CIGAR bases) and, when the
+    // CIGAR has more than two elements, no I or D among them
+    bool is_ref_read(const BamRecord &b) const
+    {
+        if (b.flag & (BAM_FSECONDARY | BAM_FQCFAIL | BAM_FDUP)) return false;
+        int64_t nm = 0;
+        if (b.aux_int("NM", nm)) {
+            const int max_edits = (int)(b.l_seq * S.max_mismatch_rate) + 1;
+            if (nm > S.nm || nm > max_edits) return false;
+        }
+        if (b.cigar.size() > 2)
+            for (uint32_t c : b.cigar)
+                if ((c & 15) == BAM_CINS || (c & 15) == BAM_CDEL) return false;
+        return !(b.flag & BAM_FUNMAP) && nm_of(b) <= 2 && cigar_mismatch(b) <= 2;
+    }
+    // build_record_RefRead (reader.cpp:903-923); the anchor only decides whether this is called
+    void add_ref_read(const BamRecord &ref, const std::string &tag, IngestedReads &out) const
+    {
+        if (ref.mapq < S.min_anchor_quality) return;
+        size_t t = 0;
+        while (t < out.ref_tags.size() && out.ref_tags[t] != tag) t++;
+        if (t == out.ref_tags.size()) out.ref_tags.push_back(tag);
+        RefRead r = { (uint32_t)ref.pos, (uint16_t)ref.l_seq, (uint16_t)t };
+        out.ref_reads.push_back(r);
     }
 
     // build_record_SR(mapped_read, unmapped_read): false only for the fatal "insert size <= read length"

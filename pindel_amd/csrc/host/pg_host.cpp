@@ -110,6 +110,27 @@ Caller::Caller(const Settings &s, const std::vector<Chromosome> *g, const std::s
 
 Caller::~Caller() { flush_reports(); }
 
+void Caller::update_ref_coverage(const std::vector<RefReadSpan> &reads, const std::vector<std::string> &tags,
+                                 unsigned start, unsigned end)
+{
+    std::vector<std::string> names(g_sampleNames.begin(), g_sampleNames.end());
+    cov_start_ = start;
+    ref_cov_.assign(names.size(), std::vector<int>());
+    std::vector<int> sample_of(tags.size(), -1);
+    for (size_t t = 0; t < tags.size(); t++)
+        for (size_t i = 0; i < names.size(); i++)
+            if (names[i] == tags[t]) sample_of[t] = (int)i;
+    const size_t length = (size_t)end - start + 1;
+    for (const RefReadSpan &r : reads) {
+        if (r.pos < start || (unsigned)(r.pos + r.length) > end) continue;
+        const int s = r.tag < sample_of.size() ? sample_of[r.tag] : -1;
+        if (s < 0) continue;           // a sample without any mapped split read yet (the reference dereferences end())
+        std::vector<int> &cov = ref_cov_[(size_t)s];
+        if (cov.empty()) cov.assign(length, 0);
+        for (unsigned k = 1; k + 1 < r.length; k++) cov[r.pos - start + k]++;
+    }
+}
+
 std::ofstream &Caller::report(int which)
 {
     static const char *suffixes[REP_N] = { "_D", "_SI", "_TD", "_INV" };
@@ -201,13 +222,17 @@ std::string Caller::support_columns(const std::vector<SplitRead> &ev, unsigned s
     o << "\tSupports " << n_reads << "\t" << n_u << "\t+ " << LeftS << "\t" << LeftU << "\t- " << RightS
       << "\t" << RightU << "\tS1 " << easy << "\tSUM_MS " << sum_ms << "\t" << names.size()
       << "\tNumSupSamples " << nsup << "\t" << nusup;
-    // reference-coverage columns: g_RefCoverageRegion is all zero without BAM ref-reads
-    // (UpdateRefReadCoverage, pindel.cpp:1272-1330); -1 outside the current bin
-    int cov_s = (bp_left + 2 >= g_RegionStart && bp_left + 2 < g_RegionEnd) ? 0 : -1;
-    int cov_e = (bp_right > g_RegionStart && bp_right < g_RegionEnd) ? 0 : -1;
+    // reference-coverage columns (update_ref_coverage; all zero for text input); -1 outside the current bin
+    const bool in_s = bp_left + 2 >= g_RegionStart && bp_left + 2 < g_RegionEnd;
+    const bool in_e = bp_right > g_RegionStart && bp_right < g_RegionEnd;
+    auto cov_at = [&](size_t sample, unsigned pos) -> int {      // g_RefCoverageRegion[pos - g_RegionStart]
+        if (sample >= ref_cov_.size() || ref_cov_[sample].empty()) return 0;
+        const size_t k = (size_t)pos - cov_start_;
+        return pos >= cov_start_ && k < ref_cov_[sample].size() ? ref_cov_[sample][k] : 0;
+    };
     for (size_t i = 0; i < names.size(); i++)
-        o << "\t" << names[i] << " " << cov_s << " " << cov_e << " " << sup[i].p << " " << sup[i].up << " "
-          << sup[i].m << " " << sup[i].um;
+        o << "\t" << names[i] << " " << (in_s ? cov_at(i, bp_left + 2) : -1) << " " << (in_e ? cov_at(i, bp_right) : -1)
+          << " " << sup[i].p << " " << sup[i].up << " " << sup[i].m << " " << sup[i].um;
     return o.str();
 }
 

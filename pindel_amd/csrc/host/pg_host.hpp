@@ -97,6 +97,13 @@ public:
     // g_reportLength, sample names.  Call once per read that has a close end.
     void note_close_mapped(SplitRead &r);
     unsigned long far_end_checksum = 0;
+    // UpdateRefReadCoverage (pindel.cpp:1272-1330), BAM input: per sample (in the order of the sample-name set as
+    // it stands now) the number of reference-supporting reads over every position of the window [start, end];
+    // a read counts from its second to its last-but-one base and only if it lies inside the window.  The two
+    // coverage integers per sample of every report header come from here (0 0 without it, as for text input).
+    struct RefReadSpan { uint32_t pos; uint16_t length; uint16_t tag; };
+    void update_ref_coverage(const std::vector<RefReadSpan> &reads, const std::vector<std::string> &tags,
+                             unsigned start, unsigned end);
     ~Caller();
 
 private:
@@ -116,6 +123,8 @@ private:
     unsigned n_si = 0, n_td = 0, n_inv = 0;
     unsigned BoxSize = 1;
     unsigned g_RegionStart = 0, g_RegionEnd = 0;
+    std::vector<std::vector<int>> ref_cov_;   // [sample][position - cov_start_]
+    unsigned cov_start_ = 0;
 
     struct Ctx;
     void search_variant(Ctx &c, int kind);

@@ -164,6 +164,19 @@ const char *pgh_bam_ingest_name(void *h, uint64_t i)
     return (r && i < r->names.size()) ? r->names[i].c_str() : nullptr;
 }
 
+// the reference-supporting reads of the window (isRefRead / build_record_RefRead): 3 values each (pos, length, tag index)
+uint64_t pgh_bam_ingest_ref_reads(void *h, uint32_t *out, uint64_t cap)
+{
+    pgh::IngestedReads *r = (pgh::IngestedReads *)h;
+    if (!r) return 0;
+    for (size_t i = 0; i < r->ref_reads.size() && i < cap; i++) {
+        out[3 * i] = r->ref_reads[i].pos;
+        out[3 * i + 1] = r->ref_reads[i].length;
+        out[3 * i + 2] = r->ref_reads[i].tag;
+    }
+    return r->ref_reads.size();
+}
+
 void pgh_bam_ingest_free(void *h) { delete (pgh::IngestedReads *)h; }
 
 // Read-pair discovery (pg_rp.hpp): the BreakDancer-like events of one window of one BAM.  out receives 4 values per

@@ -186,6 +186,15 @@ int run_bam_pipeline(const std::vector<Chromosome> &genome, const std::vector<un
                     caller.note_close_mapped(r);
                     kept.push_back(std::move(r));
                 }
+            {   // UpdateRefReadCoverage, after the close ends (sample names) and before the classifiers
+                std::vector<Caller::RefReadSpan> spans(in.ref_reads.size());
+                for (size_t i = 0; i < spans.size(); i++) {
+                    spans[i].pos = in.ref_reads[i].pos;
+                    spans[i].length = in.ref_reads[i].length;
+                    spans[i].tag = in.ref_reads[i].tag;
+                }
+                caller.update_ref_coverage(spans, in.ref_tags, ws, we);
+            }
             if (!kept.empty()) caller.process_window(chrom, kept, ws, we, bed_start, bed_end);
         }
     }

@@ -35,6 +35,7 @@ int main(int argc, char **argv)
     double t_search = 0.0;
     std::string fasta, reads_path, prefix, bd_path, bam_config;
     unsigned min_anchor_quality = 0;
+    int ref_read_nm = 2;                    // -n / --NM (isRefRead)
     bool search_rp = true;                 // -R: discordant read pairs as window hints (BAM input only; default true)
     bool use_bd = false;
     pg_params prm;
@@ -54,7 +55,7 @@ int main(int argc, char **argv)
         { "-d", "--min_num_matched_bases", 'i' }, { "-v", "--min_inversion_size", 'i' },
         { "-w", "--window_size", 'f' }, { "-T", "--number_of_threads", 'i' }, { "-b", "--breakdancer", 's' },
         { "-G", "--gpus", 's' }, { "", "--bd-hints", 's' }, { "-c", "--chromosome", 's' },
-        { "-n", "--min_NT_size", 'i' }, { "-A", "--anchor_quality", 'i' }, { "-L", "--logfilename", 's' },
+        { "-n", "--NM", 'i' }, { "", "--min_NT_size", 'i' }, { "-A", "--anchor_quality", 'i' }, { "-L", "--logfilename", 's' },
         { "-r", "--report_inversions", 'u' }, { "-t", "--report_duplications", 'u' },
         { "-l", "--report_long_insertions", 'u' }, { "-k", "--report_breakpoints", 'u' },
         { "-s", "--report_close_mapped_reads", 'u' }, { "-S", "--report_only_close_mapped_reads", 'u' },
@@ -109,6 +110,7 @@ int main(int argc, char **argv)
         else if (key == "-p") reads_path = v;
         else if (key == "-i") bam_config = v;
         else if (key == "-A") min_anchor_quality = (unsigned)iv;
+        else if (key == "-n") ref_read_nm = (int)iv;       // "-n" is registered twice in the reference; --NM comes first
         else if (key == "-o") prefix = v;
         else if (key == "-x") prm.max_range_index = (int)iv;
         else if (key == "-a") prm.additional_mismatch = (int)iv;
@@ -331,6 +333,8 @@ int main(int argc, char **argv)
         BamIngestSettings ing;
         ing.min_anchor_quality = min_anchor_quality;
         ing.spacer = prm.spacer;
+        ing.nm = ref_read_nm;
+        ing.max_mismatch_rate = prm.max_allowed_mismatch_rate;
         // BAM input: with -R (default) the window hints are live -- the events of a -b file plus the read-pair events of
         // every window; without -R the reference never hands any event to the search (UpdateBD is not called)
         use_bd = search_rp;

@@ -35,11 +35,14 @@ def _lib():
     L.pgh_bam_ingest_name.restype = C.c_char_p
     L.pgh_bam_ingest_name.argtypes = [C.c_void_p, C.c_uint64]
     L.pgh_bam_ingest_free.argtypes = [C.c_void_p]
+    L.pgh_bam_ingest_ref_reads.restype = C.c_uint64
+    L.pgh_bam_ingest_ref_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     return L
 
 
-def ingest(path, chr_name, chr_id, padded, ws, we, isz, tag="S", min_q=0, use_index=True):
-    """-> list of (name, seq, strand, pos, ms, isz, chr) in emission order"""
+def ingest(path, chr_name, chr_id, padded, ws, we, isz, tag="S", min_q=0, use_index=True, ref_reads=None):
+    """-> list of (name, seq, strand, pos, ms, isz, chr) in emission order; ref_reads (a list): receives the
+    (pos, length) of the reference-supporting reads of the window"""
     L = _lib()
     n, nb = C.c_uint64(), C.c_uint64()
     h = L.pgh_bam_ingest(str(path).encode(), chr_name.encode(), chr_id, padded, ws, we, isz, tag.encode(), min_q, 100000,
@@ -59,6 +62,11 @@ def ingest(path, chr_name, chr_id, padded, ws, we, isz, tag="S", min_q=0, use_in
                                    arr(ptr[5], np.int32, n), arr(ptr[6], np.int16, n))
     out = [(L.pgh_bam_ingest_name(h, i).decode(), seq[int(off[i]):int(off[i + 1])].tobytes().decode("latin1"),
             chr(strand[i]), int(np.uint32(pos[i])), int(ms[i]), int(iszs[i]), int(chrs[i])) for i in range(n)]
+    if ref_reads is not None:
+        k = int(L.pgh_bam_ingest_ref_reads(h, None, 0))
+        buf = np.zeros(3 * k, dtype=np.uint32)
+        L.pgh_bam_ingest_ref_reads(h, buf.ctypes.data, k)
+        ref_reads.extend((int(buf[3 * i]), int(buf[3 * i + 1])) for i in range(k))
     L.pgh_bam_ingest_free(h)
     return out
 
@@ -171,12 +179,49 @@ def _restated(records, tid, ws, we, isz, min_q, biol):
     return out
 
 
+def _ref_reads_restated(records, tid, ws, we, min_q, nm_max=2, rate=0.02):
+    """Independent restatement of isRefRead + build_record_RefRead as fetch_func_SR calls them (src/reader.cpp:620-656,
+    903-923, 1132-1147): (pos, length) of the reads that support the reference allele, in emission order."""
+    def end_pos(r):
+        if r["flag"] & F["UNMAP"] or not r["cigar"]:
+            return r["pos"] + 1
+        return r["pos"] + (sum(n for op, n in r["cigar"] if op in (0, 2, 3, 7, 8)) or 1)
+
+    def good_anchor(r):
+        if r["flag"] & F["UNMAP"] or r.get("mapq", 0) < min_q:
+            return False
+        return min_q == 0 or not (r["flag"] & (F["SECONDARY"] | F["QCFAIL"] | F["DUP"]))
+
+    def is_ref(r):
+        if r["flag"] & (F["SECONDARY"] | F["QCFAIL"] | F["DUP"]):
+            return False
+        tags = r.get("tags") or {}
+        if "NM" in tags and (tags["NM"] > nm_max or tags["NM"] > int(len(r["seq"]) * rate) + 1):
+            return False
+        if len(r["cigar"]) > 2 and any(op in (1, 2) for op, _ in r["cigar"]):
+            return False
+        return (not r["flag"] & F["UNMAP"]) and tags.get("NM", 0) <= 2 and sum(n for op, n in r["cigar"] if op != 0) <= 2
+
+    out, waiting = [], {}
+    for b1 in records:
+        if b1["tid"] != tid or not (b1["pos"] < we and end_pos(b1) > ws):
+            continue
+        b2 = waiting.pop(b1["qname"], None)
+        if b2 is None:
+            waiting[b1["qname"]] = b1
+            continue
+        for anchor, ref in ((b1, b2), (b2, b1)):
+            if good_anchor(anchor) and is_ref(ref) and ref.get("mapq", 0) >= min_q:
+                out.append((ref["pos"], len(ref["seq"])))
+    return out
+
+
 def _messy_records(rng, n_pairs, ref_len, tid=0):
     recs = []
     for k in range(n_pairs):
         pos = int(rng.integers(100, ref_len - 400))
         qn = f"q{k}"
-        kind = int(rng.integers(0, 8))
+        kind = int(rng.integers(0, 11))
         seq = "".join(rng.choice(list("ACGT"), 100))
         if rng.random() < 0.1:                                        # N's: ends (trimmed) and inside (10 % rule)
             nn = int(rng.integers(1, 16))
@@ -202,6 +247,13 @@ def _messy_records(rng, n_pairs, ref_len, tid=0):
             a["flag"] |= F["DUP"] if rng.random() < 0.5 else F["SECONDARY"]
         elif kind == 6:                                                # short read: dropped (< 22 bases)
             u["seq"] = seq[:int(rng.integers(5, 30))]
+        elif kind == 8:                                                # mapped mate with 0-4 edits: a reference read up to 2
+            u.update(flag=flags_u, pos=pos + 180, mapq=int(rng.choice([5, 30, 60])), cigar=[(0, len(seq))],
+                     tags={"NM": int(rng.integers(0, 5))} if rng.random() < 0.8 else None)
+        elif kind == 9:                                                # one-base indel: three CIGAR elements = HasIndel
+            u.update(flag=flags_u, pos=pos + 220, mapq=60, cigar=[(0, 50), (1, 1), (0, len(seq) - 51)], tags={"NM": 1})
+        elif kind == 10:                                               # two CIGAR elements: not "HasIndel", still few edits
+            u.update(flag=flags_u, pos=pos + 240, mapq=60, cigar=[(0, len(seq) - 1), (1, 1)], tags={"NM": 1})
         first_unmapped = kind == 7 or rng.random() < 0.2              # unmapped mate BEFORE its anchor in the file
         recs.append((min(a["pos"], u["pos"]), k, [u, a] if first_unmapped and u["pos"] == a["pos"] else sorted([a, u], key=lambda r: r["pos"])))
     recs.sort(key=lambda t: (t[0], t[1]))
@@ -221,15 +273,19 @@ def test_selection_rules_match_the_restatement_and_index_equals_scan(tmp_path, m
     bw.write_bam(str(bam), [("chrM", 16000), ("chrZ", ref_len)], [dict(r, tid=1, mtid=1) for r in recs], with_index=True,
                  block_bytes=0x9000)
     padded = ref_len + 200000
-    total = 0
+    total = total_refs = 0
     for ws, we in ((0, 500_000), (500_000, 1_000_000), (1_000_000, 2_300_000), (123_456, 130_000), (2_299_000, 2_300_000)):
         want = _restated([dict(r, tid=1) for r in recs], 1, ws, we, 450, min_q, ref_len)
-        by_index = ingest(bam, "chrZ", 1, padded, ws, we, 450, min_q=min_q, use_index=True)
-        by_scan = ingest(bam, "chrZ", 1, padded, ws, we, 450, min_q=min_q, use_index=False)
-        assert by_index == by_scan
+        refs_index, refs_scan = [], []
+        by_index = ingest(bam, "chrZ", 1, padded, ws, we, 450, min_q=min_q, use_index=True, ref_reads=refs_index)
+        by_scan = ingest(bam, "chrZ", 1, padded, ws, we, 450, min_q=min_q, use_index=False, ref_reads=refs_scan)
+        assert by_index == by_scan and refs_index == refs_scan
+        want_refs = _ref_reads_restated([dict(r, tid=1) for r in recs], 1, ws, we, min_q)
+        assert refs_index == want_refs
+        total_refs += len(want_refs)
         assert [(g[0], g[1], g[2], g[3], g[4], g[5]) for g in by_index] == [w[:6] for w in want]
         total += len(want)
-    assert total > 2000
+    assert total > 2000 and total_refs > 500
     assert ingest(bam, "chrM", 0, 16000 + 200000, 0, 16000, 450) == []
     assert ingest(bam, "nope", 5, 1_000_000, 0, 16000, 450) == []
 
@@ -262,6 +318,59 @@ def test_command_line_bam_input_reproduces_gold_reports(tmp_path):
     assert out.returncode == 0, out.stderr
     assert "14862 reads, close end 14862, far end 10968" in out.stdout
     gu.assert_reports_match_gold(prefix)
+
+
+@pytest.mark.gpu
+def test_command_line_bam_reference_coverage_columns(tmp_path):
+    """The two per-sample reference-coverage integers of the report headers (BAM input only: isRefRead /
+    build_record_RefRead / UpdateRefReadCoverage, src/reader.cpp:620-656, 903-923, src/pindel.cpp:1272-1330;
+    reporter.cpp:352-382): the gold reads as a BAM plus clean read pairs that support the reference.  Everything but
+    the two integers must still equal gold; the integers must equal the coverage restated here."""
+    import re
+    import subprocess
+    from pindel_amd import binding
+    fa, _ = gu.unpack(tmp_path)
+    recs = _pairs_for_text_records(_gold_text_records())
+    rng = np.random.default_rng(77)
+    cov = np.zeros(200_002, dtype=np.int64)
+    extra = []
+    for k in range(12000):
+        pos = int(rng.integers(500, 198_000))
+        mpos = pos + int(rng.integers(150, 400))
+        kind = int(rng.integers(0, 6))
+        tags_b = {"NM": 0} if kind == 0 else {"NM": 2} if kind == 1 else {"NM": 3} if kind == 2 else None
+        dup = F["DUP"] if kind == 3 else 0
+        a = dict(qname=f"ref{k}", flag=F["PAIRED"] | F["READ1"] | F["MREVERSE"], tid=0, pos=pos, mapq=60, cigar=[(0, 100)],
+                 seq="ACGT" * 25, mtid=0, mpos=mpos)
+        b = dict(qname=f"ref{k}", flag=F["PAIRED"] | F["READ2"] | F["REVERSE"] | dup, tid=0, pos=mpos, mapq=60,
+                 cigar=[(0, 90)] if kind == 4 else [(0, 100)], mtid=0, mpos=pos, tags=tags_b,
+                 # (reads with NM > 0 are split-read candidates too: all-N bases keep them out of the reports)
+                 seq=("ACGT" * 25)[:90] if kind == 4 else "N" * 100 if kind in (1, 2) else "ACGT" * 25)
+        extra += [a, b]
+        cov[pos + 1:pos + 99] += 1                                    # a: clean, always a reference read
+        if kind not in (2, 3):                                        # b: NM 3 > -n 2 and duplicates are not
+            n = len(b["seq"])
+            cov[mpos + 1:mpos + n - 1] += 1
+    bam = tmp_path / "gold_plus_ref.bam"
+    bw.write_bam(str(bam), [("1", 200000)], recs + extra, with_index=False)
+    cfg = tmp_path / "config.txt"
+    cfg.write_text("gold_plus_ref.bam\t500\tSIM1CHRVS2\n")
+    exe = os.path.join(os.path.dirname(binding.LIB_PATH), "pindel_pg")
+    prefix = str(tmp_path / "cov")
+    out = subprocess.run([exe, "-f", fa, "-i", str(cfg), "-o", prefix, "-T", "2", "-R", "false"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "14862 reads, close end 14862, far end 10968" in out.stdout
+    gu.assert_reports_match_gold(prefix)                               # (the comparison masks the two integers)
+    checked = 0
+    for suf, off_s, off_e in (("D", 1, -1), ("SI", 1, -1)):           # cov[BPLeft + 2], cov[BPRight]; BP printed 1-based
+        for line in open(f"{prefix}_{suf}"):
+            m = re.match(r"^\d+\t(?:D|I) .*\tBP (\d+)\t(\d+)\tBP_range .*\tSIM1CHRVS2 (-?\d+) (-?\d+) ", line)
+            if not m:
+                continue
+            bp1, bp2, cs, ce = (int(x) for x in m.groups())
+            assert (cs, ce) == (int(cov[bp1 + off_s]), int(cov[bp2 + off_e])), line[:200]
+            checked += 1
+    assert checked >= 10 and cov.max() > 5
 
 
 # ------------------------------------------------------------------------------------------ read-pair discovery (-R)
