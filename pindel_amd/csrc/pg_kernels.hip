@@ -512,8 +512,29 @@ __device__ __forceinline__ u32 count_le(u32 c0, u32 c1, u32 c2, u32 c3, u32 ov, 
 
 // Bit-sliced mismatch counter of the seed filter: NS slices + a sticky overflow bit per position.  Bases are
 // added one, two or three at a time (carry-save: the sum bits of two or three match masks first, then one
-// ripple through the slices -- 7, 4.5 and 3.7 VALU instructions per base).  m* are MATCH masks.  Written as asm
-// because the compiler's version of the same ripple rotates the counter through extra v_mov.
+// ripple through the slices -- 7, 4.5 and 3.7 VALU instructions per base).  Each add is ONE asm statement that
+// also takes the base(s) off the wave-uniform set (s_ff1 / s_bitset0) and shifts the planes (v_alignbit):
+// the compiler's version of the ripple rotates the counter through extra v_mov, and it pads every asm
+// statement with an s_nop, so fewer, larger statements are cheaper.
+#define PG_TAKE(j) "s_ff1_i32_b32 %[" j "], %[pm]\n\ts_bitset0_b32 %[pm], %[" j "]\n\t"
+#define PG_SHIFT(m, j) "v_alignbit_b32 %[" m "], %[hi], %[lo], %[" j "]\n\t"
+#define PG_MIRROR(t, j) "s_sub_i32 %[" t "], 32, %[" j "]\n\t"      // (writes SCC: the statements using it clobber "scc")
+// one base: k0 = ~ma & c0, c0 ^= ~ma, k1 = c1 & k0, c1 ^= k0
+#define PG_ADD1 "v_bfi_b32 %[k0], %[ma], 0, %[c0]\n\tv_xnor_b32 %[c0], %[c0], %[ma]\n\t" \
+                "v_and_b32 %[k1], %[c1], %[k0]\n\tv_xor_b32 %[c1], %[c1], %[k0]\n\t"
+// two bases: sum of the two mismatch bits = low bit ma ^ mb, high bit ~(ma | mb); the high bit and the carry out
+// of slice 0 exclude each other, so slice 1 adds t = high | carry
+#define PG_ADD2 "v_bitop3_b32 %[k0], %[c0], %[ma], %[mb] bitop3:0x60\n\tv_bitop3_b32 %[c0], %[c0], %[ma], %[mb] bitop3:0x96\n\t" \
+                "v_bitop3_b32 %[s0], %[ma], %[mb], %[k0] bitop3:0xab\n\t" \
+                "v_and_b32 %[k1], %[c1], %[s0]\n\tv_xor_b32 %[c1], %[c1], %[s0]\n\t"
+// three bases: s0 = ~(ma ^ mb ^ mc), s1 = ~maj(ma, mb, mc), then a full adder per slice
+#define PG_ADD3 "v_bitop3_b32 %[s0], %[ma], %[mb], %[mc] bitop3:0x69\n\tv_bitop3_b32 %[s1], %[ma], %[mb], %[mc] bitop3:0x17\n\t" \
+                "v_and_b32 %[k0], %[c0], %[s0]\n\tv_xor_b32 %[c0], %[c0], %[s0]\n\t" \
+                "v_bitop3_b32 %[k1], %[c1], %[s1], %[k0] bitop3:0xe8\n\tv_bitop3_b32 %[c1], %[c1], %[s1], %[k0] bitop3:0x96\n\t"
+// the carry out of slice 1 (k1) through the upper slice(s)
+#define PG_UP3 "v_and_or_b32 %[ov], %[c2], %[k1], %[ov]\n\tv_xor_b32 %[c2], %[c2], %[k1]"
+#define PG_UP4 "v_and_b32 %[k0], %[c2], %[k1]\n\tv_xor_b32 %[c2], %[c2], %[k1]\n\t" \
+               "v_and_or_b32 %[ov], %[c3], %[k0], %[ov]\n\tv_xor_b32 %[c3], %[c3], %[k0]"
 template <int NS>
 struct Counter {
     u32 c0, c1, c2, c3, ov;
@@ -522,110 +543,113 @@ struct Counter {
     {
         return thr < 0 ? 0u : count_le(c0, c1, c2, NS == 4 ? c3 : 0u, ov, thr);
     }
-    // the carry out of slice 1 (k1) through the upper slices
-    __device__ __forceinline__ void upper(u32 k1)
+#define PG_CTR3 [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2), [ov] "+v"(ov)
+#define PG_CTR4 [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2), [c3] "+v"(c3), [ov] "+v"(ov)
+#define PG_PLANES [lo] "v"(lo), [hi] "v"(hi)
+    // --- the lowest base(s) of pm (removed from it), planes shifted by the base's bit: returns the bit(s)
+    __device__ __forceinline__ void take1(u32 &pm, u32 lo, u32 hi, u32 &ja)
     {
-        if (NS == 3) {
-            asm("v_and_or_b32 %1, %0, %2, %1\n\t"        // ov |= c2 & k1
-                "v_xor_b32 %0, %0, %2"                      // c2 ^= k1
-                : "+v"(c2), "+v"(ov) : "v"(k1));
-        } else {
-            u32 k2;
-            asm("v_and_b32 %3, %0, %4\n\t"                // k2 = c2 & k1
-                "v_xor_b32 %0, %0, %4\n\t"                // c2 ^= k1
-                "v_and_or_b32 %2, %1, %3, %2\n\t"         // ov |= c3 & k2
-                "v_xor_b32 %1, %1, %3"                      // c3 ^= k2
-                : "+v"(c2), "+v"(c3), "+v"(ov), "=&v"(k2) : "v"(k1));
-        }
+        u32 ma, k0, k1;
+        if (NS == 3)
+            asm(PG_TAKE("ja") PG_SHIFT("ma", "ja") PG_ADD1 PG_UP3
+                : PG_CTR3, [pm] "+s"(pm), [ja] "=&s"(ja), [ma] "=&v"(ma), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES);
+        else
+            asm(PG_TAKE("ja") PG_SHIFT("ma", "ja") PG_ADD1 PG_UP4
+                : PG_CTR4, [pm] "+s"(pm), [ja] "=&s"(ja), [ma] "=&v"(ma), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES);
     }
-    __device__ __forceinline__ void add1(u32 m)
+    __device__ __forceinline__ void take2(u32 &pm, u32 lo, u32 hi, u32 &ja, u32 &jb)
     {
-        u32 k0, k1;
-        asm("v_bfi_b32 %2, %4, 0, %0\n\t"                 // k0 = ~m & c0
-            "v_xnor_b32 %0, %0, %4\n\t"                   // c0 ^= ~m
-            "v_and_b32 %3, %1, %2\n\t"                    // k1 = c1 & k0
-            "v_xor_b32 %1, %1, %2"                          // c1 ^= k0
-            : "+v"(c0), "+v"(c1), "=&v"(k0), "=&v"(k1) : "v"(m));
-        upper(k1);
+        u32 ma, mb, s0, k0, k1;
+        if (NS == 3)
+            asm(PG_TAKE("ja") PG_TAKE("jb") PG_SHIFT("ma", "ja") PG_SHIFT("mb", "jb") PG_ADD2 PG_UP3
+                : PG_CTR3, [pm] "+s"(pm), [ja] "=&s"(ja), [jb] "=&s"(jb), [ma] "=&v"(ma), [mb] "=&v"(mb), [s0] "=&v"(s0),
+                  [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES);
+        else
+            asm(PG_TAKE("ja") PG_TAKE("jb") PG_SHIFT("ma", "ja") PG_SHIFT("mb", "jb") PG_ADD2 PG_UP4
+                : PG_CTR4, [pm] "+s"(pm), [ja] "=&s"(ja), [jb] "=&s"(jb), [ma] "=&v"(ma), [mb] "=&v"(mb), [s0] "=&v"(s0),
+                  [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES);
     }
-    __device__ __forceinline__ void add2(u32 ma, u32 mb)
+    __device__ __forceinline__ void take3(u32 &pm, u32 lo, u32 hi, u32 &ja, u32 &jb, u32 &jc)
     {
-        // sum of the two mismatch bits: low bit ma ^ mb, high bit ~(ma | mb); the high bit and the carry out of
-        // slice 0 exclude each other, so slice 1 adds t = high | carry
-        u32 k0, t, k1;
-        asm("v_bitop3_b32 %2, %0, %5, %6 bitop3:0x60\n\t" // k0 = c0 & (ma ^ mb)
-            "v_bitop3_b32 %0, %0, %5, %6 bitop3:0x96\n\t" // c0 ^= ma ^ mb
-            "v_bitop3_b32 %3, %5, %6, %2 bitop3:0xab\n\t" // t = ~(ma | mb) | k0
-            "v_and_b32 %4, %1, %3\n\t"                    // k1 = c1 & t
-            "v_xor_b32 %1, %1, %3"                          // c1 ^= t
-            : "+v"(c0), "+v"(c1), "=&v"(k0), "=&v"(t), "=&v"(k1) : "v"(ma), "v"(mb));
-        upper(k1);
+        u32 ma, mb, mc, s0, s1, k0, k1;
+        if (NS == 3)
+            asm(PG_TAKE("ja") PG_TAKE("jb") PG_TAKE("jc") PG_SHIFT("ma", "ja") PG_SHIFT("mb", "jb") PG_SHIFT("mc", "jc")
+                PG_ADD3 PG_UP3
+                : PG_CTR3, [pm] "+s"(pm), [ja] "=&s"(ja), [jb] "=&s"(jb), [jc] "=&s"(jc), [ma] "=&v"(ma), [mb] "=&v"(mb),
+                  [mc] "=&v"(mc), [s0] "=&v"(s0), [s1] "=&v"(s1), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES);
+        else
+            asm(PG_TAKE("ja") PG_TAKE("jb") PG_TAKE("jc") PG_SHIFT("ma", "ja") PG_SHIFT("mb", "jb") PG_SHIFT("mc", "jc")
+                PG_ADD3 PG_UP4
+                : PG_CTR4, [pm] "+s"(pm), [ja] "=&s"(ja), [jb] "=&s"(jb), [jc] "=&s"(jc), [ma] "=&v"(ma), [mb] "=&v"(mb),
+                  [mc] "=&v"(mc), [s0] "=&v"(s0), [s1] "=&v"(s1), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES);
     }
-    __device__ __forceinline__ void add3(u32 ma, u32 mb, u32 mc)
+    // --- the same base(s) for the other kind: planes shifted by 32 - bit
+    __device__ __forceinline__ void mirror1(u32 lo, u32 hi, u32 ja)
     {
-        u32 s0, s1, k0, k1;
-        asm("v_bitop3_b32 %2, %6, %7, %8 bitop3:0x69\n\t" // s0 = ~(ma ^ mb ^ mc): low bit of the mismatch sum
-            "v_bitop3_b32 %3, %6, %7, %8 bitop3:0x17\n\t" // s1 = ~maj(ma, mb, mc): high bit
-            "v_and_b32 %4, %0, %2\n\t"                    // k0 = c0 & s0
-            "v_xor_b32 %0, %0, %2\n\t"                    // c0 ^= s0
-            "v_bitop3_b32 %5, %1, %3, %4 bitop3:0xe8\n\t" // k1 = maj(c1, s1, k0)
-            "v_bitop3_b32 %1, %1, %3, %4 bitop3:0x96"       // c1 ^= s1 ^ k0
-            : "+v"(c0), "+v"(c1), "=&v"(s0), "=&v"(s1), "=&v"(k0), "=&v"(k1)
-            : "v"(ma), "v"(mb), "v"(mc));
-        upper(k1);
+        u32 ta, ma, k0, k1;
+        if (NS == 3)
+            asm(PG_MIRROR("ta", "ja") PG_SHIFT("ma", "ta") PG_ADD1 PG_UP3
+                : PG_CTR3, [ta] "=&s"(ta), [ma] "=&v"(ma), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES, [ja] "s"(ja) : "scc");
+        else
+            asm(PG_MIRROR("ta", "ja") PG_SHIFT("ma", "ta") PG_ADD1 PG_UP4
+                : PG_CTR4, [ta] "=&s"(ta), [ma] "=&v"(ma), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES, [ja] "s"(ja) : "scc");
     }
-    // lowest set bit of the wave-uniform set pm, removed from it: two scalar instructions
-    static __device__ __forceinline__ u32 take(u32 &pm)
+    __device__ __forceinline__ void mirror2(u32 lo, u32 hi, u32 ja, u32 jb)
     {
-        u32 j;
-        asm("s_ff1_i32_b32 %0, %1\n\ts_bitset0_b32 %1, %0" : "=&s"(j), "+s"(pm));
-        return j;
+        u32 ta, tb, ma, mb, s0, k0, k1;
+        if (NS == 3)
+            asm(PG_MIRROR("ta", "ja") PG_MIRROR("tb", "jb") PG_SHIFT("ma", "ta") PG_SHIFT("mb", "tb") PG_ADD2 PG_UP3
+                : PG_CTR3, [ta] "=&s"(ta), [tb] "=&s"(tb), [ma] "=&v"(ma), [mb] "=&v"(mb), [s0] "=&v"(s0), [k0] "=&v"(k0),
+                  [k1] "=&v"(k1) : PG_PLANES, [ja] "s"(ja), [jb] "s"(jb) : "scc");
+        else
+            asm(PG_MIRROR("ta", "ja") PG_MIRROR("tb", "jb") PG_SHIFT("ma", "ta") PG_SHIFT("mb", "tb") PG_ADD2 PG_UP4
+                : PG_CTR4, [ta] "=&s"(ta), [tb] "=&s"(tb), [ma] "=&v"(ma), [mb] "=&v"(mb), [s0] "=&v"(s0), [k0] "=&v"(k0),
+                  [k1] "=&v"(k1) : PG_PLANES, [ja] "s"(ja), [jb] "s"(jb) : "scc");
+    }
+    __device__ __forceinline__ void mirror3(u32 lo, u32 hi, u32 ja, u32 jb, u32 jc)
+    {
+        u32 ta, tb, tc, ma, mb, mc, s0, s1, k0, k1;
+        if (NS == 3)
+            asm(PG_MIRROR("ta", "ja") PG_MIRROR("tb", "jb") PG_MIRROR("tc", "jc") PG_SHIFT("ma", "ta") PG_SHIFT("mb", "tb")
+                PG_SHIFT("mc", "tc") PG_ADD3 PG_UP3
+                : PG_CTR3, [ta] "=&s"(ta), [tb] "=&s"(tb), [tc] "=&s"(tc), [ma] "=&v"(ma), [mb] "=&v"(mb), [mc] "=&v"(mc),
+                  [s0] "=&v"(s0), [s1] "=&v"(s1), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES, [ja] "s"(ja), [jb] "s"(jb), [jc] "s"(jc) : "scc");
+        else
+            asm(PG_MIRROR("ta", "ja") PG_MIRROR("tb", "jb") PG_MIRROR("tc", "jc") PG_SHIFT("ma", "ta") PG_SHIFT("mb", "tb")
+                PG_SHIFT("mc", "tc") PG_ADD3 PG_UP4
+                : PG_CTR4, [ta] "=&s"(ta), [tb] "=&s"(tb), [tc] "=&s"(tc), [ma] "=&v"(ma), [mb] "=&v"(mb), [mc] "=&v"(mc),
+                  [s0] "=&v"(s0), [s1] "=&v"(s1), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES, [ja] "s"(ja), [jb] "s"(jb), [jc] "s"(jc) : "scc");
     }
 };
 
 // Every base of the (wave-uniform) set pm goes into the counter(s).  Kind F: the base at bit j reads the pair
 // (own word, next word) shifted by j.  Kind B: the pair (previous word, own word) shifted by 32 - j.  DUAL: both
 // kinds in one loop (the scalar bookkeeping is shared; the caller passes kind B's planes of the complementary
-// symbol).  revB (single kind B): pm arrives bit-reversed and moved up one bit, so that its bit IS the shift.
+// symbol).  Single kind B: pm arrives bit-reversed and moved up one bit, so that its bit IS the shift.
 // group: three or two bases at a time (not for the rare N bases, to keep the code small).
 template <int NS, bool DUAL>
 __device__ __forceinline__ void add_bases(bool group, u32 pm, Counter<NS> &C, u32 lo, u32 hi,
                                           Counter<NS> &C2, u32 lo2, u32 hi2)
 {
+    u32 ja, jb, jc;
     if (group) {
         int n = __popc(pm);
         while (n >= 3) {
-            const u32 ja = Counter<NS>::take(pm), jb = Counter<NS>::take(pm), jc = Counter<NS>::take(pm);
-            C.add3(__builtin_amdgcn_alignbit(hi, lo, ja), __builtin_amdgcn_alignbit(hi, lo, jb),
-                   __builtin_amdgcn_alignbit(hi, lo, jc));
-            if (DUAL)
-                C2.add3(__builtin_amdgcn_alignbit(hi2, lo2, 32u - ja), __builtin_amdgcn_alignbit(hi2, lo2, 32u - jb),
-                        __builtin_amdgcn_alignbit(hi2, lo2, 32u - jc));
+            C.take3(pm, lo, hi, ja, jb, jc);
+            if (DUAL) C2.mirror3(lo2, hi2, ja, jb, jc);
             n -= 3;
         }
         if (n == 2) {
-            const u32 ja = Counter<NS>::take(pm), jb = Counter<NS>::take(pm);
-            C.add2(__builtin_amdgcn_alignbit(hi, lo, ja), __builtin_amdgcn_alignbit(hi, lo, jb));
-            if (DUAL) C2.add2(__builtin_amdgcn_alignbit(hi2, lo2, 32u - ja), __builtin_amdgcn_alignbit(hi2, lo2, 32u - jb));
+            C.take2(pm, lo, hi, ja, jb);
+            if (DUAL) C2.mirror2(lo2, hi2, ja, jb);
         }
     }
     while (pm != 0u) {
-        const u32 j = Counter<NS>::take(pm);
-        C.add1(__builtin_amdgcn_alignbit(hi, lo, j));
-        if (DUAL) C2.add1(__builtin_amdgcn_alignbit(hi2, lo2, 32u - j));
+        C.take1(pm, lo, hi, ja);
+        if (DUAL) C2.mirror1(lo2, hi2, ja);
     }
 }
 
-// SEED FILTER, bit sliced: the lane owns the 32 window positions of word `lane` of the chunk and returns
-// the mask of positions whose candidate (of kind F or B) can matter.  Position bit i, consumed base j
-// reads reference base p+j (F) / p-j (B): one alignbit of the one-hot plane of read base j.  Mismatch
-// counts are kept bit sliced (a 4-bit ripple counter per position + overflow), 9 VALU per base for 32
-// positions.  Which candidates matter (exact, DESIGN.md "relevance"): a candidate at level k at
-// length L can only influence the result if k <= g_maxMismatch[L] + ADD -- otherwise either a lower
-// level exists (lo + ADD < k) or it is the lowest level itself and the search aborts at L with or
-// without it.  With J > bps bases inspected: relevant at some L in [bps, J] implies
-// c(bps) <= g_maxMismatch[J] + ADD (the table is monotone); relevant later implies alive after J bases,
-// c(J) <= T-1.  With J <= bps only the second test applies.  Anything kept beyond that is harmless.
 // DUAL (far end, both kinds wanted, kind B reading the complement of what kind F reads): one pass yields
 // both masks (mF, mB).  Otherwise the mask of the one kind (kindB) comes back in mF.
 template <int NB, int NS, bool DUAL>
