@@ -5,6 +5,9 @@
 #define PG_PIPELINE_HPP
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <string>
 #include <utility>
@@ -41,6 +44,10 @@ int run_pipeline(const std::vector<Chromosome> &genome, const std::vector<unsign
 {
     Caller caller(S, &genome, prefix, true);
     const unsigned WINDOW = (unsigned)(S.window_mbp * 1000000);
+    // PGH_TIMING=1: wall-clock seconds per stage of this loop on stderr (diagnostics)
+    const bool timing = getenv("PGH_TIMING") != nullptr;
+    double t_copy = 0, t_search = 0, t_keep = 0, t_call = 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     // The Pindel-text reader rescans the whole file for every window and raises g_maxPos for EVERY read it
     // passes (reader.cpp:224-226), so after the first window of a chromosome g_maxPos is the largest position
     // in the file; the windows then run until they pass it.  Here the reads are bucketed once: per chromosome
@@ -75,6 +82,7 @@ int run_pipeline(const std::vector<Chromosome> &genome, const std::vector<unsign
         for (size_t w = 0; w < starts.size(); w++) {
             if (bins[w].empty()) continue;
             const unsigned ws = starts[w], we = std::min(ws + WINDOW, global_end);
+            double t0 = now();
             std::vector<SplitRead> reads;
             reads.reserve(bins[w].size());
             for (uint32_t i : bins[w]) {
@@ -82,20 +90,27 @@ int run_pipeline(const std::vector<Chromosome> &genome, const std::vector<unsign
                 if (reads.back().MatchedRelPos > biol) reads.back().MatchedRelPos = biol;   // reader.cpp:233-235
                 reads.back().MAX_SNP_ERROR = (short)S.max_mismatch[std::min<int>(all[i].ReadLength, 499)];
             }
+            t_copy += now() - t0; t0 = now();
             int rc = search(chrom, (int)c, reads, bins[w]);
             if (rc) {
                 err = "search step failed";
                 return rc;
             }
+            t_search += now() - t0; t0 = now();
             std::vector<SplitRead> kept;                                // reader.cpp:258-291
             for (SplitRead &r : reads)
                 if (!r.UP_Close.empty()) {
                     caller.note_close_mapped(r);
                     kept.push_back(std::move(r));      // `reads` is not used after this loop
                 }
+            t_keep += now() - t0; t0 = now();
             if (!kept.empty()) caller.process_window(chrom, kept, ws, we, bed_start, bed_end);
+            t_call += now() - t0;
         }
     }
+    if (timing)
+        fprintf(stderr, "pgh timing: pipeline: copy reads %.3f s, search step %.3f s, keep %.3f s, classify + report %.3f s\n",
+                t_copy, t_search, t_keep, t_call);
     return 0;
 }
 
