@@ -369,13 +369,29 @@ private:
             f = fopen(alt.c_str(), "rb");
         }
         if (!f) return;
+        const bool ok = read_bai(f, bins_, linear_);
+        fclose(f);
+        if (!ok) {
+            bins_.clear();
+            linear_.clear();
+        }
+    }
+
+public:
+    typedef std::vector<std::unordered_map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>>> BaiBins;
+    // A .bai file: per reference the chunks of every bin (the metadata pseudo-bin 37450 is skipped) and the linear
+    // index; whatever follows (n_no_coor) is not needed.
+    static bool read_bai(FILE *f, BaiBins &bins, std::vector<std::vector<uint64_t>> &linear)
+    {
         auto rd = [&](void *p, size_t n) { return fread(p, 1, n, f) == n; };
         char magic[4];
         int32_t n_ref = 0;
         bool ok = rd(magic, 4) && memcmp(magic, "BAI\1", 4) == 0 && rd(&n_ref, 4) && n_ref >= 0;
+        bins.clear();
+        linear.clear();
         if (ok) {
-            bins_.resize((size_t)n_ref);
-            linear_.resize((size_t)n_ref);
+            bins.resize((size_t)n_ref);
+            linear.resize((size_t)n_ref);
         }
         for (int t = 0; ok && t < n_ref; t++) {
             int32_t n_bin = 0;
@@ -386,27 +402,25 @@ private:
                 ok = rd(&bin, 4) && rd(&n_chunk, 4) && n_chunk >= 0;
                 std::vector<std::pair<uint64_t, uint64_t>> cs((size_t)(ok ? n_chunk : 0));
                 for (auto &c : cs) ok = ok && rd(&c.first, 8) && rd(&c.second, 8);
-                if (ok && bin != 37450) bins_[t][bin] = cs;         // 37450: the metadata pseudo-bin
+                if (ok && bin != 37450) bins[t][bin] = cs;          // 37450: the metadata pseudo-bin
             }
             int32_t n_intv = 0;
             ok = ok && rd(&n_intv, 4) && n_intv >= 0;
             if (ok) {
-                linear_[t].resize((size_t)n_intv);
-                ok = n_intv == 0 || rd(linear_[t].data(), 8u * (size_t)n_intv);
+                linear[t].resize((size_t)n_intv);
+                ok = n_intv == 0 || rd(linear[t].data(), 8u * (size_t)n_intv);
             }
         }
-        fclose(f);
-        if (!ok) {
-            bins_.clear();
-            linear_.clear();
-        }
+        return ok;
     }
+
+private:
     std::string path_;
     BgzfReader z_;
     BamHeader hdr_;
     uint64_t first_record_ = 0;
     std::vector<uint8_t> buf_;
-    std::vector<std::unordered_map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>>> bins_;
+    BaiBins bins_;
     std::vector<std::vector<uint64_t>> linear_;
 };
 

@@ -179,6 +179,34 @@ uint64_t pgh_bam_ingest_ref_reads(void *h, uint32_t *out, uint64_t cap)
 
 void pgh_bam_ingest_free(void *h) { delete (pgh::IngestedReads *)h; }
 
+// What the BAI reader makes of an index file (test hook: the reference ships .bai files of its demo BAMs): per
+// reference 4 values -- bins (without the pseudo-bin), chunks, 64-bit sum of all chunk begin/end offsets, linear-index
+// entries; returns the number of references or -1.
+int32_t pgh_bai_summary(const char *bai_path, uint64_t *out, uint32_t cap_refs)
+{
+    FILE *f = fopen(bai_path, "rb");
+    if (!f) return -1;
+    pgh::BamFile::BaiBins bins;
+    std::vector<std::vector<uint64_t>> linear;
+    const bool ok = pgh::BamFile::read_bai(f, bins, linear);
+    fclose(f);
+    if (!ok) return -1;
+    for (size_t t = 0; t < bins.size() && t < cap_refs; t++) {
+        uint64_t chunks = 0, sum = 0;
+        for (const auto &kv : bins[t])
+            for (const auto &c : kv.second) {
+                chunks++;
+                sum += c.first + c.second;
+            }
+        for (uint64_t v : linear[t]) sum += v;
+        out[4 * t] = bins[t].size();
+        out[4 * t + 1] = chunks;
+        out[4 * t + 2] = sum;
+        out[4 * t + 3] = linear[t].size();
+    }
+    return (int32_t)bins.size();
+}
+
 // Read-pair discovery (pg_rp.hpp): the BreakDancer-like events of one window of one BAM.  out receives 4 values per
 // event (pos1, pos1b, pos2, pos2b, Pindel coordinates); rp_path (nullable): the lines of <prefix>_RP.
 int64_t pgh_rp_events(const char *bam_path, const char *chr_name, int64_t win_start, int64_t win_end, int32_t insert_size,

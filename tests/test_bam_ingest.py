@@ -37,6 +37,8 @@ def _lib():
     L.pgh_bam_ingest_free.argtypes = [C.c_void_p]
     L.pgh_bam_ingest_ref_reads.restype = C.c_uint64
     L.pgh_bam_ingest_ref_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.pgh_bai_summary.restype = C.c_int32
+    L.pgh_bai_summary.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32]
     return L
 
 
@@ -288,6 +290,38 @@ def test_selection_rules_match_the_restatement_and_index_equals_scan(tmp_path, m
     assert total > 2000 and total_refs > 500
     assert ingest(bam, "chrM", 0, 16000 + 200000, 0, 16000, 450) == []
     assert ingest(bam, "nope", 5, 1_000_000, 0, 16000, 450) == []
+
+
+@pytest.mark.parametrize("name,n_ref", [("sim1chrVs2.bam.bai", 1), ("simulated_sample_1.bam.bai", 4)])
+def test_reference_bai_files_parse(name, n_ref):
+    """The index files the reference ships (written by samtools; the BAMs themselves are not in the snapshot): the BAI
+    reader must take the metadata pseudo-bin and the trailing n_no_coor in its stride."""
+    import struct
+    path = os.path.join(os.path.dirname(gu.GOLD), "bai", name)
+    d = open(path, "rb").read()
+    assert d[:4] == b"BAI\1" and struct.unpack_from("<i", d, 4)[0] == n_ref
+    o, want = 8, []
+    for _ in range(n_ref):
+        (n_bin,) = struct.unpack_from("<i", d, o)
+        o += 4
+        bins = chunks = total = 0
+        for _ in range(n_bin):
+            bid, nch = struct.unpack_from("<Ii", d, o)
+            o += 8
+            vals = struct.unpack_from("<%dQ" % (2 * nch), d, o)
+            o += 16 * nch
+            if bid != 37450:
+                bins, chunks, total = bins + 1, chunks + nch, total + sum(vals)
+        (n_intv,) = struct.unpack_from("<i", d, o)
+        o += 4
+        total += sum(struct.unpack_from("<%dQ" % n_intv, d, o))
+        o += 8 * n_intv
+        want.append((bins, chunks, total & (2 ** 64 - 1), n_intv))
+    assert len(d) - o in (0, 8)
+    out = np.zeros(4 * n_ref, dtype=np.uint64)
+    assert _lib().pgh_bai_summary(path.encode(), out.ctypes.data, n_ref) == n_ref
+    assert [tuple(int(x) for x in out[4 * t:4 * t + 4]) for t in range(n_ref)] == want
+    assert all(w[0] >= 8 and w[3] == 13 for w in want)
 
 
 def test_insert_size_not_above_read_length_is_an_error(tmp_path):
