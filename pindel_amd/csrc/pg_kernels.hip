@@ -61,6 +61,7 @@ typedef unsigned int u32;
 #define PG_CLAIM 8u         // reads claimed per atomic
 #endif
 #define PG_BIG 0xffffu      // "no candidate" level
+#define PG_CHR_TAB 24       // chromosomes whose word offset / size are kept in LDS (a read's first dependent load otherwise)
 
 __device__ __forceinline__ u64 ballot64(bool p) { return __ballot(p); }
 // DPP lane shifts (no LDS round trip).  row_shr:n moves lane i-n -> i inside each 16-lane row and
@@ -205,6 +206,7 @@ struct Lds {
     u64 qp[2 * 4 * NB];                       // the read's bit planes, two orientations
     uint16_t queue[64];                       // survivors of the prefilter for one candidate pass: (window position << 1) | kind
     u32 mm_bp[PG_MM_BREAKS];                  // breakpoints of g_maxMismatch (copied from the kernel arguments)
+    u32 chr_tab[3 * PG_CHR_TAB];              // word offset (lo, hi) and size of the first PG_CHR_TAB chromosomes
 };
 
 struct Search {
@@ -215,7 +217,8 @@ struct Search {
     uint4 *bufB;
     uint2 *hdrB;
     void *accB;
-    const u32 *mm_bp;    // LDS copy of PgDevParams::mm_bp
+    const u32 *mm_bp;
+    const u32 *chr_tab;    // LDS copy of PgDevParams::mm_bp
     // what the LDS window currently holds: bases [win_lo, win_hi) of the chromosome whose AbsLoc 0 is
     // at word index win_wo; the first staged base is wbase = win_lo (any alignment)
     long long win_wo;
@@ -276,6 +279,20 @@ __device__ __forceinline__ int max_mismatch_at(const u32 *mm_bp, int L)
 #pragma unroll
     for (int k = 0; k < PG_MM_BREAKS; k++) m += (u32)L >= mm_bp[k] ? 1 : 0;
     return m;
+}
+
+// word offset / size of a chromosome: from LDS for the first PG_CHR_TAB ones (c is wave-uniform)
+__device__ __forceinline__ long long chr_word_off_of(const PgDevRef &ref, const Search &S, int c)
+{
+    if (c < PG_CHR_TAB)
+        return (long long)((u64)(u32)uni((int)S.chr_tab[3 * c]) | ((u64)(u32)uni((int)S.chr_tab[3 * c + 1]) << 32));
+    const u64 w = ref.chr_word_off[c];
+    return (long long)((u64)(u32)uni((int)(u32)w) | ((u64)(u32)uni((int)(u32)(w >> 32)) << 32));
+}
+__device__ __forceinline__ int chr_size_of(const PgDevRef &ref, const Search &S, int c)
+{
+    if (c < PG_CHR_TAB) return uni((int)S.chr_tab[3 * c + 2]);
+    return uni((int)ref.chr_size[c]);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1099,16 +1116,31 @@ __device__ __forceinline__ void emit_runs(const Search &S, bool antiF, bool anti
 }
 
 // ---------------------------------------------------------------------------------
+// The read's bases -> bit planes (code bit 0 / 1, N, other; forward and reversed) in LDS.  In two steps, so that the
+// caller can put other loads between the request and the first use of the bases.
 template <int NB>
-__device__ __forceinline__ void load_planes(const uint8_t *seq, int len, int lane, u64 *qp)
+struct ReadBases {
+    uint8_t cf[NB], cr[NB];
+};
+template <int NB>
+__device__ __forceinline__ void request_bases(const uint8_t *seq, int len, int lane, ReadBases<NB> &rb)
+{
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        const int idx = 64 * b + lane;
+        const bool in = idx < len;
+        rb.cf[b] = in ? seq[idx] : 0;
+        rb.cr[b] = in ? seq[len - 1 - idx] : 0;
+    }
+}
+template <int NB>
+__device__ __forceinline__ void make_planes(const ReadBases<NB> &rb, int len, int lane, u64 *qp)
 {
     __syncthreads();
 #pragma unroll
     for (int b = 0; b < NB; b++) {
-        int idx = 64 * b + lane;
-        bool in = idx < len;
-        uint8_t cf = in ? seq[idx] : 0;
-        uint8_t cr = in ? seq[len - 1 - idx] : 0;
+        const bool in = 64 * b + lane < len;
+        const uint8_t cf = rb.cf[b], cr = rb.cr[b];
         // code: A=0 C=1 G=2 T=3
         bool fA = cf == 'A', fC = cf == 'C', fG = cf == 'G', fT = cf == 'T', fN = cf == 'N';
         bool rA = cr == 'A', rC = cr == 'C', rG = cr == 'G', rT = cr == 'T', rN = cr == 'N';
@@ -1163,14 +1195,30 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     const uint4 r0 = rp[0], r1 = rp[1];
     const int len = uni((int)(r1.x & 0xffffu));
     const int chr = uni((int)r0.w);
-    const long long chr_wo = (long long)ref.chr_word_off[chr];
+    const long long chr_wo = chr_word_off_of(ref, S, chr);
     S.len = len;
     S.M = uni((int)(r1.y >> 24));
     S.T = S.M + prm.add_mm + 1;
     S.thr = uni((int)(r1.y & 0xffffu));
-    load_planes<NB>(B.seq + ((u64)r0.x | ((u64)r0.y << 32)), len, lane, qplanes);
+    // The record is the read's first memory round trip; its bases and the window of the first close-end attempt are
+    // the second: both are requested before either is used (the scan below finds the window resident).
+    ReadBases<NB> rb;
+    request_bases<NB>(B.seq + ((u64)r0.x | ((u64)r0.y << 32)), len, lane, rb);
+    if (mode & PG_MODE_CLOSE) {
+        const int strand0 = uni((int)((r1.y >> 16) & 0xffu));
+        if (len - 1 >= prm.min_close && (strand0 == '+' || strand0 == '-')) {
+            const int apos0 = uni((int)r0.z), isz0 = uni((int)(short)(r1.x >> 16));
+            const int s1 = strand0 == '+' ? apos0 : apos0 - isz0, e1 = s1 + isz0;     // attempt 0: R = 0
+            if (s1 < e1) {
+                const int se = e1 < s1 + (int)PG_CHUNK ? e1 : s1 + (int)PG_CHUNK;
+                stage_window<NB>(ref, S, chr_wo, s1 - 64 * NB, se + 64 * NB, lane);
+            }
+        }
+    }
+    make_planes<NB>(rb, len, lane, qplanes);
 #if defined(PG_DUP) && PG_DUP == 1
-    load_planes<NB>(B.seq + ((u64)r0.x | ((u64)r0.y << 32)), len, opaque(lane), qplanes);
+    request_bases<NB>(B.seq + ((u64)r0.x | ((u64)r0.y << 32)), len, opaque(lane), rb);
+    make_planes<NB>(rb, len, opaque(lane), qplanes);
 #endif
 
 #if defined(PG_STOP) && PG_STOP == 1
@@ -1304,7 +1352,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
         Q.first_ok = first_base_ok<NB>(Q);
         if (Q.first_ok) {
             const u32 mm0 = mm_of(S, 10 + lane);
-            const int chr_size = (int)ref.chr_size[chr];
+            const int chr_size = chr_size_of(ref, S, chr);
             int far_bases = 0;
             // a search window's result replaces UP_Far if its MaxLen is >= (NewUPFarIsBetter, farend_searcher.cpp:30-44)
             auto far_update = [&](int origin, const pg_window *bdw) {
@@ -1334,10 +1382,10 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                 for (int w = 0; w < nbd; w++) {
                     const pg_window bw = bd[w];
                     const int st = bw.start < 0 ? bw.end - 1 : bw.start;
-                    const int csz = (int)ref.chr_size[bw.chr_id];
+                    const int csz = chr_size_of(ref, S, uni(bw.chr_id));
                     const int s = st < 0 ? 0 : st, e = bw.end > csz ? csz : bw.end;
                     far_bases += (e > s ? e - s : 0) + 2 * len;
-                    scan_range<NB, Id>(ref, S, Q, A, (long long)ref.chr_word_off[bw.chr_id], s, s, e, e, 0, 0, st,
+                    scan_range<NB, Id>(ref, S, Q, A, chr_word_off_of(ref, S, uni(bw.chr_id)), s, s, e, e, 0, 0, st,
                                        (u32)w, opaque(lane), false, unused0, unused1, unused_valid);
                 }
                 if (S.nsurv > 0) far_update(0, bd);
@@ -1422,6 +1470,12 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
     __shared__ Lds<NB, Id> lds;
     const int lane = threadIdx.x;
     if (lane < PG_MM_BREAKS) lds.mm_bp[lane] = prm.mm_bp[lane];
+    if (lane < PG_CHR_TAB && lane < ref.n_chr) {
+        const u64 wo = ref.chr_word_off[lane];
+        lds.chr_tab[3 * lane] = (u32)wo;
+        lds.chr_tab[3 * lane + 1] = (u32)(wo >> 32);
+        lds.chr_tab[3 * lane + 2] = ref.chr_size[lane];
+    }
     __syncthreads();
     Search S;
     S.queue = lds.queue;
@@ -1431,6 +1485,7 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
     S.hdrB = lds.hdrB;
     S.accB = lds.accB;
     S.mm_bp = lds.mm_bp;
+    S.chr_tab = lds.chr_tab;
     S.add_mm = prm.add_mm;
     S.min_perfect = prm.min_perfect;
     u64 *qplanes = lds.qp;                        // [0]: forward, [1]: reversed consumption order
