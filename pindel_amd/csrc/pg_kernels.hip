@@ -61,6 +61,8 @@ typedef unsigned int u32;
 #define PG_CLAIM 8u         // reads claimed per atomic
 #endif
 #define PG_BIG 0xffffu      // "no candidate" level
+// reads of up to 128 bases: the records of a claim are fetched at once into LDS (longer reads have no LDS to spare)
+#define PG_REC_LDS(nb) ((nb) <= 2)
 #define PG_CHR_TAB 24       // chromosomes whose word offset / size are kept in LDS (a read's first dependent load otherwise)
 
 __device__ __forceinline__ u64 ballot64(bool p) { return __ballot(p); }
@@ -207,6 +209,7 @@ struct Lds {
     uint16_t queue[64];                       // survivors of the prefilter for one candidate pass: (window position << 1) | kind
     u32 mm_bp[PG_MM_BREAKS];                  // breakpoints of g_maxMismatch (copied from the kernel arguments)
     u32 chr_tab[3 * PG_CHR_TAB];              // word offset (lo, hi) and size of the first PG_CHR_TAB chromosomes
+    uint4 rec[PG_REC_LDS(NB) ? 2 * PG_CLAIM : 0];   // the packed records of the claimed reads (one coalesced load per claim)
 };
 
 struct Search {
@@ -218,7 +221,8 @@ struct Search {
     uint2 *hdrB;
     void *accB;
     const u32 *mm_bp;
-    const u32 *chr_tab;    // LDS copy of PgDevParams::mm_bp
+    const u32 *chr_tab;
+    const uint4 *rec;    // PG_REC_LDS: the claim's records in LDS    // LDS copy of PgDevParams::mm_bp
     // what the LDS window currently holds: bases [win_lo, win_hi) of the chromosome whose AbsLoc 0 is
     // at word index win_wo; the first staged base is wbase = win_lo (any alignment)
     long long win_wo;
@@ -1183,7 +1187,7 @@ __device__ __forceinline__ bool first_base_ok(const Query<NB> &Q)
 //               r = 1 .. MaxRangeIndex+1 until goodFarEndFound                          pindel.cpp:1006-1070
 template <int NB, typename Id, int mode>
 __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevParams &prm, const PgDevBatch &B,
-                                            Search &S, u64 *qplanes, const uint32_t rid, const int lane)
+                                            Search &S, u64 *qplanes, const uint32_t rid, const int slot, const int lane)
 {
     S.win_wo = -1;
     S.win_hi = S.wbase = 0;
@@ -1191,8 +1195,15 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     S.cap_state = 255;
     S.want_cap = false;
     // the read's packed record (rid is wave-uniform)
-    const uint4 *rp = (const uint4 *)(B.in + rid);
-    const uint4 r0 = rp[0], r1 = rp[1];
+    uint4 r0, r1;
+    if (PG_REC_LDS(NB)) {
+        r0 = S.rec[2 * slot];
+        r1 = S.rec[2 * slot + 1];
+    } else {
+        const uint4 *rp = (const uint4 *)(B.in + rid);
+        r0 = rp[0];
+        r1 = rp[1];
+    }
     const int len = uni((int)(r1.x & 0xffffu));
     const int chr = uni((int)r0.w);
     const long long chr_wo = chr_word_off_of(ref, S, chr);
@@ -1486,6 +1497,7 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
     S.accB = lds.accB;
     S.mm_bp = lds.mm_bp;
     S.chr_tab = lds.chr_tab;
+    S.rec = lds.rec;
     S.add_mm = prm.add_mm;
     S.min_perfect = prm.min_perfect;
     u64 *qplanes = lds.qp;                        // [0]: forward, [1]: reversed consumption order
@@ -1504,8 +1516,14 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
             continue;
         }
         const uint32_t first = lo + got, end = hi - first < PG_CLAIM ? hi : first + PG_CLAIM;
+        if (PG_REC_LDS(NB)) {
+            __syncthreads();
+            if ((uint32_t)lane < 8u * (end - first))
+                ((u32 *)lds.rec)[lane] = ((const u32 *)(B.in + B.first_read + first))[lane];
+            __syncthreads();
+        }
         for (uint32_t i = first; i < end; i++)
-            search_read<NB, Id, mode>(ref, prm, B, S, qplanes, B.first_read + i, opaque(lane));
+            search_read<NB, Id, mode>(ref, prm, B, S, qplanes, B.first_read + i, (int)(i - first), opaque(lane));
     }
 }
 
