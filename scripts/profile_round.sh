@@ -42,7 +42,7 @@ cat "$out/hbm_traffic.json"
 cd "$root" || exit 1
 {
     echo "# cumulative instructions per read of builds that stop early (bench workload, $reads reads)"
-    echo "# stop1 = read planes loaded; stop2 = + close end, first attempt up to the end of its scan; stop6 = + its evaluation;"
+    echo "# stop1 = record + read planes loaded, window of the first close-end attempt filled; stop2 = + close end, first attempt up to the end of its scan; stop6 = + its evaluation;"
     echo "# stop7 = + emission of its points; stop3 = whole close end (retries included); stop4 = + far end up to the end of"
     echo "# the first range's scan; stop5 = + its evaluation; full = the shipped kernel"
     for k in 1 2 6 7 3 4 5; do
