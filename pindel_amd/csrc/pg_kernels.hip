@@ -222,6 +222,7 @@ struct Search {
     void *accB;
     const u32 *mm_bp;
     const u32 *chr_tab;
+    int mm_j[2];         // g_maxMismatch[J] for the two filter depths J of this read (plain, wide): once per read
     const uint4 *rec;    // PG_REC_LDS: the claim's records in LDS    // LDS copy of PgDevParams::mm_bp
     // what the LDS window currently holds: bases [win_lo, win_hi) of the chromosome whose AbsLoc 0 is
     // at word index win_wo; the first staged base is wbase = win_lo (any alignment)
@@ -516,6 +517,13 @@ __device__ __forceinline__ u32 bits32(int lo, int hi)      // bits [lo,hi), clam
 #ifndef PG_SEED_J_WIDE
 #define PG_SEED_J_WIDE 2
 #endif
+// consumed bases the seed filter inspects for a read of `len` bases with T levels
+__device__ __forceinline__ int seed_depth(int len, int T, bool wide)
+{
+    int J = len - 1 < 32 ? len - 1 : 32;
+    const int jt = PG_SEED_J(T) + (wide ? PG_SEED_J_WIDE : 0);
+    return J > jt ? jt : J;
+}
 
 // positions whose bit-sliced mismatch count (c3 c2 c1 c0, ov = overflowed) is <= thr (wave-uniform)
 __device__ __forceinline__ u32 count_le(u32 c0, u32 c1, u32 c2, u32 c3, u32 ov, int thr)
@@ -748,11 +756,9 @@ __device__ __forceinline__ void seed_filter(const Search &S, const Query<NB> &Q,
     const int T = S.T;
     // bases inspected: two more in the chunks of wide far-end windows, where survivors cost a whole pass of
     // fold_candidates for a handful of candidates (measured: -4 % time at -x 5, +2 % if used everywhere)
-    int J = S.len - 1 < 32 ? S.len - 1 : 32;
-    const int jt = PG_SEED_J(T) + (wide ? PG_SEED_J_WIDE : 0);
-    if (J > jt) J = jt;
+    const int J = seed_depth(S.len, T, wide);
     const int jb = S.bps < J ? S.bps : J;
-    int cap0 = uni(max_mismatch_at(S.mm_bp, J)) + S.add_mm;        // min(T-1, g_maxMismatch[J] + ADD)
+    int cap0 = S.mm_j[wide ? 1 : 0] + S.add_mm;                    // min(T-1, g_maxMismatch[J] + ADD)
     if (cap0 > T - 1) cap0 = T - 1;
     // ... and, once candidates have been folded, min with the state's bound: a seed whose level at bps exceeds
     // (lowest level present at L) + ADD for every L in [bps, J] cannot be the lowest there nor within ADD of it
@@ -1004,8 +1010,7 @@ __device__ __forceinline__ void evaluate(Search &S, const Acc<NB, Id> &A, u32 mm
     if (S.want_cap) {
         // max over L in [bps, J] of the lowest level present (none present: no bound), + ADD; J as in seed_filter
         // for the chunks of wide windows (the only ones filtered after an evaluation)
-        int J = S.len - 1 < 32 ? S.len - 1 : 32;
-        if (J > PG_SEED_J(S.T) + PG_SEED_J_WIDE) J = PG_SEED_J(S.T) + PG_SEED_J_WIDE;
+        const int J = seed_depth(S.len, S.T, true);
         u32 v = (S.bps + lane <= J) ? t1 : 0u;
         // (each shift is taken once, outside the select: a DPP read under a diverged EXEC mask sees 0 in the
         // lanes that are switched off)
@@ -1211,6 +1216,14 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     S.M = uni((int)(r1.y >> 24));
     S.T = S.M + prm.add_mm + 1;
     S.thr = uni((int)(r1.y & 0xffffu));
+    // g_maxMismatch at the two filter depths (<= M: the breakpoints from index M on lie beyond the read)
+    {
+        const int j0 = seed_depth(len, S.T, false), j1 = seed_depth(len, S.T, true);
+        const int bp = (int)S.mm_bp[lane & (PG_MM_BREAKS - 1)];          // lane k < M: breakpoint k
+        const bool mine = lane < S.M;
+        S.mm_j[0] = __popcll(ballot64(mine && j0 >= bp));
+        S.mm_j[1] = __popcll(ballot64(mine && j1 >= bp));
+    }
     // The record is the read's first memory round trip; its bases and the window of the first close-end attempt are
     // the second: both are requested before either is used (the scan below finds the window resident).
     ReadBases<NB> rb;
