@@ -110,9 +110,9 @@ struct PgSoaOut {
 #define PG_CHUNK_SHIFT 11
 #define PG_EQ_ROWS 5u
 // LDS window capacity in 32-base words: chunk(s) + overhang of nb 64-base blocks on both sides + slack.  Reads of
-// up to 128 bases (nb <= 2) take the chunks of wide far-end windows two at a time; longer reads keep one chunk per
+// up to 192 bases (nb <= 3) take the chunks of wide far-end windows two at a time; longer reads keep one chunk per
 // fill, where the extra KB of LDS would cost a resident wave per SIMD.
-#define PG_PAIR_CHUNKS(nb) ((nb) <= 2)
+#define PG_PAIR_CHUNKS(nb) ((nb) <= 3)
 #define PG_WIN_WORDS(nb) (((PG_PAIR_CHUNKS(nb) ? 2u : 1u) * PG_CHUNK + 2u * (64u * (nb))) / 32u + 6u)
 
 #ifdef __cplusplus

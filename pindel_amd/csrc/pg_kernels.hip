@@ -61,8 +61,8 @@ typedef unsigned int u32;
 #define PG_CLAIM 8u         // reads claimed per atomic
 #endif
 #define PG_BIG 0xffffu      // "no candidate" level
-// reads of up to 128 bases: the records of a claim are fetched at once into LDS (longer reads have no LDS to spare)
-#define PG_REC_LDS(nb) ((nb) <= 2)
+// reads of up to 256 bases: the records of a claim are fetched at once into LDS (longer reads have no LDS to spare)
+#define PG_REC_LDS(nb) ((nb) <= 4)
 #define PG_CHR_TAB 24       // chromosomes whose word offset / size are kept in LDS (a read's first dependent load otherwise)
 
 __device__ __forceinline__ u64 ballot64(bool p) { return __ballot(p); }
@@ -202,7 +202,7 @@ template <int NB, typename Id>
 struct Lds {
     uint4 win[PG_WIN_WORDS(NB)];              // staged window: code planes (lo, hi, N)
     uint4 bufA[68];                           // tier A entries {mis0 lo, sne0 lo, id lo, meta}; scratch for the quarter merge
-    uint4 bufB[64 * NB];                      // tier B entries: NB x {mis lo, mis hi, sne lo, sne hi} per candidate
+    uint2 bufB[64 * NB];                      // tier B entries: the mismatch bitmap, NB x {mis lo, mis hi} per candidate
     uint2 hdrB[64];                           // ... and their {id lo, meta}
     typename AccB<Id>::T accB[NB > 1 ? 64 * (NB - 1) : 1];   // reduction state of the rounds >= 1 (AccB)
     u64 qp[2 * 4 * NB];                       // the read's bit planes, two orientations
@@ -217,7 +217,7 @@ struct Search {
     uint16_t *queue;
     uint4 *win;
     uint4 *bufA;
-    uint4 *bufB;
+    uint2 *bufB;
     uint2 *hdrB;
     void *accB;
     const u32 *mm_bp;
@@ -345,7 +345,7 @@ template <int NB, typename Id, bool MIXED>
 __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB> &Q, Acc<NB, Id> &A, int wbase,
                                                 int origin, u32 region, int n, int lane)
 {
-    constexpr int EW = NB;                                // uint4 words per tier B entry
+    constexpr int EW = NB;                                // 64-base blocks per tier B entry
     bool valid = lane < n;
     int p = 0;
     bool isB = MIXED ? false : Q.allowB;
@@ -355,7 +355,7 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
         p = wbase + (int)(e >> 1);
     }
     const bool comp = isB ? Q.cB : Q.cF;
-    // Per 64-base block: mismatch / inequality words go straight into the candidate's tier B entry (LDS);
+    // Per 64-base block: the mismatch word goes straight into the candidate's tier B entry (LDS);
     // only popcounts stay in registers.  Words of blocks that are not computed keep stale bits: they can
     // only add mismatches to a candidate that is dead there anyway.
     int cum = 0, lvl0 = 0, kA = 0;
@@ -376,7 +376,7 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
             const u64 lm = low_bits(S.len - 64 * b);
             m &= lm;
             s = (m ^ s) & lm;                             // exact inequality (the read's N bits flipped)
-            S.bufB[lane * EW + b] = make_uint4((u32)m, (u32)(m >> 32), (u32)s, (u32)(s >> 32));
+            S.bufB[lane * EW + b] = make_uint2((u32)m, (u32)(m >> 32));
             cum += __popcll(m);
             if (b == 0) {
                 lvl0 = __popcll(m & low_bits(S.bps));
@@ -437,11 +437,12 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
         if (mask == 0ull) continue;                       // uniform
         const int lB = opaque(lane);
         const int L = L0 + lB;
-        u64 Mk[NB], BP[NB];
+        u64 Mk[NB], BP[NB], QN[NB];
 #pragma unroll
         for (int b = 0; b < NB; b++) {
             Mk[b] = low_bits(L - 64 * b);
             BP[b] = bit_range(L - S.min_perfect - 64 * b, L - 64 * b);
+            QN[b] = q_nn<NB>(Q, b);
         }
         u32 m1 = A.m1, m2 = A.m2, ok = A.ok;
         Id wid = A.id;
@@ -454,17 +455,18 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
         while (mask != 0ull) {
             const int i = __ffsll((long long)mask) - 1;
             mask &= mask - 1ull;
-            const uint4 *e = S.bufB + i * EW;
+            const uint2 *e = S.bufB + i * EW;
             const uint2 h = S.hdrB[i];
             u32 k = 0u;
             u64 bad = 0ull;
 #pragma unroll
             for (int b = 0; b < NB; b++) {
                 if (b > r + 1) continue;                  // L <= bps + 64 r + 63 < 64 (r + 2)
-                const uint4 w = e[b];
-                const u64 m = (u64)w.x | ((u64)w.y << 32), sn = (u64)w.z | ((u64)w.w << 32);
+                const uint2 w = e[b];
+                const u64 m = (u64)w.x | ((u64)w.y << 32);
                 k += (u32)__popcll(b < r ? m : (m & Mk[b]));
-                if (b + 1 >= r) bad |= sn & BP[b];        // L - m >= 64 r - 64 (m <= 64 <= 64 + bps)
+                // exact inequality = mismatch with the read's N bits flipped (block_masks); the window lies inside the read
+                if (b + 1 >= r) bad |= (m ^ QN[b]) & BP[b];        // L - m >= 64 r - 64 (m <= 64 <= 64 + bps)
             }
             u32 okc = bad == 0ull ? (h.y >> 31) : 0u;
             if (S.len_check) okc = (u32)L >= ((h.y >> 8) & 0x7fu) ? okc : 0u;   // uniform branch
