@@ -5,11 +5,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <array>
+#include <atomic>
 #include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <fstream>
 #include <sstream>
+#include <thread>
 
 namespace pgh {
 
@@ -131,8 +134,69 @@ void Caller::update_ref_coverage(const std::vector<RefReadSpan> &reads, const st
     }
 }
 
-std::ofstream &Caller::report(int which)
+// the buffers of the worker that formats a box (for_boxes); null on any other thread
+static thread_local std::ostringstream *tl_box_out = nullptr;
+
+const char *Caller::ev_no(EvKind k)
 {
+    static const char *tok[EV_N] = { "\x01" "A", "\x01" "B", "\x01" "C", "\x01" "D", "\x01" "E" };
+    return tok[k];
+}
+
+unsigned Caller::take_event_number(int k)
+{
+    switch (k) {
+    case EV_D: d_template++; return (unsigned)(d_template + d_nontemplate - 1);
+    case EV_D_NT: d_nontemplate++; return (unsigned)(d_template + d_nontemplate - 1);
+    case EV_SI: return n_si++;
+    case EV_TD: return n_td++;
+    default: return n_inv++;
+    }
+}
+
+void Caller::for_boxes(unsigned n_boxes, const std::function<void(unsigned)> &body)
+{
+    std::vector<std::array<std::string, REP_N>> texts(n_boxes);
+    const unsigned nt = std::max(1u, std::min(host_threads(), n_boxes / 64u + 1u));
+    std::atomic<unsigned> next(0);
+    auto work = [&]() {
+        std::ostringstream os[REP_N];
+        tl_box_out = os;
+        for (unsigned b = next.fetch_add(1); b < n_boxes; b = next.fetch_add(1)) {
+            body(b);
+            for (int k = 0; k < REP_N; k++)
+                if (os[k].tellp() > 0) {
+                    texts[b][k] = os[k].str();
+                    os[k].str(std::string());
+                    os[k].clear();
+                }
+        }
+        tl_box_out = nullptr;
+    };
+    if (nt == 1) work();
+    else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++) th.emplace_back(work);
+        for (std::thread &x : th) x.join();
+    }
+    for (unsigned b = 0; b < n_boxes; b++)
+        for (int k = 0; k < REP_N; k++) {
+            const std::string &t = texts[b][k];
+            if (t.empty()) continue;
+            std::ostream &out = report(k);
+            size_t from = 0;
+            for (size_t at = t.find('\x01', from); at != std::string::npos; at = t.find('\x01', from)) {
+                out.write(t.data() + from, (std::streamsize)(at - from));
+                out << take_event_number(t[at + 1] - 'A');
+                from = at + 2;
+            }
+            out.write(t.data() + from, (std::streamsize)(t.size() - from));
+        }
+}
+
+std::ostream &Caller::report(int which)
+{
+    if (tl_box_out) return tl_box_out[which];
     static const char *suffixes[REP_N] = { "_D", "_SI", "_TD", "_INV" };
     std::ofstream &f = rep_[which];
     if (!f.is_open()) {
@@ -161,6 +225,39 @@ void Caller::note_close_mapped(SplitRead &r)
     else r.LeftMostPos = (int)(last.AbsLoc + close_len - r.getReadLength());
     r.SampleName2Number.insert(std::make_pair(r.Tag, 1u));
     g_sampleNames.insert(r.Tag);
+}
+
+void Caller::note_close_mapped_all(std::vector<SplitRead> &reads)
+{
+    const size_t n = reads.size();
+    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(host_threads(), n / 16384 + 1));
+    std::vector<short> max_len(nt, 0);
+    std::vector<std::set<std::string>> tags(nt);
+    auto work = [&](unsigned t) {
+        for (size_t i = n * t / nt; i < n * (t + 1) / nt; i++) {
+            SplitRead &r = reads[i];
+            if (r.UP_Close.empty()) continue;
+            if (max_len[t] < r.getReadLength()) max_len[t] = r.getReadLength();
+            r.Used = false;
+            r.UniqueRead = true;
+            const UniquePoint &last = r.UP_Close.back();
+            const short close_len = last.LengthStr;
+            if (r.MatchedD == '+') r.LeftMostPos = (int)(last.AbsLoc + 1 - close_len);
+            else r.LeftMostPos = (int)(last.AbsLoc + close_len - r.getReadLength());
+            r.SampleName2Number.insert(std::make_pair(r.Tag, 1u));
+            if (tags[t].empty() || !tags[t].count(r.Tag)) tags[t].insert(r.Tag);
+        }
+    };
+    if (nt == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++) th.emplace_back(work, t);
+        for (std::thread &x : th) x.join();
+    }
+    for (unsigned t = 0; t < nt; t++) {
+        if (g_reportLength < max_len[t]) g_reportLength = max_len[t];
+        g_sampleNames.insert(tags[t].begin(), tags[t].end());
+    }
 }
 
 // GetRealStart4Insertion, src/pindel.cpp:2134-2162
@@ -239,14 +336,14 @@ std::string Caller::support_columns(const std::vector<SplitRead> &ev, unsigned s
 // OutputDeletions, src/reporter.cpp:271-444
 void Caller::output_deletion(Ctx &c, std::vector<SplitRead> &g, unsigned s, unsigned e, unsigned rs, unsigned re)
 {
-    std::ofstream &out = report(REP_D);
+    std::ostream &out = report(REP_D);
     const std::string &ref = c.chrom->seq;
     const SplitRead &f = g[s];
     unsigned n_reads = 0;
     std::string sup = support_columns(g, s, e, f.BPLeft, f.BPRight, n_reads);
     short gap = f.IndelSize < 14 ? (short)f.IndelSize : (short)(13 + (int)log10((double)(f.IndelSize - 10)));
     out << HASHES << '\n';
-    out << (d_template + d_nontemplate) << "\tD " << f.IndelSize << "\tNT " << f.NT_size << " \"" << f.NT_str
+    out << ev_no(EV_D) << "\tD " << f.IndelSize << "\tNT " << f.NT_size << " \"" << f.NT_str
         << "\"\tChrID " << f.FragName << "\tBP " << f.BPLeft + 1 << "\t" << f.BPRight + 1 << "\tBP_range "
         << rs + 1 << "\t" << re + 1 << sup << '\n';
     const long rl = g_reportLength;
@@ -273,13 +370,13 @@ void Caller::output_deletion(Ctx &c, std::vector<SplitRead> &g, unsigned s, unsi
 // OutputDI, src/reporter.cpp:757-872
 void Caller::output_di(Ctx &c, std::vector<SplitRead> &g, unsigned s, unsigned e)
 {
-    std::ofstream &out = report(REP_D);
+    std::ostream &out = report(REP_D);
     const std::string &ref = c.chrom->seq;
     const SplitRead &f = g[s];
     unsigned n_reads = 0;
     std::string sup = support_columns(g, s, e, f.BPLeft, f.BPRight, n_reads);
     out << HASHES << '\n';
-    out << (d_template + d_nontemplate) << "\tD " << f.IndelSize << "\tNT " << f.NT_size << " \"" << f.NT_str
+    out << ev_no(EV_D_NT) << "\tD " << f.IndelSize << "\tNT " << f.NT_size << " \"" << f.NT_str
         << "\"\tChrID " << f.FragName << "\tBP " << f.BPLeft + 1 << "\t" << f.BPRight + 1 << "\tBP_range "
         << f.BPLeft + 1 << "\t" << f.BPRight + 1 << sup << '\n';
     const long rl = g_reportLength;
@@ -312,13 +409,13 @@ static std::string consensus_inserted(const std::vector<SplitRead> &g, unsigned 
 // OutputSIs, src/reporter.cpp:630-755
 void Caller::output_si(Ctx &c, std::vector<SplitRead> &g, unsigned s, unsigned e, unsigned rs, unsigned re)
 {
-    std::ofstream &out = report(REP_SI);
+    std::ostream &out = report(REP_SI);
     const std::string &ref = c.chrom->seq;
     const SplitRead &f = g[s];
     unsigned n_reads = 0;
     std::string sup = support_columns(g, s, e, f.BPLeft, f.BPRight, n_reads);
     out << HASHES << '\n';
-    out << n_si << "\tI " << f.IndelSize << "\tNT " << f.IndelSize << " \"" << consensus_inserted(g, s, e)
+    out << ev_no(EV_SI) << "\tI " << f.IndelSize << "\tNT " << f.IndelSize << " \"" << consensus_inserted(g, s, e)
         << "\"\tChrID " << f.FragName << "\tBP " << f.BPLeft + 1 << "\t" << f.BPRight + 1 << "\tBP_range "
         << rs + 1 << "\t" << re + 1 << sup << '\n';
     const long rl = g_reportLength;
@@ -332,7 +429,6 @@ void Caller::output_si(Ctx &c, std::vector<SplitRead> &g, unsigned s, unsigned e
         short after = (short)(rl + rl - before - r.getReadLength());
         out << std::string(after > 0 ? after : 0, ' ') << read_tail(r) << '\n';
     }
-    n_si++;
 }
 
 // SortOutputD, src/reporter.cpp:1395-1570
@@ -341,15 +437,15 @@ void Caller::sort_output_d(Ctx &c, std::vector<std::vector<unsigned>> &boxes)
     std::vector<SplitRead> &reads = *c.reads;
     const std::string &ref = c.chrom->seq;
     struct Ev { unsigned s, e, bl, br, rs, re; };
-    for (unsigned b = 0; b < c.NumBoxes; b++) {
+    for_boxes(c.NumBoxes, [&](unsigned b) {
         std::vector<unsigned> &box = boxes[b];
-        if (box.empty() || box.size() < S.NumRead2ReportCutOff) continue;
+        if (box.empty() || box.size() < S.NumRead2ReportCutOff) return;
         exchange_sort(reads, box);
         mark_duplicates(reads, box);
         std::vector<SplitRead> good;
         for (unsigned i : box)
             if (reads[i].UniqueRead) good.push_back(reads[i]);
-        if (good.empty()) continue;
+        if (good.empty()) return;
         std::vector<Ev> evs;
         Ev cur = { 0, 0, good[0].BPLeft, good[0].BPRight, 0, 0 };
         std::string cur_chr = good[0].FragName;
@@ -380,10 +476,9 @@ void Caller::sort_output_d(Ctx &c, std::vector<std::vector<unsigned>> &boxes)
             if (support < S.NumRead2ReportCutOff) continue;
             if (good[ev.s].IndelSize < S.BalanceCutoff || report_event(good, ev.s, ev.e)) {
                 output_deletion(c, good, ev.s, ev.e, ev.rs, ev.re);
-                d_template++;
             }
         }
-    }
+    });
 }
 
 // SortOutputDI, src/reporter.cpp:1709-1851
@@ -401,9 +496,9 @@ void Caller::sort_output_di(Ctx &c, std::vector<std::vector<unsigned>> &boxes)
     std::vector<SplitRead> &reads = *c.reads;
     const std::string &ref = c.chrom->seq;
     struct Ev { unsigned s, e, bl, isz; short nt; };
-    for (unsigned b = 0; b < c.NumBoxes; b++) {
+    for_boxes(c.NumBoxes, [&](unsigned b) {
         std::vector<unsigned> &box = boxes[b];
-        if (box.empty() || box.size() < S.NumRead2ReportCutOff) continue;
+        if (box.empty() || box.size() < S.NumRead2ReportCutOff) return;
         const size_t n = box.size();
         // the reference's own exchange sort for DI (reporter.cpp:1732-1768)
         for (size_t a = 0; a + 1 < n; a++)
@@ -436,7 +531,7 @@ void Caller::sort_output_di(Ctx &c, std::vector<std::vector<unsigned>> &boxes)
         std::vector<SplitRead> good;
         for (unsigned i : box)
             if (reads[i].UniqueRead) good.push_back(reads[i]);
-        if (good.empty()) continue;
+        if (good.empty()) return;
         std::vector<Ev> evs;
         Ev cur = { 0, 0, good[0].BPLeft, good[0].IndelSize, (short)good[0].NT_size };
         for (unsigned i = 1; i < good.size(); i++) {
@@ -458,11 +553,10 @@ void Caller::sort_output_di(Ctx &c, std::vector<std::vector<unsigned>> &boxes)
                     output_short_inv(c, good, ev.s, ev.e);
                 } else {
                     output_di(c, good, ev.s, ev.e);
-                    d_nontemplate++;
                 }
             }
         }
-    }
+    });
 }
 
 // SortOutputSI, src/reporter.cpp:975-1091
@@ -471,15 +565,15 @@ void Caller::sort_output_si(Ctx &c, std::vector<std::vector<unsigned>> &boxes)
     std::vector<SplitRead> &reads = *c.reads;
     const std::string &ref = c.chrom->seq;
     struct Ev { unsigned s, e, bl, br, isz, rs, re; std::string str; };
-    for (unsigned b = 0; b < c.NumBoxes; b++) {
+    for_boxes(c.NumBoxes, [&](unsigned b) {
         std::vector<unsigned> &box = boxes[b];
-        if (box.empty() || box.size() < S.NumRead2ReportCutOff) continue;
+        if (box.empty() || box.size() < S.NumRead2ReportCutOff) return;
         exchange_sort(reads, box);
         mark_duplicates(reads, box);
         std::vector<SplitRead> good;
         for (unsigned i : box)
             if (reads[i].UniqueRead) good.push_back(reads[i]);
-        if (good.empty()) continue;
+        if (good.empty()) return;
         std::vector<Ev> evs;
         auto init = [&](unsigned i) {
             Ev e;
@@ -510,7 +604,7 @@ void Caller::sort_output_si(Ctx &c, std::vector<std::vector<unsigned>> &boxes)
             unsigned short support = (unsigned short)(ev.e - ev.s + 1);
             if (support >= S.NumRead2ReportCutOff && ev.rs < ev.re) output_si(c, good, ev.s, ev.e, ev.rs, ev.re);
         }
-    }
+    });
 }
 
 // ---------------------------------------------------------------------------------
@@ -538,7 +632,8 @@ void Caller::search_variant(Ctx &c, int kind)
         printf("Reads already used: %u\nFar ends already mapped %u\nChecksum of far ends: %u\n", used, far, bp_sum);
     }
 
-    for (unsigned ri = 0; ri < reads.size(); ri++) {
+    classify_reads(reads.size(), boxes, [&](unsigned lo_, unsigned hi_, BoxSink &sink) {
+    for (unsigned ri = lo_; ri < hi_; ri++) {
         SplitRead &r = reads[ri];
         if (r.FragName != r.FarFragName) continue;
         if (r.Used || r.UP_Far.empty()) continue;
@@ -625,7 +720,7 @@ void Caller::search_variant(Ctx &c, int kind)
                     } else if (r.BPLeft + 1 >= c.region_start && r.BPLeft + 1 <= c.region_end) {
                         unsigned box = (unsigned)((int)r.BPLeft / (int)BoxSize);
                         if (box < c.NumBoxes) {
-                            boxes[box].push_back(ri);
+                            sink[box].push_back(ri);
                             r.Used = true;
                         }
                     }
@@ -633,6 +728,7 @@ void Caller::search_variant(Ctx &c, int kind)
             }
         }
     }
+    });
     if (kind == 0) sort_output_d(c, boxes);
     else sort_output_si(c, boxes);
 }
@@ -642,7 +738,8 @@ void Caller::search_indels(Ctx &c)
 {
     std::vector<SplitRead> &reads = *c.reads;
     std::vector<std::vector<unsigned>> boxes(c.NumBoxes);
-    for (unsigned ri = 0; ri < reads.size(); ri++) {
+    classify_reads(reads.size(), boxes, [&](unsigned lo_, unsigned hi_, BoxSink &sink) {
+    for (unsigned ri = lo_; ri < hi_; ri++) {
         SplitRead &r = reads[ri];
         if (r.Used || r.UP_Far.empty() || r.FragName != r.FarFragName) continue;
         const UniquePoint &cp = r.UP_Close.back();
@@ -680,11 +777,12 @@ void Caller::search_indels(Ctx &c)
         } else if (r.BPLeft + 1 >= c.region_start && r.BPLeft + 1 <= c.region_end) {
             unsigned box = (unsigned)((int)r.BPLeft / (int)BoxSize);
             if (box < c.NumBoxes) {
-                boxes[box].push_back(ri);
+                sink[box].push_back(ri);
                 r.Used = true;
             }
         }
     }
+    });
     sort_output_di(c, boxes);
 }
 

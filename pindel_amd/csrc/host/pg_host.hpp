@@ -20,6 +20,7 @@
 #include <map>
 #include <set>
 #include <fstream>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -96,6 +97,8 @@ public:
     // post-close-end bookkeeping of ReadInRead (reader.cpp:258-291): CloseEndLength, LeftMostPos,
     // g_reportLength, sample names.  Call once per read that has a close end.
     void note_close_mapped(SplitRead &r);
+    // ... for every read of `reads` that has a close end, on a few threads
+    void note_close_mapped_all(std::vector<SplitRead> &reads);
     unsigned long far_end_checksum = 0;
     // UpdateRefReadCoverage (pindel.cpp:1272-1330), BAM input: per sample (in the order of the sample-name set as
     // it stands now) the number of reference-supporting reads over every position of the window [start, end];
@@ -112,8 +115,16 @@ private:
     enum { REP_D = 0, REP_SI, REP_TD, REP_INV, REP_N };
     std::ofstream rep_[REP_N];
     std::vector<char> rep_buf_[REP_N];
-    std::ofstream &report(int which);
+    std::ostream &report(int which);        // the file -- or, inside for_boxes, the calling worker's buffer
     void flush_reports();
+    // The event number at the head of a report entry.  Entries are formatted box by box in parallel (for_boxes),
+    // so the number is a two-byte token in the text and becomes the running count when the boxes' texts are
+    // written in box order: D entries print template + non-template deletions so far.
+    enum EvKind { EV_D = 0, EV_D_NT, EV_SI, EV_TD, EV_INV, EV_N };
+    static const char *ev_no(EvKind k);
+    unsigned take_event_number(int k);
+    // body(b) for every box, on a few threads; what it wrote through report() lands in the files in box order
+    void for_boxes(unsigned n_boxes, const std::function<void(unsigned)> &body);
     Settings S;
     const std::vector<Chromosome> *genome;
     std::string prefix;

@@ -8,6 +8,9 @@
 #include <functional>
 #include <unordered_set>
 #include <utility>
+#include <cstdlib>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "pg_host.hpp"
@@ -232,5 +235,47 @@ inline void mark_duplicates(std::vector<SplitRead> &reads, const std::vector<uns
 }
 
 }  // namespace detail
+
+// The classifiers' per-read loops on a few threads: body(lo, hi, sink) runs the loop over reads [lo, hi) and queues
+// reads for boxes through sink[box].push_back(ri); afterwards the boxes receive them range by range, i.e. in ascending
+// read index like the sequential loop would have pushed them.  (Every iteration touches its own read only.)
+// threads for the classifiers and reporters: min(hardware, 16), or PGH_THREADS when set (1 = sequential)
+inline unsigned host_threads()
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw == 0) hw = 1;
+    unsigned v = std::min(hw, 16u);
+    if (const char *e = getenv("PGH_THREADS")) {
+        const int k = atoi(e);
+        if (k >= 1) v = (unsigned)std::min(k, 64);
+    }
+    return v;
+}
+
+struct BoxSink {
+    std::vector<std::pair<unsigned, unsigned>> v;
+    struct Ref {
+        BoxSink &s;
+        unsigned b;
+        void push_back(unsigned ri) { s.v.emplace_back(b, ri); }
+    };
+    Ref operator[](unsigned b) { return Ref{ *this, b }; }
+};
+template <class Body>
+inline void classify_reads(size_t n, std::vector<std::vector<unsigned>> &boxes, Body body)
+{
+    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(host_threads(), n / 8192 + 1));
+    std::vector<BoxSink> sinks(nt);
+    if (nt == 1) body(0u, (unsigned)n, sinks[0]);
+    else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++)
+            th.emplace_back([&, t]() { body((unsigned)(n * t / nt), (unsigned)(n * (t + 1) / nt), sinks[t]); });
+        for (std::thread &x : th) x.join();
+    }
+    for (BoxSink &s : sinks)
+        for (const auto &p : s.v) boxes[p.first].push_back(p.second);
+}
+
 }  // namespace pgh
 #endif

@@ -58,7 +58,8 @@ void Caller::search_tandem_dup(Ctx &c)
     std::vector<SplitRead> &reads = *c.reads;
     const std::string &ref = c.chrom->seq;
     std::vector<std::vector<unsigned>> boxes(c.NumBoxes);
-    for (unsigned ri = 0; ri < reads.size(); ri++) {
+    classify_reads(reads.size(), boxes, [&](unsigned lo_, unsigned hi_, BoxSink &sink) {
+    for (unsigned ri = lo_; ri < hi_; ri++) {
         SplitRead &r = reads[ri];
         if (r.Used || r.UP_Far.empty() || r.FragName != r.FarFragName) continue;
         const bool plus = r.MatchedD == '+';
@@ -108,11 +109,12 @@ void Caller::search_tandem_dup(Ctx &c)
                     }
                     if (r.BPLeft == 0) continue;
                     left_most_td(ref, S.spacer, r);
-                    PGH_BOX_READ(r, ri, boxes, true);
+                    PGH_BOX_READ(r, ri, sink, true);
                 }
             }
         }
     }
+    });
     sort_output_td(c, boxes, false);
 }
 
@@ -120,7 +122,8 @@ void Caller::search_tandem_dup_nt(Ctx &c)
 {
     std::vector<SplitRead> &reads = *c.reads;
     std::vector<std::vector<unsigned>> boxes(c.NumBoxes);
-    for (unsigned ri = 0; ri < reads.size(); ri++) {
+    classify_reads(reads.size(), boxes, [&](unsigned lo_, unsigned hi_, BoxSink &sink) {
+    for (unsigned ri = lo_; ri < hi_; ri++) {
         SplitRead &r = reads[ri];
         if (r.Used || r.UP_Far.empty() || r.FragName != r.FarFragName) continue;
         const UniquePoint &cp = r.UP_Close.back();
@@ -156,21 +159,22 @@ void Caller::search_tandem_dup_nt(Ctx &c)
         } else {
             continue;
         }
-        PGH_BOX_READ(r, ri, boxes, true);
+        PGH_BOX_READ(r, ri, sink, true);
     }
+    });
     sort_output_td(c, boxes, true);
 }
 
 // OutputTDs, src/reporter.cpp:157-269
 void Caller::output_td(Ctx &c, std::vector<SplitRead> &g, unsigned s, unsigned e, unsigned, unsigned)
 {
-    std::ofstream &out = report(REP_TD);
+    std::ostream &out = report(REP_TD);
     const std::string &ref = c.chrom->seq;
     const SplitRead &f = g[s];
     unsigned n_reads = 0;
     std::string sup = support_columns(g, s, e, f.BPLeft - 1, f.BPRight + 1, n_reads);
     out << HASHES << '\n';
-    out << n_td << "\tTD " << f.IndelSize << "\tNT " << f.NT_size << " \"" << f.NT_str << "\"\tChrID "
+    out << ev_no(EV_TD) << "\tTD " << f.IndelSize << "\tNT " << f.NT_size << " \"" << f.NT_str << "\"\tChrID "
         << f.FragName << "\tBP " << f.BPLeft << "\t" << f.BPRight + 2 << "\tBP_range " << f.BPLeft << "\t"
         << f.BPRight + 2 << sup << '\n';
     const long rl = g_reportLength;
@@ -191,15 +195,15 @@ void Caller::sort_output_td(Ctx &c, std::vector<std::vector<unsigned>> &boxes, b
     std::vector<SplitRead> &reads = *c.reads;
     const std::string &ref = c.chrom->seq;
     struct Ev { unsigned s, e, bl, br, rs, re; };
-    for (unsigned b = 0; b < c.NumBoxes; b++) {
+    for_boxes(c.NumBoxes, [&](unsigned b) {
         std::vector<unsigned> &box = boxes[b];
-        if (box.empty() || box.size() < S.NumRead2ReportCutOff) continue;
+        if (box.empty() || box.size() < S.NumRead2ReportCutOff) return;
         exchange_sort(reads, box);                       // bubblesortReads
         mark_duplicates(reads, box);                     // markDuplicates
         std::vector<SplitRead> good;
         for (unsigned i : box)
             if (reads[i].UniqueRead) good.push_back(reads[i]);
-        if (good.empty()) continue;
+        if (good.empty()) return;
         std::vector<Ev> evs;
         Ev cur = { 0, 0, good[0].BPLeft, good[0].BPRight, 0, 0 };
         auto close_event = [&]() {
@@ -224,10 +228,9 @@ void Caller::sort_output_td(Ctx &c, std::vector<std::vector<unsigned>> &boxes, b
             if (ev.re < ev.rs || ev.rs == 0) continue;
             if (good[ev.s].IndelSize < S.BalanceCutoff || report_event(good, ev.s, ev.e)) {
                 output_td(c, good, ev.s, ev.e, ev.rs, ev.re);
-                n_td++;
             }
         }
-    }
+    });
 }
 
 // ------------------------------------------------------------------------------ inversions
@@ -266,7 +269,8 @@ void Caller::search_inversions(Ctx &c)
     const std::string &ref = c.chrom->seq;
     std::vector<std::vector<unsigned>> boxes(c.NumBoxes);
     const unsigned MIN = (unsigned)S.MIN_IndelSize_Inversion;
-    for (unsigned ri = 0; ri < reads.size(); ri++) {
+    classify_reads(reads.size(), boxes, [&](unsigned lo_, unsigned hi_, BoxSink &sink) {
+    for (unsigned ri = lo_; ri < hi_; ri++) {
         SplitRead &r = reads[ri];
         if (r.Used || r.UP_Far.empty() || r.FragName != r.FarFragName) continue;
         if (!(r.UP_Close[0].Strand != r.UP_Far[0].Strand && r.UP_Close[0].Direction == r.UP_Far[0].Direction))
@@ -334,11 +338,12 @@ void Caller::search_inversions(Ctx &c)
                     r.NT_str = "";
                     r.NT_size = 0;
                     left_most_inv(ref, S.spacer, r);
-                    PGH_BOX_READ(r, ri, boxes, plus);   // the '-' branches skip the bin-border test
+                    PGH_BOX_READ(r, ri, sink, plus);   // the '-' branches skip the bin-border test
                 }
             }
         }
     }
+    });
     sort_output_inv(c, boxes, false);
 }
 
@@ -347,7 +352,8 @@ void Caller::search_inversions_nt(Ctx &c)
     std::vector<SplitRead> &reads = *c.reads;
     std::vector<std::vector<unsigned>> boxes(c.NumBoxes);
     const unsigned MIN = (unsigned)S.MIN_IndelSize_Inversion;
-    for (unsigned ri = 0; ri < reads.size(); ri++) {
+    classify_reads(reads.size(), boxes, [&](unsigned lo_, unsigned hi_, BoxSink &sink) {
+    for (unsigned ri = lo_; ri < hi_; ri++) {
         SplitRead &r = reads[ri];
         if (r.Used || r.UP_Far.empty() || r.FragName != r.FarFragName) continue;
         const UniquePoint &cp = r.UP_Close.back();
@@ -370,7 +376,7 @@ void Caller::search_inversions_nt(Ctx &c)
                 r.NT_str = sub(reverse_complement(r.UnmatchedSeq), r.BP + 1, r.NT_size);
                 r.BPLeft = cp.AbsLoc + 1 - S.spacer;
                 r.BPRight = fp.AbsLoc - S.spacer;
-                PGH_BOX_READ(r, ri, boxes, true);
+                PGH_BOX_READ(r, ri, sink, true);
             }
             if (fp.AbsLoc + MIN < cp.AbsLoc) {
                 r.Right = (int)(cp.AbsLoc - cp.LengthStr + r.getReadLength());
@@ -381,7 +387,7 @@ void Caller::search_inversions_nt(Ctx &c)
                 r.NT_str = sub(r.UnmatchedSeq, r.BP + 1, r.NT_size);
                 r.BPRight = cp.AbsLoc - S.spacer;
                 r.BPLeft = (fp.AbsLoc + 1) - S.spacer;
-                PGH_BOX_READ(r, ri, boxes, true);
+                PGH_BOX_READ(r, ri, sink, true);
             }
         } else if (r.MatchedD == '-') {
             if (fp.Direction != '-') continue;
@@ -394,7 +400,7 @@ void Caller::search_inversions_nt(Ctx &c)
                 r.NT_str = sub(r.UnmatchedSeq, r.BP + 1, r.NT_size);
                 r.BPLeft = fp.AbsLoc - S.spacer;
                 r.BPRight = cp.AbsLoc - 1 - S.spacer;
-                PGH_BOX_READ(r, ri, boxes, true);
+                PGH_BOX_READ(r, ri, sink, true);
             }
             if (cp.AbsLoc + MIN < fp.AbsLoc) {
                 r.Right = (int)(fp.AbsLoc + fp.LengthStr - 1);
@@ -405,17 +411,18 @@ void Caller::search_inversions_nt(Ctx &c)
                 r.NT_str = sub(reverse_complement(r.UnmatchedSeq), r.BP + 1, r.NT_size);
                 r.BPLeft = cp.AbsLoc - S.spacer;
                 r.BPRight = fp.AbsLoc - 1 - S.spacer;
-                PGH_BOX_READ(r, ri, boxes, true);
+                PGH_BOX_READ(r, ri, sink, true);
             }
         }
     }
+    });
     sort_output_inv(c, boxes, true);
 }
 
 // OutputInversions, src/reporter.cpp:446-628
 void Caller::output_inv(Ctx &c, std::vector<SplitRead> &g, unsigned s, unsigned e, unsigned, unsigned)
 {
-    std::ofstream &out = report(REP_INV);
+    std::ostream &out = report(REP_INV);
     const std::string &ref = c.chrom->seq;
     const SplitRead &f = g[s];
     short lnt = 0, rnt = 0;
@@ -435,7 +442,7 @@ void Caller::output_inv(Ctx &c, std::vector<SplitRead> &g, unsigned s, unsigned 
     unsigned n_reads = 0;
     std::string sup = support_columns(g, s, e, f.BPLeft - 1, f.BPRight + 1, n_reads);
     out << HASHES << '\n';
-    out << n_inv++ << "\tINV " << f.IndelSize << "\tNT " << lnt << ":" << rnt << " \"" << lstr << "\":\"" << rstr
+    out << ev_no(EV_INV) << "\tINV " << f.IndelSize << "\tNT " << lnt << ":" << rnt << " \"" << lstr << "\":\"" << rstr
         << "\"\tChrID " << f.FragName << "\tBP " << f.BPLeft + 1 - 1 << "\t" << f.BPRight + 1 + 1 << "\tBP_range "
         << f.BPLeft + 1 - 1 << "\t" << f.BPRight + 1 + 1 << sup << '\n';
     const long rl = g_reportLength;
@@ -471,13 +478,13 @@ void Caller::output_inv(Ctx &c, std::vector<SplitRead> &g, unsigned s, unsigned 
 // OutputShortInversion, src/reporter.cpp:1588-1696
 void Caller::output_short_inv(Ctx &c, std::vector<SplitRead> &g, unsigned s, unsigned e)
 {
-    std::ofstream &out = report(REP_INV);
+    std::ostream &out = report(REP_INV);
     const std::string &ref = c.chrom->seq;
     const SplitRead &f = g[s];
     unsigned n_reads = 0;
     std::string sup = support_columns(g, s, e, f.BPLeft, f.BPRight, n_reads);
     out << HASHES << '\n';
-    out << n_inv++ << "\tINV " << f.IndelSize << "\tNT " << f.NT_size << " \"" << f.NT_str << "\"\tChrID "
+    out << ev_no(EV_INV) << "\tINV " << f.IndelSize << "\tNT " << f.NT_size << " \"" << f.NT_str << "\"\tChrID "
         << f.FragName << "\tBP " << f.BPLeft + 1 << "\t" << f.BPRight + 1 << "\tBP_range " << f.BPLeft + 1 << "\t"
         << f.BPRight + 1 << sup << '\n';
     const long rl = g_reportLength;
@@ -498,9 +505,9 @@ void Caller::sort_output_inv(Ctx &c, std::vector<std::vector<unsigned>> &boxes, 
 {
     std::vector<SplitRead> &reads = *c.reads;
     struct Ev { unsigned s, e, rs, re; };
-    for (unsigned b = 0; b < c.NumBoxes; b++) {
+    for_boxes(c.NumBoxes, [&](unsigned b) {
         std::vector<unsigned> &box = boxes[b];
-        if (box.empty() || box.size() < S.NumRead2ReportCutOff) continue;
+        if (box.empty() || box.size() < S.NumRead2ReportCutOff) return;
         const size_t n = box.size();
         for (size_t a = 0; a + 1 < n; a++)
             for (size_t d = a + 1; d < n; d++) {
@@ -535,7 +542,7 @@ void Caller::sort_output_inv(Ctx &c, std::vector<std::vector<unsigned>> &boxes, 
             }
         std::vector<SplitRead> good;                 // ALL reads of the box, unique or not
         for (unsigned i : box) good.push_back(reads[i]);
-        if (good.empty()) continue;
+        if (good.empty()) return;
         std::vector<Ev> evs;
         unsigned cs = 0, ce = 0, cbl = good[0].BPLeft, cbr = good[0].BPRight;
         bool whether = true;                          // never re-armed inside a box (output_sorter.cpp:150)
@@ -578,7 +585,7 @@ void Caller::sort_output_inv(Ctx &c, std::vector<std::vector<unsigned>> &boxes, 
             if (good[ev.s].IndelSize < S.BalanceCutoff || report_event(good, ev.s, ev.e))
                 output_inv(c, good, ev.s, ev.e, ev.rs, ev.re);
         }
-    }
+    });
 }
 
 }  // namespace pgh

@@ -83,13 +83,15 @@ int run_pipeline(const std::vector<Chromosome> &genome, const std::vector<unsign
             if (bins[w].empty()) continue;
             const unsigned ws = starts[w], we = std::min(ws + WINDOW, global_end);
             double t0 = now();
-            std::vector<SplitRead> reads;
-            reads.reserve(bins[w].size());
-            for (uint32_t i : bins[w]) {
-                reads.push_back(all[i]);
-                if (reads.back().MatchedRelPos > biol) reads.back().MatchedRelPos = biol;   // reader.cpp:233-235
-                reads.back().MAX_SNP_ERROR = (short)S.max_mismatch[std::min<int>(all[i].ReadLength, 499)];
-            }
+            std::vector<SplitRead> reads(bins[w].size());
+            pg_adapter::parallel_ranges(reads.size(), [&](size_t lo, size_t hi) {
+                for (size_t k = lo; k < hi; k++) {
+                    const uint32_t i = bins[w][k];
+                    reads[k] = all[i];
+                    if (reads[k].MatchedRelPos > biol) reads[k].MatchedRelPos = biol;   // reader.cpp:233-235
+                    reads[k].MAX_SNP_ERROR = (short)S.max_mismatch[std::min<int>(all[i].ReadLength, 499)];
+                }
+            });
             t_copy += now() - t0; t0 = now();
             int rc = search(chrom, (int)c, reads, bins[w]);
             if (rc) {
@@ -97,12 +99,10 @@ int run_pipeline(const std::vector<Chromosome> &genome, const std::vector<unsign
                 return rc;
             }
             t_search += now() - t0; t0 = now();
-            std::vector<SplitRead> kept;                                // reader.cpp:258-291
+            caller.note_close_mapped_all(reads);                        // reader.cpp:258-291
+            std::vector<SplitRead> kept;
             for (SplitRead &r : reads)
-                if (!r.UP_Close.empty()) {
-                    caller.note_close_mapped(r);
-                    kept.push_back(std::move(r));      // `reads` is not used after this loop
-                }
+                if (!r.UP_Close.empty()) kept.push_back(std::move(r));      // `reads` is not used after this loop
             t_keep += now() - t0; t0 = now();
             if (!kept.empty()) caller.process_window(chrom, kept, ws, we, bed_start, bed_end);
             t_call += now() - t0;
@@ -195,12 +195,10 @@ int run_bam_pipeline(const std::vector<Chromosome> &genome, const std::vector<un
                 err = "search step failed";
                 return rc;
             }
+            caller.note_close_mapped_all(reads);
             std::vector<SplitRead> kept;
             for (SplitRead &r : reads)
-                if (!r.UP_Close.empty()) {
-                    caller.note_close_mapped(r);
-                    kept.push_back(std::move(r));
-                }
+                if (!r.UP_Close.empty()) kept.push_back(std::move(r));
             {   // UpdateRefReadCoverage, after the close ends (sample names) and before the classifiers
                 std::vector<Caller::RefReadSpan> spans(in.ref_reads.size());
                 for (size_t i = 0; i < spans.size(); i++) {

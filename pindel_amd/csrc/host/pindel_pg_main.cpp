@@ -133,7 +133,11 @@ int main(int argc, char **argv)
                 return 2;
             }
         }
-        // -T (threads: the search runs on the GPU), -n, -A, -L: accepted, no effect on this path
+        else if (key == "-T") {
+            // host threads of the classifiers / reporters (the search itself runs on the GPU); PGH_THREADS wins
+            if (iv >= 1) setenv("PGH_THREADS", std::to_string(iv).c_str(), 0);
+        }
+        // -L: accepted, no effect on this path
     }
     // -G 0,1,...: the reads of every bin are sharded over these devices in contiguous ranges (reads are
     // independent: the loop of SearchFarEnds / ReadBuffer::flush, src/pindel.cpp:1115-1138), reference

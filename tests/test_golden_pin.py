@@ -39,6 +39,26 @@ def test_oracle_pinned_by_gold_reports(tmp_path):
     gu.assert_reports_match_gold(prefix)
 
 
+def test_reports_do_not_depend_on_host_threads(tmp_path, monkeypatch):
+    """The classifiers run their per-read loops and the reporters format their boxes on several threads
+    (PGH_THREADS; reads reach the boxes and boxes reach the files in the sequential order): same bytes, = gold."""
+    fa, reads_txt, chroms, batch = _load(tmp_path)
+    p = pyoracle.make_params()
+    r = pyoracle.search_batch(p, [s for _, s in chroms], batch.seq, batch.seq_off, batch.anchor_strand,
+                              batch.anchor_pos, batch.insert_size, batch.chr_id)
+    co, cp = gu.csr_from_strided(r["close_cnt"], r["close_pts"])
+    fo, fp = gu.csr_from_strided(r["far_cnt"], r["far_pts"])
+    st = hostlib.default_settings(pyoracle.max_mismatch_table())
+    outs = {}
+    for threads in ("1", "2", "7", "16"):
+        monkeypatch.setenv("PGH_THREADS", threads)
+        prefix = str(tmp_path / f"t{threads}")
+        hostlib.call_from_points(fa, reads_txt, prefix, st, co, cp, fo, fp, r["rc_flag"])
+        gu.assert_reports_match_gold(prefix)
+        outs[threads] = [open(f"{prefix}_{s}", "rb").read() for s in gu.SUFFIXES]
+    assert outs["1"] == outs["2"] == outs["7"] == outs["16"]
+
+
 @pytest.mark.gpu
 def test_gpu_path_reproduces_gold_reports(tmp_path, engine_factory):
     from pindel_amd import binding
