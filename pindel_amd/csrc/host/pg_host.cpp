@@ -134,13 +134,21 @@ void Caller::update_ref_coverage(const std::vector<RefReadSpan> &reads, const st
     }
 }
 
-// the buffers of the worker that formats a box (for_boxes); null on any other thread
+// the buffers of the worker that formats a box (for_boxes) and the places of the event numbers in them;
+// null on any other thread
+struct EvMark { size_t at; int kind; };
 static thread_local std::ostringstream *tl_box_out = nullptr;
+static thread_local std::vector<EvMark> *tl_box_marks = nullptr;
 
-const char *Caller::ev_no(EvKind k)
+std::ostream &operator<<(std::ostream &out, Caller::EvNo e)
 {
-    static const char *tok[EV_N] = { "\x01" "A", "\x01" "B", "\x01" "C", "\x01" "D", "\x01" "E" };
-    return tok[k];
+    if (tl_box_out)
+        for (int k = 0; k < 4; k++)
+            if (&out == static_cast<std::ostream *>(&tl_box_out[k])) {
+                tl_box_marks[k].push_back(EvMark{ (size_t)out.tellp(), (int)e.kind });
+                break;
+            }
+    return out;
 }
 
 unsigned Caller::take_event_number(int k)
@@ -156,22 +164,31 @@ unsigned Caller::take_event_number(int k)
 
 void Caller::for_boxes(unsigned n_boxes, const std::function<void(unsigned)> &body)
 {
-    std::vector<std::array<std::string, REP_N>> texts(n_boxes);
+    struct BoxText {
+        std::string text[REP_N];
+        std::vector<EvMark> marks[REP_N];
+    };
+    std::vector<BoxText> texts(n_boxes);
     const unsigned nt = std::max(1u, std::min(host_threads(), n_boxes / 64u + 1u));
     std::atomic<unsigned> next(0);
     auto work = [&]() {
         std::ostringstream os[REP_N];
+        std::vector<EvMark> marks[REP_N];
         tl_box_out = os;
+        tl_box_marks = marks;
         for (unsigned b = next.fetch_add(1); b < n_boxes; b = next.fetch_add(1)) {
             body(b);
             for (int k = 0; k < REP_N; k++)
                 if (os[k].tellp() > 0) {
-                    texts[b][k] = os[k].str();
+                    texts[b].text[k] = os[k].str();
+                    texts[b].marks[k].swap(marks[k]);
+                    marks[k].clear();
                     os[k].str(std::string());
                     os[k].clear();
                 }
         }
         tl_box_out = nullptr;
+        tl_box_marks = nullptr;
     };
     if (nt == 1) work();
     else {
@@ -181,14 +198,14 @@ void Caller::for_boxes(unsigned n_boxes, const std::function<void(unsigned)> &bo
     }
     for (unsigned b = 0; b < n_boxes; b++)
         for (int k = 0; k < REP_N; k++) {
-            const std::string &t = texts[b][k];
+            const std::string &t = texts[b].text[k];
             if (t.empty()) continue;
             std::ostream &out = report(k);
             size_t from = 0;
-            for (size_t at = t.find('\x01', from); at != std::string::npos; at = t.find('\x01', from)) {
-                out.write(t.data() + from, (std::streamsize)(at - from));
-                out << take_event_number(t[at + 1] - 'A');
-                from = at + 2;
+            for (const EvMark &m : texts[b].marks[k]) {
+                out.write(t.data() + from, (std::streamsize)(m.at - from));
+                out << take_event_number(m.kind);
+                from = m.at;
             }
             out.write(t.data() + from, (std::streamsize)(t.size() - from));
         }

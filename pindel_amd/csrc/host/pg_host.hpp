@@ -118,10 +118,13 @@ private:
     std::ostream &report(int which);        // the file -- or, inside for_boxes, the calling worker's buffer
     void flush_reports();
     // The event number at the head of a report entry.  Entries are formatted box by box in parallel (for_boxes),
-    // so the number is a two-byte token in the text and becomes the running count when the boxes' texts are
-    // written in box order: D entries print template + non-template deletions so far.
+    // so `out << ev_no(kind)` writes nothing and only marks the place; the number -- the running count of that kind
+    // (D entries print template + non-template deletions so far) -- is put in when the boxes' texts are written in
+    // box order.
     enum EvKind { EV_D = 0, EV_D_NT, EV_SI, EV_TD, EV_INV, EV_N };
-    static const char *ev_no(EvKind k);
+    struct EvNo { EvKind kind; };
+    static EvNo ev_no(EvKind k) { EvNo e = { k }; return e; }
+    friend std::ostream &operator<<(std::ostream &out, EvNo e);
     unsigned take_event_number(int k);
     // body(b) for every box, on a few threads; what it wrote through report() lands in the files in box order
     void for_boxes(unsigned n_boxes, const std::function<void(unsigned)> &body);
