@@ -27,7 +27,13 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
 #include <string>
+#include <string_view>
+#include <thread>
 #include <unordered_map>
 #include <utility>
 #include <vector>
@@ -264,13 +270,26 @@ public:
             hdr_.lengths.push_back(l_ref);
         }
         first_record_ = z_.tell();
-        bins_.clear();
-        linear_.clear();
+        idx_.reset();
         if (use_index) load_index();
         return true;
     }
+    // a second reader of the same file (own file handle; header and index shared): for reading sub-ranges of a
+    // window on several threads
+    bool open_like(const BamFile &o, std::string &err)
+    {
+        path_ = o.path_;
+        if (!z_.open(path_)) {
+            err = "cannot open " + path_;
+            return false;
+        }
+        hdr_ = o.hdr_;
+        first_record_ = o.first_record_;
+        idx_ = o.idx_;
+        return true;
+    }
     const BamHeader &header() const { return hdr_; }
-    bool has_index() const { return !bins_.empty(); }
+    bool has_index() const { return idx_ && !idx_->bins.empty(); }
 
     // next record of the stream; false at the end
     bool next(BamRecord &r)
@@ -279,7 +298,13 @@ public:
         if (!z_.read(&block_size, 4) || block_size < 32) return false;
         buf_.resize((size_t)block_size);
         if (!z_.read(buf_.data(), (size_t)block_size)) return false;
-        const uint8_t *p = buf_.data();
+        return decode(buf_.data(), (size_t)block_size, r);
+    }
+    // the bytes of the record `next` delivered last (block_size bytes, without the length word)
+    const std::vector<uint8_t> &last_raw() const { return buf_; }
+    // one record from its bytes
+    static bool decode(const uint8_t *p, size_t block_size, BamRecord &r)
+    {
         auto i32 = [&](size_t o) { return (int32_t)(p[o] | (p[o + 1] << 8) | (p[o + 2] << 16) | ((uint32_t)p[o + 3] << 24)); };
         r.tid = i32(0);
         r.pos = i32(4);
@@ -292,7 +317,7 @@ public:
         r.mpos = i32(24);
         r.tlen = i32(28);
         size_t o = 32;
-        if (r.l_seq < 0 || o + l_read_name + 4u * n_cigar + (size_t)(r.l_seq + 1) / 2 + (size_t)r.l_seq > (size_t)block_size) return false;
+        if (r.l_seq < 0 || o + l_read_name + 4u * n_cigar + (size_t)(r.l_seq + 1) / 2 + (size_t)r.l_seq > block_size) return false;
         r.qname.assign((const char *)p + o, l_read_name ? l_read_name - 1 : 0);
         o += l_read_name;
         r.cigar.resize(n_cigar);
@@ -300,7 +325,7 @@ public:
         o += 4u * n_cigar;
         r.seq4.assign(p + o, p + o + (size_t)(r.l_seq + 1) / 2);
         o += (size_t)(r.l_seq + 1) / 2 + (size_t)r.l_seq;        // + qualities
-        r.aux.assign(p + o, p + (size_t)block_size);
+        r.aux.assign(p + o, p + block_size);
         return true;
     }
 
@@ -318,6 +343,8 @@ public:
                 if (r.tid == tid && r.pos < end && r.end_pos() > beg) fn(r);
             return true;
         }
+        const BaiBins &bins_ = idx_->bins;
+        const std::vector<std::vector<uint64_t>> &linear_ = idx_->linear;
         if ((size_t)tid >= bins_.size()) return true;
         // reg2bins (SAM specification section 5.3)
         std::vector<uint32_t> want;
@@ -340,8 +367,11 @@ public:
         }
         std::sort(chunks.begin(), chunks.end());
         std::vector<std::pair<uint64_t, uint64_t>> merged;
+        // chunks that touch, overlap or lie within 256 KB of file of each other are read in one go (the records in
+        // between fail the overlap test below)
         for (const auto &c : chunks) {
-            if (!merged.empty() && c.first <= merged.back().second) merged.back().second = std::max(merged.back().second, c.second);
+            if (!merged.empty() && (c.first >> 16) <= (merged.back().second >> 16) + (256u << 10))
+                merged.back().second = std::max(merged.back().second, c.second);
             else merged.push_back(c);
         }
         for (const auto &c : merged) {
@@ -360,8 +390,7 @@ private:
     }
     void load_index()
     {
-        bins_.clear();
-        linear_.clear();
+        idx_.reset();
         FILE *f = fopen((path_ + ".bai").c_str(), "rb");
         if (!f) {
             std::string alt = path_;
@@ -369,12 +398,10 @@ private:
             f = fopen(alt.c_str(), "rb");
         }
         if (!f) return;
-        const bool ok = read_bai(f, bins_, linear_);
+        std::shared_ptr<Index> ix(new Index());
+        const bool ok = read_bai(f, ix->bins, ix->linear);
         fclose(f);
-        if (!ok) {
-            bins_.clear();
-            linear_.clear();
-        }
+        if (ok) idx_ = ix;
     }
 
 public:
@@ -420,8 +447,11 @@ private:
     BamHeader hdr_;
     uint64_t first_record_ = 0;
     std::vector<uint8_t> buf_;
-    BaiBins bins_;
-    std::vector<std::vector<uint64_t>> linear_;
+    struct Index {
+        BaiBins bins;
+        std::vector<std::vector<uint64_t>> linear;
+    };
+    std::shared_ptr<const Index> idx_;
 };
 
 // ------------------------------------------------------------------------------------------ read selection
@@ -472,27 +502,118 @@ public:
     {
         if (out.batch.off.empty()) out.batch.off.push_back(0);
         const int tid = bam.header().id_of(chr_name);
-        std::unordered_map<std::string, BamRecord> waiting;         // read_to_map_qual: first mate seen, by name
         bool ok = true;
-        const bool q = bam.query(tid, win_start, win_end, [&](const BamRecord &b1) {
-            if (!ok) return;
-            auto it = waiting.find(b1.qname);
-            if (it == waiting.end()) {
-                // first of its name: remember it; a read that is "weird" is its own anchor
-                waiting.emplace(b1.qname, b1);
-                if (is_weird(b1)) ok = build_record(bam, b1, b1, chr_id, chr_padded_size, insert_size, tag, out);
-                return;
-            }
-            const BamRecord b2 = it->second;
-            waiting.erase(it);
+        // fetch_func_SR, the two cases: the first record of a name (a read that is "weird" is its own anchor), and
+        // the second one together with the first (b2)
+        auto first_of_name = [&](const BamRecord &b1) {
+            if (is_weird(b1)) ok = ok && build_record(bam, b1, b1, chr_id, chr_padded_size, insert_size, tag, out);
+        };
+        auto pair_complete = [&](const BamRecord &b1, const BamRecord &b2) {
             if (is_weird(b2)) ok = ok && build_record(bam, b2, b2, chr_id, chr_padded_size, insert_size, tag, out);
             if (is_good_anchor(b1) && is_weird(b2)) ok = ok && build_record(bam, b1, b2, chr_id, chr_padded_size, insert_size, tag, out);
             if (is_good_anchor(b1) && is_ref_read(b2)) add_ref_read(b2, tag, out);
             if (is_good_anchor(b2) && is_weird(b1)) ok = ok && build_record(bam, b2, b1, chr_id, chr_padded_size, insert_size, tag, out);
             if (is_good_anchor(b2) && is_ref_read(b1)) add_ref_read(b1, tag, out);
-        });
+        };
+        std::unordered_map<std::string, BamRecord> waiting;         // read_to_map_qual: first mate seen, by name
+        auto take = [&](const BamRecord &b1) {                      // the records in file order
+            if (!ok) return;
+            auto it = waiting.find(b1.qname);
+            if (it == waiting.end()) {
+                waiting.emplace(b1.qname, b1);
+                first_of_name(b1);
+                return;
+            }
+            const BamRecord b2 = it->second;
+            waiting.erase(it);
+            pair_complete(b1, b2);
+        };
+        // With an index (= a coordinate-sorted file) the window is cut into sub-ranges by start position; every
+        // sub-range is inflated and decoded by its own reader on its own thread (BGZF inflation and record decoding
+        // are most of the ingest time), and the records then pass through the selection above in file order: a
+        // sub-range keeps the records that START in it (the first one also those that reach into the window).
+        const unsigned nt = tid >= 0 && bam.has_index() ? std::min<unsigned>(ingest_threads(), (unsigned)((win_end - win_start) >> 18) + 1u) : 1u;
+        if (nt > 1) {
+            struct Part {
+                std::vector<uint8_t> bytes;        // the records that start in the sub-range, back to back
+                std::vector<uint64_t> ends;        // end offset of each in `bytes`
+                bool ok = true;
+            };
+            std::vector<Part> parts(nt);
+            std::vector<std::thread> th;
+            const double tq0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+            for (unsigned t = 0; t < nt; t++)
+                th.emplace_back([&, t]() {
+                    BamFile mine;
+                    std::string err;
+                    Part &part = parts[t];
+                    if (!mine.open_like(bam, err)) {
+                        part.ok = false;
+                        return;
+                    }
+                    const int64_t lo = win_start + (win_end - win_start) * (int64_t)t / nt;
+                    const int64_t hi = win_start + (win_end - win_start) * (int64_t)(t + 1) / nt;
+                    part.ok = mine.query(tid, lo, hi, [&](const BamRecord &r) {
+                        if (t != 0 && r.pos < lo) return;
+                        const std::vector<uint8_t> &raw = mine.last_raw();
+                        part.bytes.insert(part.bytes.end(), raw.begin(), raw.end());
+                        part.ends.push_back(part.bytes.size());
+                    });
+                });
+            for (std::thread &x : th) x.join();
+            const double tq1 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+            if (getenv("PGH_TIMING")) { size_t nb = 0, nr = 0; for (const Part &q : parts) { nb += q.bytes.size(); nr += q.ends.size(); } fprintf(stderr, "ingest: %u threads, read phase %.3f s, %zu records, %zu bytes\n", nt, tq1 - tq0, nr, nb); }
+            for (const Part &part : parts)
+                if (!part.ok) {
+                    error = "BAM read failed";
+                    return false;
+                }
+            // the same pairing on the records' bytes, which stay where they are: the name is a view into them and the
+            // first mate is decoded again when the second one arrives (no per-record copies)
+            struct Raw { const uint8_t *p; size_t n; };
+            std::unordered_map<std::string_view, Raw> waiting_raw;
+            BamRecord r, r2;
+            for (const Part &part : parts) {
+                uint64_t from = 0;
+                for (uint64_t to : part.ends) {
+                    const uint8_t *p = part.bytes.data() + from;
+                    const size_t n = (size_t)(to - from);
+                    from = to;
+                    if (!ok) continue;
+                    if (!BamFile::decode(p, n, r)) {
+                        error = "BAM read failed";
+                        return false;
+                    }
+                    const std::string_view name((const char *)p + 32, r.qname.size());
+                    auto it = waiting_raw.find(name);
+                    if (it == waiting_raw.end()) {
+                        waiting_raw.emplace(name, Raw{ p, n });
+                        first_of_name(r);
+                        continue;
+                    }
+                    (void)BamFile::decode(it->second.p, it->second.n, r2);
+                    waiting_raw.erase(it);
+                    pair_complete(r, r2);
+                }
+            }
+            return ok;
+        }
+        const bool q = bam.query(tid, win_start, win_end, take);
         if (!q) error = "BAM read failed";
         return q && ok;
+    }
+
+    // threads of read_window: min(hardware, 16), or PGH_THREADS
+    static unsigned ingest_threads()
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        if (hw == 0) hw = 1;
+        unsigned v = std::min(hw, 16u);
+        if (const char *e = getenv("PGH_THREADS")) {
+            const int k = atoi(e);
+            if (k >= 1) v = (unsigned)std::min(k, 64);
+        }
+        return v;
     }
 
 private:

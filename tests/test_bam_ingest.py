@@ -324,6 +324,25 @@ def test_reference_bai_files_parse(name, n_ref):
     assert all(w[0] >= 8 and w[3] == 13 for w in want)
 
 
+def test_ingest_does_not_depend_on_host_threads(tmp_path, monkeypatch):
+    """With an index a window is inflated and decoded sub-range by sub-range on several threads (PGH_THREADS) and the
+    records then pass through the pairing in file order: same batch, same reference reads, for any thread count."""
+    rng = np.random.default_rng(99)
+    ref_len = 3_000_000
+    recs = _messy_records(rng, 8000, ref_len)
+    bam = tmp_path / "threads.bam"
+    bw.write_bam(str(bam), [("chrZ", ref_len)], recs, with_index=True, block_bytes=0x4000)
+    got = {}
+    for threads in ("1", "3", "8", "16"):
+        monkeypatch.setenv("PGH_THREADS", threads)
+        refs = []
+        got[threads] = (ingest(bam, "chrZ", 0, ref_len + 200000, 0, ref_len, 450, ref_reads=refs), refs)
+    assert len(got["1"][0]) > 3000 and len(got["1"][1]) > 500
+    assert got["1"] == got["3"] == got["8"] == got["16"]
+    monkeypatch.delenv("PGH_THREADS")
+    assert got["1"][0] == ingest(bam, "chrZ", 0, ref_len + 200000, 0, ref_len, 450, use_index=False)
+
+
 def test_insert_size_not_above_read_length_is_an_error(tmp_path):
     bam = tmp_path / "short_insert.bam"
     recs = _pairs_for_text_records([("@x/1", "ACGT" * 25, "+", 5000, 37, 500, "S")])
