@@ -382,6 +382,51 @@ public:
         return true;
     }
 
+    // The same query cut into `parts` sub-ranges by start position, each read by its own reader (own file handle, shared
+    // header and index) on its own thread: fn(part, record, reader) is called on that thread for the records that START
+    // in the sub-range (part 0: also those that only reach into [beg, end)), in file order within the part -- so the
+    // parts taken one after the other are the records of query() in the same order, for a coordinate-sorted file
+    // (which a file with an index is).  Threads: min(hardware, 16) or PGH_THREADS.
+    static unsigned worker_threads()
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        if (hw == 0) hw = 1;
+        unsigned v = std::min(hw, 16u);
+        if (const char *e = getenv("PGH_THREADS")) {
+            const int k = atoi(e);
+            if (k >= 1) v = (unsigned)std::min(k, 64);
+        }
+        return v;
+    }
+    unsigned split_parts(int tid, int64_t beg, int64_t end) const
+    {
+        if (tid < 0 || !has_index() || end <= beg) return 1;
+        return std::min<unsigned>(worker_threads(), (unsigned)((end - beg) >> 18) + 1u);
+    }
+    template <class Fn>
+    bool query_split(int tid, int64_t beg, int64_t end, unsigned parts, Fn fn) const
+    {
+        std::vector<int> part_ok(parts, 1);
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < parts; t++)
+            th.emplace_back([&, t]() {
+                BamFile mine;
+                std::string err;
+                if (!mine.open_like(*this, err)) {
+                    part_ok[t] = 0;
+                    return;
+                }
+                const int64_t lo = beg + (end - beg) * (int64_t)t / parts, hi = beg + (end - beg) * (int64_t)(t + 1) / parts;
+                part_ok[t] = mine.query(tid, lo, hi, [&](const BamRecord &r) {
+                    if (t == 0 || r.pos >= lo) fn(t, r, mine);
+                }) ? 1 : 0;
+            });
+        for (std::thread &x : th) x.join();
+        for (unsigned t = 0; t < parts; t++)
+            if (!part_ok[t]) return false;
+        return true;
+    }
+
 private:
     bool bad(std::string &err)
     {
@@ -532,42 +577,21 @@ public:
         // sub-range is inflated and decoded by its own reader on its own thread (BGZF inflation and record decoding
         // are most of the ingest time), and the records then pass through the selection above in file order: a
         // sub-range keeps the records that START in it (the first one also those that reach into the window).
-        const unsigned nt = tid >= 0 && bam.has_index() ? std::min<unsigned>(ingest_threads(), (unsigned)((win_end - win_start) >> 18) + 1u) : 1u;
+        const unsigned nt = bam.split_parts(tid, win_start, win_end);
         if (nt > 1) {
             struct Part {
                 std::vector<uint8_t> bytes;        // the records that start in the sub-range, back to back
                 std::vector<uint64_t> ends;        // end offset of each in `bytes`
-                bool ok = true;
             };
             std::vector<Part> parts(nt);
-            std::vector<std::thread> th;
-            const double tq0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-            for (unsigned t = 0; t < nt; t++)
-                th.emplace_back([&, t]() {
-                    BamFile mine;
-                    std::string err;
-                    Part &part = parts[t];
-                    if (!mine.open_like(bam, err)) {
-                        part.ok = false;
-                        return;
-                    }
-                    const int64_t lo = win_start + (win_end - win_start) * (int64_t)t / nt;
-                    const int64_t hi = win_start + (win_end - win_start) * (int64_t)(t + 1) / nt;
-                    part.ok = mine.query(tid, lo, hi, [&](const BamRecord &r) {
-                        if (t != 0 && r.pos < lo) return;
-                        const std::vector<uint8_t> &raw = mine.last_raw();
-                        part.bytes.insert(part.bytes.end(), raw.begin(), raw.end());
-                        part.ends.push_back(part.bytes.size());
-                    });
-                });
-            for (std::thread &x : th) x.join();
-            const double tq1 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-            if (getenv("PGH_TIMING")) { size_t nb = 0, nr = 0; for (const Part &q : parts) { nb += q.bytes.size(); nr += q.ends.size(); } fprintf(stderr, "ingest: %u threads, read phase %.3f s, %zu records, %zu bytes\n", nt, tq1 - tq0, nr, nb); }
-            for (const Part &part : parts)
-                if (!part.ok) {
-                    error = "BAM read failed";
-                    return false;
-                }
+            if (!bam.query_split(tid, win_start, win_end, nt, [&](unsigned t, const BamRecord &, const BamFile &reader) {
+                    const std::vector<uint8_t> &raw = reader.last_raw();
+                    parts[t].bytes.insert(parts[t].bytes.end(), raw.begin(), raw.end());
+                    parts[t].ends.push_back(parts[t].bytes.size());
+                })) {
+                error = "BAM read failed";
+                return false;
+            }
             // the same pairing on the records' bytes, which stay where they are: the name is a view into them and the
             // first mate is decoded again when the second one arrives (no per-record copies)
             struct Raw { const uint8_t *p; size_t n; };
@@ -601,19 +625,6 @@ public:
         const bool q = bam.query(tid, win_start, win_end, take);
         if (!q) error = "BAM read failed";
         return q && ok;
-    }
-
-    // threads of read_window: min(hardware, 16), or PGH_THREADS
-    static unsigned ingest_threads()
-    {
-        unsigned hw = std::thread::hardware_concurrency();
-        if (hw == 0) hw = 1;
-        unsigned v = std::min(hw, 16u);
-        if (const char *e = getenv("PGH_THREADS")) {
-            const int k = atoi(e);
-            if (k >= 1) v = (unsigned)std::min(k, 64);
-        }
-        return v;
     }
 
 private:

@@ -49,7 +49,7 @@ inline bool rp_discover(BamFile &bam, const std::string &chr_name, int64_t win_s
 {
     const BamHeader &hdr = bam.header();
     const int tid = hdr.id_of(chr_name);
-    return bam.query(tid, win_start, win_end, [&](const BamRecord &r) {
+    auto consider = [&](const BamRecord &r, std::vector<RpRead> &dst) {
         if (!(r.flag & BAM_FPAIRED)) return;
         if (r.mapq < min_anchor_quality) return;
         if ((r.flag & BAM_FUNMAP) || (r.flag & BAM_FMUNMAP)) return;                     // both mates mapped
@@ -73,8 +73,18 @@ inline bool rp_discover(BamFile &bam, const std::string &chr_name, int64_t win_s
             std::swap(t.OriginalPosA, t.OriginalPosB);
             std::swap(t.ChrNameA, t.ChrNameB);
         }
-        out.push_back(t);
-    });
+        dst.push_back(t);
+    };
+    // with an index: sub-ranges of the window on several threads, taken in order afterwards (BamFile::query_split)
+    const unsigned nt = bam.split_parts(tid, win_start, win_end);
+    if (nt > 1) {
+        std::vector<std::vector<RpRead>> parts(nt);
+        if (!bam.query_split(tid, win_start, win_end, nt, [&](unsigned t, const BamRecord &r, const BamFile &) { consider(r, parts[t]); }))
+            return false;
+        for (const std::vector<RpRead> &part : parts) out.insert(out.end(), part.begin(), part.end());
+        return true;
+    }
+    return bam.query(tid, win_start, win_end, [&](const BamRecord &r) { consider(r, out); });
 }
 
 namespace rp_detail {
