@@ -4,6 +4,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <algorithm>
 #include <array>
 #include <atomic>
@@ -69,34 +70,82 @@ int load_fasta(const std::string &path, std::vector<Chromosome> &out, unsigned s
 int load_pindel_text(const std::string &path, const std::vector<Chromosome> &genome,
                      std::vector<SplitRead> &out, std::string &err)
 {
-    std::ifstream in(path.c_str());
-    if (!in) {
+    // Three lines per record, taken in order from the top whatever they contain (PindelReadReader: getline x 3); the
+    // list ends at an empty name line or at an incomplete record.  The file is read in one piece, cut into lines,
+    // and the records are parsed on several threads; the first malformed record (in file order) is the error.
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) {
         err = "cannot open " + path;
         return -1;
     }
-    std::string l1, l2, l3;
-    while (std::getline(in, l1)) {
-        if (l1.empty()) break;
-        if (!std::getline(in, l2) || !std::getline(in, l3)) break;
-        SplitRead r;
-        r.Name = l1;
-        while (!l2.empty() && !isalnum((unsigned char)l2[l2.size() - 1])) l2.resize(l2.size() - 1);
-        r.UnmatchedSeq = l2;
-        r.ReadLength = (short)l2.size();
-        std::istringstream iss(l3);
-        iss >> r.MatchedD >> r.FragName >> r.MatchedRelPos >> r.MS >> r.InsertSize >> r.Tag;
-        if (l1[0] != '@') {
-            err = "Something wrong with the read name: " + l1;
-            return -1;
-        }
-        if (r.MatchedD != '+' && r.MatchedD != '-') {
-            err = "+/- expected in read " + l1;
-            return -1;
-        }
-        for (size_t c = 0; c < genome.size(); c++)
-            if (genome[c].name == r.FragName) r.chr_id = (int)c;
-        out.push_back(r);
+    std::string buf;
+    {
+        char tmp[1 << 16];
+        size_t k;
+        fseeko(f, 0, SEEK_END);
+        const off_t sz = ftello(f);
+        fseeko(f, 0, SEEK_SET);
+        if (sz > 0) buf.reserve((size_t)sz);
+        while ((k = fread(tmp, 1, sizeof tmp, f)) > 0) buf.append(tmp, k);
+        fclose(f);
     }
+    std::vector<size_t> ls;                                   // line starts; line i = [ls[i], ls[i + 1] - 1)
+    for (size_t at = 0; at < buf.size();) {
+        ls.push_back(at);
+        const void *nl = memchr(buf.data() + at, '\n', buf.size() - at);
+        at = nl ? (size_t)((const char *)nl - buf.data()) + 1 : buf.size() + 1;
+    }
+    const size_t n_lines = ls.size();
+    ls.push_back(buf.size() + 1);
+    auto line = [&](size_t i) { return std::string(buf.data() + ls[i], std::min(ls[i + 1] - 1, buf.size()) - ls[i]); };
+    size_t n_rec = n_lines / 3;
+    for (size_t k = 0; k < n_rec; k++)
+        if (std::min(ls[3 * k + 1] - 1, buf.size()) == ls[3 * k]) {                 // empty name line: end of the list
+            n_rec = k;
+            break;
+        }
+    const size_t base = out.size();
+    out.resize(base + n_rec);
+    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(host_threads(), n_rec / 8192 + 1));
+    std::vector<size_t> first_bad(nt, (size_t)-1);
+    std::vector<std::string> bad_msg(nt);
+    auto work = [&](unsigned t) {
+        for (size_t k = n_rec * t / nt; k < n_rec * (t + 1) / nt; k++) {
+            SplitRead &r = out[base + k];
+            const std::string l1 = line(3 * k), l3 = line(3 * k + 2);
+            std::string l2 = line(3 * k + 1);
+            r.Name = l1;
+            while (!l2.empty() && !isalnum((unsigned char)l2[l2.size() - 1])) l2.resize(l2.size() - 1);
+            r.ReadLength = (short)l2.size();
+            r.UnmatchedSeq.swap(l2);
+            std::istringstream iss(l3);
+            iss >> r.MatchedD >> r.FragName >> r.MatchedRelPos >> r.MS >> r.InsertSize >> r.Tag;
+            if (l1[0] != '@') {
+                first_bad[t] = k;
+                bad_msg[t] = "Something wrong with the read name: " + l1;
+                return;
+            }
+            if (r.MatchedD != '+' && r.MatchedD != '-') {
+                first_bad[t] = k;
+                bad_msg[t] = "+/- expected in read " + l1;
+                return;
+            }
+            for (size_t c = 0; c < genome.size(); c++)
+                if (genome[c].name == r.FragName) r.chr_id = (int)c;
+        }
+    };
+    if (nt == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++) th.emplace_back(work, t);
+        for (std::thread &x : th) x.join();
+    }
+    for (unsigned t = 0; t < nt; t++)
+        if (first_bad[t] != (size_t)-1) {
+            err = bad_msg[t];
+            out.resize(base + first_bad[t]);
+            return -1;
+        }
     return 0;
 }
 

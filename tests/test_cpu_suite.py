@@ -233,3 +233,37 @@ def test_breakdancer_hints_match_the_restatement(tmp_path):
     rc = L.pgh_bd_query(str(bad).encode(), spacer, 3, arr, 0, spacer, spacer + 1000, 0, None, off.ctypes.data,
                         win.ctypes.data, cap, C.byref(nev))
     assert rc == 1 and nev.value == 0                    # ignored, like CheckBreakDancerFileFormat
+
+
+def test_pindel_text_loader_framing_and_errors(tmp_path):
+    """load_pindel_text: three lines per record from the top, the list ends at an empty name line or an incomplete record,
+    the FIRST malformed record is the error (the parser runs on several threads)."""
+    import ctypes as C
+    import numpy as np
+    from pindel_amd import hostlib
+    from oracle import pyoracle
+    fa = tmp_path / "r.fa"
+    fa.write_text(">c1\n" + "ACGT" * 500 + "\n")
+    st = hostlib.default_settings(pyoracle.max_mismatch_table())
+    empty_pts = np.zeros(0, dtype=pyoracle.POINT_DTYPE)
+
+    def run(text, n):
+        rp = tmp_path / "reads.txt"
+        rp.write_bytes(text)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        hostlib.call_from_points(str(fa), str(rp), str(tmp_path / "o"), st, off, empty_pts, off, empty_pts, np.zeros(n, dtype=np.uint8))
+
+    rec = lambda k, strand=b"+", name=None: (name or b"@r%d/1" % k) + b"\n" + b"ACGTACGTAC" * 3 + b"\n" + strand + b"\tc1\t%d\t60\t500\tS\n" % (100 + k)
+    good = b"".join(rec(k) for k in range(20000))
+    run(good, 20000)                                                        # 20000 records, all accepted
+    run(good + b"@tail/1\nACGT\n", 20000)                                   # incomplete last record: dropped
+    run(b"".join(rec(k) for k in range(100)) + b"\n" + good, 100)           # an empty name line ends the list
+    for bad_at, bad, msg in ((15000, rec(15000, name=b"r15000"), "Something wrong with the read name: r15000"),
+                             (7, rec(7, strand=b"x"), "+/- expected in read @r7/1")):
+        text = b"".join(bad if k == bad_at else rec(k) for k in range(20000))
+        with pytest.raises(RuntimeError, match=msg.replace("+", "\\+")):
+            run(text, 20000)
+    # two malformed records: the first one in the file is reported
+    text = b"".join(rec(k, strand=b"x") if k in (300, 19000) else rec(k) for k in range(20000))
+    with pytest.raises(RuntimeError, match="expected in read @r300/1"):
+        run(text, 20000)
