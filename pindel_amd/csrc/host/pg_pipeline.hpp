@@ -35,6 +35,19 @@ inline std::vector<unsigned> read_fai(const std::string &fasta_path, const std::
     return fai;
 }
 
+// Frees the strings and point lists of a window's reads on several threads (the destructors of ~10^7 reads are
+// seconds of single-threaded work otherwise); the vector itself is left empty.
+inline void release_reads(std::vector<SplitRead> &v)
+{
+    pg_adapter::parallel_ranges(v.size(), [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) {
+            SplitRead gone;
+            std::swap(gone, v[i]);
+        }
+    });
+    std::vector<SplitRead>().swap(v);
+}
+
 // search(chrom, chr_id, reads, index_in_all): must fill UP_Close / UP_Far of every read (leaving
 // UP_Close empty when there is no close end) and leave UnmatchedSeq as GetCloseEnd would.
 template <class Search>
@@ -46,7 +59,7 @@ int run_pipeline(const std::vector<Chromosome> &genome, const std::vector<unsign
     const unsigned WINDOW = (unsigned)(S.window_mbp * 1000000);
     // PGH_TIMING=1: wall-clock seconds per stage of this loop on stderr (diagnostics)
     const bool timing = getenv("PGH_TIMING") != nullptr;
-    double t_copy = 0, t_search = 0, t_keep = 0, t_call = 0;
+    double t_copy = 0, t_search = 0, t_keep = 0, t_call = 0, t_free = 0;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     // The Pindel-text reader rescans the whole file for every window and raises g_maxPos for EVERY read it
     // passes (reader.cpp:224-226), so after the first window of a chromosome g_maxPos is the largest position
@@ -105,12 +118,15 @@ int run_pipeline(const std::vector<Chromosome> &genome, const std::vector<unsign
                 if (!r.UP_Close.empty()) kept.push_back(std::move(r));      // `reads` is not used after this loop
             t_keep += now() - t0; t0 = now();
             if (!kept.empty()) caller.process_window(chrom, kept, ws, we, bed_start, bed_end);
-            t_call += now() - t0;
+            t_call += now() - t0; t0 = now();
+            release_reads(kept);
+            release_reads(reads);
+            t_free += now() - t0;
         }
     }
     if (timing)
-        fprintf(stderr, "pgh timing: pipeline: copy reads %.3f s, search step %.3f s, keep %.3f s, classify + report %.3f s\n",
-                t_copy, t_search, t_keep, t_call);
+        fprintf(stderr, "pgh timing: pipeline: copy reads %.3f s, search step %.3f s, keep %.3f s, classify + report %.3f s, free %.3f s\n",
+                t_copy, t_search, t_keep, t_call, t_free);
     return 0;
 }
 
@@ -209,6 +225,8 @@ int run_bam_pipeline(const std::vector<Chromosome> &genome, const std::vector<un
                 caller.update_ref_coverage(spans, in.ref_tags, ws, we);
             }
             if (!kept.empty()) caller.process_window(chrom, kept, ws, we, bed_start, bed_end);
+            release_reads(kept);
+            release_reads(reads);
         }
     }
     return 0;
