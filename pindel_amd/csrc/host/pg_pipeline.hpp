@@ -114,6 +114,11 @@ int run_pipeline(const std::vector<Chromosome> &genome, const std::vector<unsign
             t_search += now() - t0; t0 = now();
             caller.note_close_mapped_all(reads);                        // reader.cpp:258-291
             std::vector<SplitRead> kept;
+            {
+                size_t n_kept = 0;
+                for (const SplitRead &r : reads) n_kept += r.UP_Close.empty() ? 0 : 1;
+                kept.reserve(n_kept);
+            }
             for (SplitRead &r : reads)
                 if (!r.UP_Close.empty()) kept.push_back(std::move(r));      // `reads` is not used after this loop
             t_keep += now() - t0; t0 = now();
@@ -213,6 +218,11 @@ int run_bam_pipeline(const std::vector<Chromosome> &genome, const std::vector<un
             }
             caller.note_close_mapped_all(reads);
             std::vector<SplitRead> kept;
+            {
+                size_t n_kept = 0;
+                for (const SplitRead &r : reads) n_kept += r.UP_Close.empty() ? 0 : 1;
+                kept.reserve(n_kept);
+            }
             for (SplitRead &r : reads)
                 if (!r.UP_Close.empty()) kept.push_back(std::move(r));
             {   // UpdateRefReadCoverage, after the close ends (sample names) and before the classifiers
