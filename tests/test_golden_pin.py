@@ -59,6 +59,42 @@ def test_reports_do_not_depend_on_host_threads(tmp_path, monkeypatch):
     assert outs["1"] == outs["2"] == outs["7"] == outs["16"]
 
 
+def test_reports_thread_independent_on_a_larger_synthetic_set(tmp_path, monkeypatch):
+    """40 000 synthetic reads (all SV types) on a 2-Mbp reference, points from the oracle: several thousand events in
+    hundreds of boxes; the four reports are the same bytes on 1 and on 8 host threads."""
+    from pindel_amd import synth
+    n, length = 40_000, 2_000_000
+    ref = synth.make_reference(length, seed=31)
+    biol = ref[100000:-100000]
+    fa = tmp_path / "ref.fa"
+    with open(fa, "wb") as f:
+        f.write(b">chrS\n")
+        for i in range(0, len(biol), 60):
+            f.write(biol[i:i + 60] + b"\n")
+    b = synth.make_reads(ref, n, seed=32)
+    order = np.argsort(b.anchor_pos, kind="stable")
+    seq = np.asarray(b.seq).reshape(n, 100)
+    reads_txt = tmp_path / "reads.txt"
+    with open(reads_txt, "wb") as f:
+        for k, i in enumerate(order):
+            f.write(b"@r%d/1\n" % k + seq[i].tobytes() + b"\n" + bytes([b.anchor_strand[i]]) +
+                    b"\tchrS\t%d\t60\t500\tS1\n" % int(b.anchor_pos[i]))
+    p = pyoracle.make_params()
+    r = pyoracle.search_batch(p, [ref], seq[order].reshape(-1), (np.arange(n + 1) * 100).astype(np.uint64), b.anchor_strand[order],
+                              b.anchor_pos[order], b.insert_size[order], b.chr_id[order])
+    co, cp = gu.csr_from_strided(r["close_cnt"], r["close_pts"])
+    fo, fp = gu.csr_from_strided(r["far_cnt"], r["far_pts"])
+    st = hostlib.default_settings(pyoracle.max_mismatch_table())
+    outs = {}
+    for threads in ("1", "8"):
+        monkeypatch.setenv("PGH_THREADS", threads)
+        prefix = str(tmp_path / f"t{threads}")
+        hostlib.call_from_points(str(fa), str(reads_txt), prefix, st, co, cp, fo, fp, r["rc_flag"])
+        outs[threads] = [open(f"{prefix}_{s}", "rb").read() for s in gu.SUFFIXES]
+    assert outs["1"] == outs["8"]
+    assert outs["1"][0].count(b"\tD ") > 300 and outs["1"][1].count(b"\tI ") > 300      # hundreds of events
+
+
 @pytest.mark.gpu
 def test_gpu_path_reproduces_gold_reports(tmp_path, engine_factory):
     from pindel_amd import binding
