@@ -164,10 +164,24 @@ int  pg_reference_fetch(const pg_ctx *ctx, int32_t chr_id, uint64_t start, uint6
 
 /* ---- the path, host buffers in / host results out ---------------------- */
 int  pg_close_end_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_result **out);
-/* `close` must be the result of pg_close_end_batch on the same reads (it carries
- * UP_Close and the rc flags); it is extended in place with UP_Far. */
+/* Both seams on ONE read vector: `close` must be the result of pg_close_end_batch on the same reads, given here in
+ * their ORIGINAL orientation (the result carries UP_Close and the rc flags); it is extended in place with UP_Far.
+ * The reference's own call site has a different vector by then -- see pg_far_end_batch_from_close. */
 int  pg_far_end_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_result *close,
                       const pg_windows *bd_hints /* nullable */);
+/* Seam 2 exactly where the reference calls it: SearchFarEnds(chrSeq, state.Reads_SR, chr), src/pindel.cpp:1115-1138,
+ * called at :1888 on the FILTERED UNION of many flushes -- ReadBuffer::flush keeps only the reads that got a close end
+ * (src/read_buffer.cpp:55-64), 50 000 raw reads at a time (src/reader.cpp:55).  So this entry takes the reads as the
+ * close end left them (UnmatchedSeq already reverse-complemented where GetCloseEnd did so, src/pindel.cpp:2545) and,
+ * per read, the two things SearchFarEnd reads from UP_Close:
+ *   close_last[i] = UP_Close.back().AbsLoc      getLastAbsLocCloseEnd(), src/pindel.cpp:475-478 (centre of the ranges)
+ *   close_max[i]  = UP_Close.back().LengthStr   UP_Close.MaxLen(), src/pindel.cpp:480-483, 490-498 (goodFarEndFound);
+ *                                               <= 0: the read has no close end and is not searched
+ * No result of an earlier call is needed; anchor_strand / anchor_pos / insert_size of the batch are not read by the far
+ * end (they must still be valid arrays).  The result holds UP_Far (far_off / far_runs); its close lists are empty and
+ * its rc flags zero. */
+int  pg_far_end_batch_from_close(pg_ctx *ctx, const pg_read_batch *reads, const uint32_t *close_last,
+                                 const int16_t *close_max, const pg_windows *bd_hints /* nullable */, pg_result **out);
 int  pg_search_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_result **out);
 
 /* Multi-GPU form of pg_search_batch: the reads are split into n_ctx contiguous ranges (reads are independent:

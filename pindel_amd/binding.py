@@ -64,6 +64,7 @@ EXPORTS = [
     "pg_default_params", "pg_create", "pg_destroy", "pg_last_error", "pg_get_max_mismatch",
     "pg_load_reference", "pg_load_fasta", "pg_reference_save_packed", "pg_reference_load_packed", "pg_reference_n_chr", "pg_reference_name",
     "pg_reference_comp_size", "pg_reference_fetch", "pg_close_end_batch", "pg_far_end_batch",
+    "pg_far_end_batch_from_close",
     "pg_search_batch", "pg_search_batch_multi", "pg_result_view_get", "pg_result_free", "pg_expand_runs",
     "pg_device_batch_upload", "pg_device_batch_set_windows", "pg_device_batch_search", "pg_device_batch_download",
     "pg_device_batch_free", "pg_last_search_stats", "pg_device_batch_algorithmic_bytes",
@@ -124,6 +125,7 @@ def lib():
     L.pg_reference_fetch.argtypes = [vp, i32, u64, u64, vp]
     L.pg_close_end_batch.argtypes = [vp, C.POINTER(PgReadBatch), C.POINTER(vp)]
     L.pg_far_end_batch.argtypes = [vp, C.POINTER(PgReadBatch), vp, C.POINTER(PgWindows)]
+    L.pg_far_end_batch_from_close.argtypes = [vp, C.POINTER(PgReadBatch), vp, vp, C.POINTER(PgWindows), C.POINTER(vp)]
     L.pg_search_batch.argtypes = [vp, C.POINTER(PgReadBatch), C.POINTER(vp)]
     L.pg_search_batch_multi.argtypes = [C.POINTER(vp), i32, C.POINTER(PgReadBatch), C.POINTER(vp)]
     L.pg_result_view_get.argtypes = [vp, C.POINTER(PgResultView)]
@@ -304,6 +306,21 @@ class Engine:
                                              C.byref(w) if w is not None else None))
         close.refresh()
         return close
+
+    def far_end_batch_from_close(self, batch, close_last, close_max, bd=None, bd_off=None) -> Result:
+        """pg_far_end_batch_from_close: the reads as the close end left them + UP_Close.back()'s AbsLoc / LengthStr."""
+        s, keep = _batch_struct(batch)
+        cl = np.ascontiguousarray(close_last, dtype=np.uint32)
+        cm = np.ascontiguousarray(close_max, dtype=np.int16)
+        w = None
+        if bd is not None:
+            bd = np.ascontiguousarray(bd, dtype=WINDOW_DTYPE)
+            bd_off = np.ascontiguousarray(bd_off, dtype=np.uint64)
+            w = PgWindows(bd_off.ctypes.data, bd.ctypes.data)
+        h = C.c_void_p()
+        self._check(self._L.pg_far_end_batch_from_close(self._h, C.byref(s), cl.ctypes.data, cm.ctypes.data,
+                                                        C.byref(w) if w is not None else None, C.byref(h)))
+        return Result(h, self)
 
     def search_batch(self, batch) -> Result:
         s, keep = _batch_struct(batch)

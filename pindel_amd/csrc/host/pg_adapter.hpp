@@ -4,7 +4,10 @@
 //                                          (src/read_buffer.cpp:36-101) and of the two OpenMP
 //                                          loops in ReadInRead (src/reader.cpp:248-255, 300-305)
 //   SearchFarEnds(ctx, reads, hints)       replaces SearchFarEnds(chrSeq, reads, chr)
-//                                          (src/pindel.cpp:1115-1138)
+//                                          (src/pindel.cpp:1115-1138, called at :1888 on state.Reads_SR =
+//                                          the reads ReadBuffer::flush kept, src/read_buffer.cpp:55-64):
+//                                          needs nothing but the reads themselves -- UnmatchedSeq as the
+//                                          close end left it and UP_Close.back()
 //
 // Both are templates over the read type so that they compile unchanged against the
 // reference's SPLIT_READ (fields Name/UnmatchedSeq/MatchedD/MatchedRelPos/InsertSize/FragName/
@@ -168,7 +171,40 @@ int CloseEndBatch(pg_ctx *ctx, std::vector<Read> &reads, ChrOf chr_of, MakePoint
     return PG_OK;
 }
 
-// Far end for the reads of CloseEndBatch (same order, same count).  `hints` may be null.
+// Far end at the reference's own call site (src/pindel.cpp:1888): `reads` is whatever vector the caller holds by
+// then -- the reads of many CloseEndBatch flushes that kept a close end, in any order -- each carrying UnmatchedSeq
+// as GetCloseEnd left it and a non-empty UP_Close (a read with an empty UP_Close is passed through: no far end).
+// `hints` may be null.
+template <class Read, class ChrOf, class MakePoint>
+int SearchFarEnds(pg_ctx *ctx, std::vector<Read> &reads, ChrOf chr_of, MakePoint make_point, const pg_windows *hints)
+{
+    Batch b = make_batch(reads, chr_of);
+    const size_t n = reads.size();
+    std::vector<uint32_t> close_last(n);
+    std::vector<int16_t> close_max(n);
+    parallel_ranges(n, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) {
+            const bool has = !reads[i].UP_Close.empty();
+            close_last[i] = has ? (uint32_t)reads[i].UP_Close[reads[i].UP_Close.size() - 1].AbsLoc : 0u;   // getLastAbsLocCloseEnd
+            close_max[i] = has ? (int16_t)reads[i].UP_Close[reads[i].UP_Close.size() - 1].LengthStr : (int16_t)0;   // MaxLen
+        }
+    });
+    pg_read_batch v = b.view();
+    pg_result *res = nullptr;
+    int rc_ = pg_far_end_batch_from_close(ctx, &v, close_last.data(), close_max.data(), hints, &res);
+    if (rc_) return rc_;
+    pg_result_view rv;
+    pg_result_view_get(res, &rv);
+    parallel_ranges(n, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++)
+            fill_points(reads[i].UP_Far, rv.far_runs, rv.far_off[i], rv.far_off[i + 1], make_point);
+    });
+    pg_result_free(res);
+    return PG_OK;
+}
+
+// Both seams on ONE read vector (same order, same count as CloseEndBatch; saves the close-summary upload when a
+// caller does keep the flush's reads together).  `hints` may be null.
 template <class Read, class ChrOf, class MakePoint>
 int SearchFarEnds(pg_ctx *ctx, std::vector<Read> &reads, ChrOf chr_of, MakePoint make_point,
                   pg_result *close_result, const pg_windows *hints)

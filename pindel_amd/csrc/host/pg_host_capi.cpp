@@ -86,7 +86,7 @@ int pgh_call_from_points(const char *fasta_path, const char *reads_path, const c
         }
         return 0;
     };
-    return run_pipeline(genome, fai, all, S, out_prefix, attach, g_err);
+    return run_pipeline(genome, fai, all, S, out_prefix, attach, pgh::NoFarSearch(), g_err);
 }
 
 // BreakDancer hints (pg_bdhints.hpp) for one bin: clusters of the reads whose last close-end point is at

@@ -48,15 +48,27 @@ inline void release_reads(std::vector<SplitRead> &v)
     std::vector<SplitRead>().swap(v);
 }
 
-// search(chrom, chr_id, reads, index_in_all): must fill UP_Close / UP_Far of every read (leaving
-// UP_Close empty when there is no close end) and leave UnmatchedSeq as GetCloseEnd would.
-template <class Search>
+// The two seams, in the reference's order (src/pindel.cpp:1816-1888):
+//   search(chrom, chr_id, reads, index_in_all)   on ALL reads of the window: must fill UP_Close (empty when there is no
+//                                                close end) and leave UnmatchedSeq as GetCloseEnd would
+//                                                (ReadBuffer::flush, src/read_buffer.cpp:36-101); may fill UP_Far too
+//   far_search(chrom, chr_id, kept)              on the reads that kept a close end (state.Reads_SR): fills UP_Far
+//                                                (SearchFarEnds, src/pindel.cpp:1115-1138, called at :1888)
+struct NoFarSearch {
+    int operator()(const Chromosome &, int, std::vector<SplitRead> &) const { return 0; }
+};
+
+template <class Search, class FarSearch>
 int run_pipeline(const std::vector<Chromosome> &genome, const std::vector<unsigned> &fai,
                  const std::vector<SplitRead> &all, const Settings &S, const std::string &prefix,
-                 Search search, std::string &err)
+                 Search search, FarSearch far_search, std::string &err)
 {
     Caller caller(S, &genome, prefix, true);
     const unsigned WINDOW = (unsigned)(S.window_mbp * 1000000);
+    if (WINDOW == 0) {
+        err = "window size (-w) must be at least 0.000001 Mbp";
+        return -1;
+    }
     // PGH_TIMING=1: wall-clock seconds per stage of this loop on stderr (diagnostics)
     const bool timing = getenv("PGH_TIMING") != nullptr;
     double t_copy = 0, t_search = 0, t_keep = 0, t_call = 0, t_free = 0;
@@ -122,6 +134,11 @@ int run_pipeline(const std::vector<Chromosome> &genome, const std::vector<unsign
             for (SplitRead &r : reads)
                 if (!r.UP_Close.empty()) kept.push_back(std::move(r));      // `reads` is not used after this loop
             t_keep += now() - t0; t0 = now();
+            if (!kept.empty() && (rc = far_search(chrom, (int)c, kept))) {
+                err = "far-end search step failed";
+                return rc;
+            }
+            t_search += now() - t0; t0 = now();
             if (!kept.empty()) caller.process_window(chrom, kept, ws, we, bed_start, bed_end);
             t_call += now() - t0; t0 = now();
             release_reads(kept);
@@ -148,16 +165,20 @@ struct BamSource {
 // bd != null && search_rp: before the reads of a window are taken, its discordant read pairs become BreakDancer-like
 // events (get_RP_Reads_Discovery + BDData::UpdateBD, src/pindel.cpp:1838-1848; -R, default on) next to the events of
 // a -b file; the search step then looks their windows up per read (loadRegion / getCorrespondingSearchWindowCluster).
-template <class Search>
+template <class Search, class FarSearch>
 int run_bam_pipeline(const std::vector<Chromosome> &genome, const std::vector<unsigned> &fai,
                      const std::vector<BamSource> &bams, const BamIngestSettings &ingest, const Settings &S,
-                     const std::string &prefix, Search search, std::string &err, size_t *n_reads_total = nullptr,
+                     const std::string &prefix, Search search, FarSearch far_search, std::string &err, size_t *n_reads_total = nullptr,
                      BDHints *bd = nullptr, bool search_rp = false, size_t *n_rp_events = nullptr)
 {
     Caller caller(S, &genome, prefix, true);
     std::ofstream rp_out;
     if (bd && search_rp) rp_out.open((prefix + "_RP").c_str(), std::ios::trunc);
     const unsigned WINDOW = (unsigned)(S.window_mbp * 1000000);
+    if (WINDOW == 0) {
+        err = "window size (-w) must be at least 0.000001 Mbp";
+        return -1;
+    }
     std::vector<BamFile> files(bams.size());
     for (size_t k = 0; k < bams.size(); k++)
         if (!files[k].open(bams[k].path, err)) return -1;
@@ -225,6 +246,10 @@ int run_bam_pipeline(const std::vector<Chromosome> &genome, const std::vector<un
             }
             for (SplitRead &r : reads)
                 if (!r.UP_Close.empty()) kept.push_back(std::move(r));
+            if (!kept.empty() && (rc = far_search(chrom, (int)c, kept))) {
+                err = "far-end search step failed";
+                return rc;
+            }
             {   // UpdateRefReadCoverage, after the close ends (sample names) and before the classifiers
                 std::vector<Caller::RefReadSpan> spans(in.ref_reads.size());
                 for (size_t i = 0; i < spans.size(); i++) {

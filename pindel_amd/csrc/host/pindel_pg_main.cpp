@@ -11,6 +11,7 @@
 #include <cstring>
 #include <fstream>
 #include <algorithm>
+#include <functional>
 #include <iterator>
 #include <string>
 #include <thread>
@@ -38,6 +39,7 @@ int main(int argc, char **argv)
     int ref_read_nm = 2;                    // -n / --NM (isRefRead)
     bool search_rp = true;                 // -R: discordant read pairs as window hints (BAM input only; default true)
     bool use_bd = false;
+    size_t flush_reads = 0;                // --flush-reads: reads per close-end call (0 = a whole bin)
     pg_params prm;
     pg_default_params(&prm);
     Settings S;
@@ -54,7 +56,7 @@ int main(int argc, char **argv)
         { "-M", "--minimum_support_for_event", 'i' }, { "-B", "--balance_cutoff", 'i' },
         { "-d", "--min_num_matched_bases", 'i' }, { "-v", "--min_inversion_size", 'i' },
         { "-w", "--window_size", 'f' }, { "-T", "--number_of_threads", 'i' }, { "-b", "--breakdancer", 's' },
-        { "-G", "--gpus", 's' }, { "", "--bd-hints", 's' }, { "-c", "--chromosome", 's' },
+        { "-G", "--gpus", 's' }, { "", "--bd-hints", 's' }, { "", "--flush-reads", 'i' }, { "-c", "--chromosome", 's' },
         { "-n", "--NM", 'i' }, { "", "--min_NT_size", 'i' }, { "-A", "--anchor_quality", 'i' }, { "-L", "--logfilename", 's' },
         { "-r", "--report_inversions", 'u' }, { "-t", "--report_duplications", 'u' },
         { "-l", "--report_long_insertions", 'u' }, { "-k", "--report_breakpoints", 'u' },
@@ -123,7 +125,14 @@ int main(int argc, char **argv)
         else if (key == "-B") S.BalanceCutoff = (unsigned)iv;
         else if (key == "-d") S.Min_Num_Matched_Bases = (int)iv;
         else if (key == "-v") S.MIN_IndelSize_Inversion = (int)iv;
-        else if (key == "-w") S.window_mbp = fv;
+        else if (key == "-w") {
+            if ((unsigned)(fv * 1000000) == 0) {
+                fprintf(stderr, "pindel_pg: -w must be at least 0.000001 (Mbp)\n");
+                return 2;
+            }
+            S.window_mbp = fv;
+        }
+        else if (key == "--flush-reads") flush_reads = iv > 0 ? (size_t)iv : 0;
         else if (key == "-G") gpu_list = v;
         else if (key == "-b") bd_path = v;                                     // --breakdancer
         else if (key == "--bd-hints") use_bd = std::string(v) == "on";         // see below: off = what 0.2.5b9 does
@@ -261,74 +270,95 @@ int main(int argc, char **argv)
         printf("pindel_pg: BD events: %zu%s\n", bd.n_events(), use_bd ? "" : " (not used for Pindel-text input; --bd-hints on to use them)");
     }
     size_t n_close = 0, n_far = 0;
-    // close end + far end of a contiguous range of a bin's reads on one device (ReadBuffer::flush, then SearchFarEnds)
-    auto search_shard = [&](pg_ctx *c, std::vector<SplitRead> &reads) {
-        pg_result *res = nullptr;
-        int r = pg_adapter::CloseEndBatch(c, reads, chr_of, make_point, &res);
-        if (r) return r;
-        std::vector<uint64_t> hoff;
-        std::vector<pg_window> hwin;
-        pg_windows hints = { nullptr, nullptr };
-        if (use_bd && bd.n_events() && !reads.empty()) {
-            hoff.push_back(0);
-            for (const SplitRead &x : reads) {
-                if (!x.UP_Close.empty())
-                    for (const BDWindow &w : bd.cluster(x.UP_Close.back().AbsLoc)) {
-                        pg_window pw = { w.chr_id, (int32_t)w.start, (int32_t)w.end };
-                        hwin.push_back(pw);
-                    }
-                hoff.push_back(hwin.size());
-            }
-            hints.offset = hoff.data();
-            hints.windows = hwin.empty() ? nullptr : hwin.data();
+    // fn(ctx, part) on contiguous shards of `reads`, one host thread and one ctx per device; the parts are moved out
+    // and back, so the order is kept (reads are independent: identical results for any device count)
+    auto on_devices = [&](std::vector<SplitRead> &reads, const std::function<int(pg_ctx *, std::vector<SplitRead> &)> &fn) {
+        const size_t nd = ctxs.size(), n = reads.size();
+        if (nd == 1 || n < 2 * nd) return fn(ctxs[0], reads);
+        std::vector<std::vector<SplitRead>> parts(nd);
+        std::vector<int> rcs(nd, 0);
+        for (size_t d = 0; d < nd; d++) {
+            const size_t lo = n * d / nd, hi = n * (d + 1) / nd;
+            parts[d].assign(std::make_move_iterator(reads.begin() + lo), std::make_move_iterator(reads.begin() + hi));
         }
-        r = pg_adapter::SearchFarEnds(c, reads, chr_of, make_point, res, hints.offset ? &hints : nullptr);
-        pg_result_free(res);
+        std::vector<std::thread> th;
+        for (size_t d = 0; d < nd; d++) th.emplace_back([&, d]() { rcs[d] = fn(ctxs[d], parts[d]); });
+        for (std::thread &x : th) x.join();
+        int r = 0;
+        for (size_t d = 0; d < nd; d++) {
+            if (rcs[d]) r = rcs[d];
+            std::move(parts[d].begin(), parts[d].end(), reads.begin() + n * d / nd);
+        }
         return r;
     };
-    auto search = [&](const Chromosome &, int, std::vector<SplitRead> &reads, const std::vector<uint32_t> &) {
+    // Seam 1 (ReadBuffer::flush, src/read_buffer.cpp:36-101): the close end of ALL reads of the bin, `flush_reads` at a
+    // time like the reference's 50 000-read buffer (src/reader.cpp:55; 0 = the whole bin in one call -- the results do
+    // not depend on it).  The pipeline then keeps the reads with a close end, as flush() does (:55-64).
+    auto close_search = [&](const Chromosome &, int, std::vector<SplitRead> &reads, const std::vector<uint32_t> &) {
         const double t0 = now_s();
-        if (use_bd && bd.n_events() && !reads.empty()) {
+        int r = on_devices(reads, [&](pg_ctx *c, std::vector<SplitRead> &part) {
+            const size_t step = flush_reads ? flush_reads : std::max<size_t>(part.size(), 1);
+            if (step >= part.size()) {
+                pg_result *res = nullptr;
+                const int rr = pg_adapter::CloseEndBatch(c, part, chr_of, make_point, &res);
+                pg_result_free(res);
+                return rr;
+            }
+            for (size_t lo = 0; lo < part.size(); lo += step) {
+                const size_t hi = std::min(part.size(), lo + step);
+                std::vector<SplitRead> buf(std::make_move_iterator(part.begin() + lo), std::make_move_iterator(part.begin() + hi));
+                pg_result *res = nullptr;
+                const int rr = pg_adapter::CloseEndBatch(c, buf, chr_of, make_point, &res);
+                pg_result_free(res);
+                std::move(buf.begin(), buf.end(), part.begin() + lo);
+                if (rr) return rr;
+            }
+            return 0;
+        });
+        t_search += now_s() - t0;
+        return r;
+    };
+    // Seam 2 (SearchFarEnds, src/pindel.cpp:1115-1138, called at :1888 on state.Reads_SR): the far end of the reads that
+    // kept a close end -- the filtered union of the flushes -- through pg_far_end_batch_from_close.
+    auto far_search = [&](const Chromosome &, int, std::vector<SplitRead> &kept) {
+        const double t0 = now_s();
+        if (use_bd && bd.n_events() && !kept.empty()) {
             // the bin of these reads, as main() hands it to g_bdData.loadRegion (pindel.cpp:1828, 1853)
-            unsigned lo = reads[0].MatchedRelPos;
-            for (const SplitRead &x : reads) lo = std::min(lo, x.MatchedRelPos);
+            unsigned lo = kept[0].MatchedRelPos;
+            for (const SplitRead &x : kept) lo = std::min(lo, x.MatchedRelPos);
             const unsigned W = (unsigned)(S.window_mbp * 1000000);
             const unsigned ws = lo / W * W, we = ws + W;
             std::string berr;
-            if (!bd.load_region(chr_names, reads[0].chr_id, ws + prm.spacer, we + prm.spacer, berr)) {
+            if (!bd.load_region(chr_names, kept[0].chr_id, ws + prm.spacer, we + prm.spacer, berr)) {
                 fprintf(stderr, "pindel_pg: %s\n", berr.c_str());
                 return (int)PG_E_INVALID;
             }
         }
-        int r = 0;
-        const size_t nd = ctxs.size(), n = reads.size();
-        if (nd == 1 || n < 2 * nd) r = search_shard(ctxs[0], reads);
-        else {
-            // contiguous shards, one host thread and one ctx per device; moved out and back: order is kept
-            std::vector<std::vector<SplitRead>> parts(nd);
-            std::vector<int> rcs(nd, 0);
-            for (size_t d = 0; d < nd; d++) {
-                const size_t lo = n * d / nd, hi = n * (d + 1) / nd;
-                parts[d].assign(std::make_move_iterator(reads.begin() + lo), std::make_move_iterator(reads.begin() + hi));
+        int r = on_devices(kept, [&](pg_ctx *c, std::vector<SplitRead> &part) {
+            std::vector<uint64_t> hoff;
+            std::vector<pg_window> hwin;
+            pg_windows hints = { nullptr, nullptr };
+            if (use_bd && bd.n_events() && !part.empty()) {
+                hoff.push_back(0);
+                for (const SplitRead &x : part) {
+                    for (const BDWindow &w : bd.cluster(x.UP_Close.back().AbsLoc)) {
+                        pg_window pw = { w.chr_id, (int32_t)w.start, (int32_t)w.end };
+                        hwin.push_back(pw);
+                    }
+                    hoff.push_back(hwin.size());
+                }
+                hints.offset = hoff.data();
+                hints.windows = hwin.empty() ? nullptr : hwin.data();
             }
-            std::vector<std::thread> th;
-            for (size_t d = 0; d < nd; d++) th.emplace_back([&, d]() { rcs[d] = search_shard(ctxs[d], parts[d]); });
-            for (std::thread &x : th) x.join();
-            for (size_t d = 0; d < nd; d++) {
-                if (rcs[d]) r = rcs[d];
-                std::move(parts[d].begin(), parts[d].end(), reads.begin() + n * d / nd);
-            }
-        }
-        size_t bin_close = 0, bin_far = 0;
-        for (const SplitRead &x : reads) {
-            bin_close += !x.UP_Close.empty();
-            bin_far += !x.UP_Far.empty();
-        }
-        n_close += bin_close;
+            return pg_adapter::SearchFarEnds(c, part, chr_of, make_point, hints.offset ? &hints : nullptr);
+        });
+        size_t bin_far = 0;
+        for (const SplitRead &x : kept) bin_far += !x.UP_Far.empty();
+        n_close += kept.size();
         n_far += bin_far;
         // ReportCloseAndFarEndCounts (src/pindel.cpp:1094-1113), over the reads that kept a close end
-        printf("Total: %zu;\tClose_end_found %zu;\tFar_end_found %zu;\tUsed\t0.\n\nFor LI and BP: %zu\n\n", bin_close, bin_close,
-               bin_far, bin_close - bin_far);
+        printf("Total: %zu;\tClose_end_found %zu;\tFar_end_found %zu;\tUsed\t0.\n\nFor LI and BP: %zu\n\n", kept.size(), kept.size(),
+               bin_far, kept.size() - bin_far);
         t_search += now_s() - t0;
         return r;
     };
@@ -342,10 +372,10 @@ int main(int argc, char **argv)
         // BAM input: with -R (default) the window hints are live -- the events of a -b file plus the read-pair events of
         // every window; without -R the reference never hands any event to the search (UpdateBD is not called)
         use_bd = search_rp;
-        rc = run_bam_pipeline(genome, fai, bams, ing, S, prefix, search, err, &n_bam_reads, &bd, search_rp, &n_rp_events);
+        rc = run_bam_pipeline(genome, fai, bams, ing, S, prefix, close_search, far_search, err, &n_bam_reads, &bd, search_rp, &n_rp_events);
         if (search_rp) printf("pindel_pg: read-pair events added as window hints: %zu\n", n_rp_events);
     } else
-        rc = run_pipeline(genome, fai, all, S, prefix, search, err);
+        rc = run_pipeline(genome, fai, all, S, prefix, close_search, far_search, err);
     if (rc) fprintf(stderr, "pindel_pg: %s (%s)\n", err.c_str(), pg_last_error(ctx));
     else {
         printf("pindel_pg: %zu reads, close end %zu, far end %zu\n", bams.empty() ? all.size() : n_bam_reads, n_close, n_far);

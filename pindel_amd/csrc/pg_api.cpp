@@ -1344,36 +1344,33 @@ static int attach_windows(pg_ctx *ctx, pg_device_batch *b, const pg_windows *bd_
     return pack_reads(ctx, b, 0, b->n);
 }
 
-int pg_far_end_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_result *close, const pg_windows *bd_hints)
+// Far end of `reads` given each read's close-end summary (host arrays; rc_flag may be null = the sequences are
+// already in the orientation GetCloseEnd left them in).  far_off / far_runs of `dst` are replaced.
+static int far_end_impl(pg_ctx *ctx, const pg_read_batch *reads, const uint8_t *rc_flag, const uint32_t *close_last,
+                        const uint16_t *close_max, const pg_windows *bd_hints, pg_result *dst)
 {
-    use_device(ctx);
-    if (!ctx || !reads || !close) return PG_E_INVALID;
-    if (close->n != reads->n_reads) return fail(ctx, PG_E_INVALID, "close result does not belong to these reads");
     pg_device_batch *b = nullptr;
     std::vector<uint64_t> off0;
     int rc = alloc_batch(ctx, reads, true, off0, &b, true);
     if (rc) return rc;
-    if ((rc = pack_reads(ctx, b, 0, b->n))) {
-        free_batch_buffers(b);
-        delete b;
-        return rc;
-    }
-    const size_t n = b->n;
     auto bail = [&](int code) {
         free_batch_buffers(b);
         delete b;
         return code;
     };
+    if ((rc = pack_reads(ctx, b, 0, b->n))) return bail(rc);
+    const size_t n = b->n;
     if (n) {
-        if (close->rc_flag.size() != n || close->close_last.size() != n || close->close_max.size() != n)
-            return bail(fail(ctx, PG_E_INVALID, "close result carries no close-end summary"));
-        if (hipMemcpy(b->rc_flag, close->rc_flag.data(), n, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(b->close_last, close->close_last.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(b->close_max, close->close_max.data(), n * 2, hipMemcpyHostToDevice) != hipSuccess)
+        // (the output block of the batch, rc_flag included, was zeroed by alloc_batch)
+        if ((rc_flag && hipMemcpyAsync(b->rc_flag, rc_flag, n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) ||
+            hipMemcpyAsync(b->close_last, close_last, n * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(b->close_max, close_max, n * 2, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
             return bail(fail(ctx, PG_E_DEVICE, "upload of close-end summary failed"));
         const PgSoaOut a = soa_out(b);
         if (pg_pack_close_summary(&a, b->out_rec, b->n, ctx->stream) != 0)
             return bail(fail(ctx, PG_E_DEVICE, "close-end summary pack kernel failed"));
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess)       // the host arrays may be pageable temporaries
+            return bail(fail(ctx, PG_E_DEVICE, "upload of close-end summary failed"));
     }
     if ((rc = attach_windows(ctx, b, bd_hints))) return bail(rc);
     rc = run_search(ctx, b, PG_MODE_FAR);
@@ -1381,9 +1378,51 @@ int pg_far_end_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_result *close, 
     pg_result tmp;
     rc = download(ctx, b, &tmp);
     if (rc) return bail(rc);
-    close->far_off.swap(tmp.far_off);
-    close->far_runs.swap(tmp.far_runs);
+    dst->far_off.swap(tmp.far_off);
+    dst->far_runs.swap(tmp.far_runs);
     return bail(PG_OK);
+}
+
+int pg_far_end_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_result *close, const pg_windows *bd_hints)
+{
+    use_device(ctx);
+    if (!ctx || !reads || !close) return PG_E_INVALID;
+    if (close->n != reads->n_reads) return fail(ctx, PG_E_INVALID, "close result does not belong to these reads");
+    const size_t n = reads->n_reads;
+    if (n && (close->rc_flag.size() != n || close->close_last.size() != n || close->close_max.size() != n))
+        return fail(ctx, PG_E_INVALID, "close result carries no close-end summary");
+    return far_end_impl(ctx, reads, close->rc_flag.data(), close->close_last.data(), close->close_max.data(), bd_hints, close);
+}
+
+int pg_far_end_batch_from_close(pg_ctx *ctx, const pg_read_batch *reads, const uint32_t *close_last,
+                                const int16_t *close_max, const pg_windows *bd_hints, pg_result **out)
+{
+    use_device(ctx);
+    if (!ctx || !reads || !out) return PG_E_INVALID;
+    *out = nullptr;
+    const size_t n = reads->n_reads;
+    if (n && (!close_last || !close_max)) return fail(ctx, PG_E_INVALID, "null close-end summary");
+    // MaxLenCloseEnd() of a read without UP_Close is 0: such a read is not searched (farend_searcher.cpp:60-66)
+    std::vector<uint16_t> cmax(n);
+    for (size_t i = 0; i < n; i++) cmax[i] = close_max[i] > 0 ? (uint16_t)close_max[i] : (uint16_t)0;
+    pg_result *r = new pg_result();
+    r->n = (uint32_t)n;
+    if (!r->close_off.assign(n + 1, 0) || !r->rc_flag.assign(n, 0) || !r->close_last.resize(n) || !r->close_max.resize(n)) {
+        delete r;
+        return fail(ctx, PG_E_NOMEM, "pinned host memory for the result");
+    }
+    r->close_runs.resize(0);
+    for (size_t i = 0; i < n; i++) {
+        r->close_last[i] = close_last[i];
+        r->close_max[i] = cmax[i];
+    }
+    int rc = far_end_impl(ctx, reads, nullptr, close_last, cmax.data(), bd_hints, r);
+    if (rc) {
+        delete r;
+        return rc;
+    }
+    *out = r;
+    return PG_OK;
 }
 
 int pg_result_view_get(const pg_result *r, pg_result_view *v)

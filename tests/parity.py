@@ -19,10 +19,26 @@ def assert_same_points(gpu_pts, orc_pts, what):
             raise AssertionError(f"{what}: field {f} differs at point {k}: gpu {gpu_pts[k]} oracle {orc_pts[k]}")
 
 
+def points_per_read(off, runs):
+    """UniquePoints each read owns, from its CSR offsets (in runs) and the run lengths."""
+    pts = runs["len_last"].astype(np.int64) - runs["len_first"].astype(np.int64) + 1
+    assert (pts > 0).all(), "a run with len_last < len_first"
+    cum = np.concatenate([[0], np.cumsum(pts)])
+    off = np.asarray(off, dtype=np.int64)
+    assert off[0] == 0 and (np.diff(off) >= 0).all() and off[-1] == len(runs), "CSR offsets are not a partition of the runs"
+    return cum[off[1:]] - cum[off[:-1]]
+
+
 def compare_result(gpu: "binding.Result", orc: dict, n: int, check_far=True):
     """Bit-exact comparison of UP_Close, UP_Far and the rc flag for every read."""
     assert gpu.n == n
     np.testing.assert_array_equal(gpu.rc_flag, orc["rc_flag"], err_msg="rc_flag")
+    # read boundaries first: a list attributed to the neighbouring read must not pass the concatenated comparison below
+    np.testing.assert_array_equal(points_per_read(gpu.close_off, gpu.close_runs), orc["close_cnt"][:n],
+                                  err_msg="UP_Close points per read")
+    if check_far:
+        np.testing.assert_array_equal(points_per_read(gpu.far_off, gpu.far_runs), orc["far_cnt"][:n],
+                                      err_msg="UP_Far points per read")
     # whole-batch comparison on the expanded point arrays (fast path), then per read on failure
     g_close = binding.expand_runs(gpu.close_runs)
     o_close = np.concatenate([oracle_points(orc, i, "close") for i in range(n)]) if n else g_close

@@ -119,6 +119,18 @@ def test_gpu_path_reproduces_gold_reports(tmp_path, engine_factory):
     prefix = str(tmp_path / "gpu")
     hostlib.call_from_points(fa, reads_txt, prefix, st, co, cp, fo, fp, res.rc_flag)
     gu.assert_reports_match_gold(prefix)
+    # the same through pg_search_batch_multi (three contexts, contiguous shards, one host thread each)
+    others = [engine_factory(), engine_factory()]
+    for e in others:
+        e.load_fasta(fa)
+    multi = binding.Engine.search_batch_multi([eng] + others, batch)
+    assert np.array_equal(multi.close_off, res.close_off) and np.array_equal(multi.far_off, res.far_off)
+    assert np.array_equal(multi.rc_flag, res.rc_flag)
+    assert multi.close_runs.tobytes() == res.close_runs.tobytes() and multi.far_runs.tobytes() == res.far_runs.tobytes()
+    prefix = str(tmp_path / "gpu_multi")
+    hostlib.call_from_points(fa, reads_txt, prefix, st, point_off(multi.close_off, multi.close_runs), binding.expand_runs(multi.close_runs),
+                             point_off(multi.far_off, multi.far_runs), binding.expand_runs(multi.far_runs), multi.rc_flag)
+    gu.assert_reports_match_gold(prefix)
 
 
 @pytest.mark.gpu
@@ -137,6 +149,14 @@ def test_command_line_reproduces_gold_reports(tmp_path):
     assert "Total: 14862;\tClose_end_found 14862;\tFar_end_found 10968;" in out.stdout
     assert "Far ends already mapped 10968" in out.stdout and "Checksum of far ends: " in out.stdout
     gu.assert_reports_match_gold(prefix)
+    # the close end in ReadBuffer-sized flushes (here 4 000 reads: four flushes), the far end on their filtered union
+    prefix = str(tmp_path / "cli_flush")
+    out = subprocess.run([exe, "-f", fa, "-p", reads_txt, "-o", prefix, "--flush-reads", "4000"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "close end 14862, far end 10968" in out.stdout
+    gu.assert_reports_match_gold(prefix)
+    bad = subprocess.run([exe, "-f", fa, "-p", reads_txt, "-o", prefix, "-w", "0"], capture_output=True, text=True)
+    assert bad.returncode == 2 and "-w must be" in bad.stderr
 
 
 @pytest.mark.gpu

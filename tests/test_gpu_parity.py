@@ -435,3 +435,65 @@ def test_rejections_are_loud(engine_factory, small_ref, tmp_path):
     # the engine still works after all of that
     eng.load_reference(small_ref)
     compare_result(eng.search_batch(batch), run_oracle({}, small_ref, batch), batch.n)
+
+
+def _rc_bytes(a):
+    lut = np.zeros(256, dtype=np.uint8)              # Convert2RC4N: everything but ACGTN -> 0
+    for x, y in zip(b"ACGTN", b"TGCAN"):
+        lut[x] = y
+    return lut[a[::-1]]
+
+
+def test_far_end_seam_on_the_filtered_union_of_flushes(engine_factory, small_ref):
+    """Seam 2 where the reference calls it (src/pindel.cpp:1888): the close end runs in 50 000-read flushes
+    (ReadBuffer, src/reader.cpp:55), every flush keeps only the reads with a close end, already reverse-complemented
+    where GetCloseEnd did so (src/read_buffer.cpp:55-64), the kept reads of all flushes are concatenated, and
+    pg_far_end_batch_from_close searches that vector from nothing but the reads and UP_Close.back()."""
+    from pindel_amd import binding, hostio
+    eng = engine_factory()
+    eng.load_reference(small_ref)
+    n, flush = 120_000, 50_000
+    batch = synth.make_reads(small_ref[0][1], n, seed=77)
+    orc = run_oracle({}, small_ref, batch)
+    kept_idx, seqs, close_last, close_max = [], [], [], []
+    off = batch.seq_off.astype(np.int64)
+    for lo in range(0, n, flush):
+        hi = min(n, lo + flush)
+        res = eng.close_end_batch(batch.slice(lo, hi))
+        has = np.diff(res.close_off.astype(np.int64)) > 0
+        pts = binding.expand_runs(res.close_runs)
+        last_run = res.close_runs[res.close_off[1:][has].astype(np.int64) - 1]
+        # UP_Close.back(): the last point of the last run
+        d = last_run["len_last"].astype(np.int64) - last_run["len_first"]
+        back = (last_run["flags"] & 1) != 0
+        cl = np.where(back, last_run["abs_loc_first"].astype(np.int64) - d, last_run["abs_loc_first"].astype(np.int64) + d)
+        assert len(pts) == int((orc["close_cnt"][lo:hi]).sum())
+        for k, i in enumerate(np.nonzero(has)[0]):
+            g = lo + int(i)
+            s = batch.seq[off[g]:off[g + 1]]
+            seqs.append((_rc_bytes(s) if res.rc_flag[i] else s).tobytes())
+            kept_idx.append(g)
+        close_last.append(cl)
+        close_max.append(last_run["len_last"].astype(np.int16))
+    kept_idx = np.array(kept_idx)
+    close_last = np.concatenate(close_last).astype(np.uint32)
+    close_max = np.concatenate(close_max)
+    np.testing.assert_array_equal(kept_idx, np.nonzero(orc["close_cnt"][:n] > 0)[0])
+    assert 60_000 < len(kept_idx) < n                     # the vector seam 2 sees is NOT the vector seam 1 saw
+    kept = hostio.batch_from_lists(seqs, [bytes([c]) for c in batch.anchor_strand[kept_idx]], batch.anchor_pos[kept_idx],
+                                   batch.insert_size[kept_idx], batch.chr_id[kept_idx])
+    far = eng.far_end_batch_from_close(kept, close_last, close_max)
+    assert far.n == len(kept_idx) and far.close_off[-1] == 0 and not far.rc_flag.any()
+    from tests.parity import oracle_points, points_per_read
+    np.testing.assert_array_equal(points_per_read(far.far_off, far.far_runs), orc["far_cnt"][kept_idx])
+    g_far = binding.expand_runs(far.far_runs)
+    o_far = np.concatenate([oracle_points(orc, int(i), "far") for i in kept_idx])
+    assert g_far.tobytes() == o_far.tobytes()
+    assert (orc["far_cnt"][kept_idx] > 0).sum() > 40_000
+    # reads without a close end (close_max <= 0) are passed through unsearched
+    cm0 = close_max.copy()
+    cm0[::2] = 0
+    half = eng.far_end_batch_from_close(kept, close_last, cm0)
+    cnt = points_per_read(half.far_off, half.far_runs)
+    assert not cnt[::2].any()
+    np.testing.assert_array_equal(cnt[1::2], orc["far_cnt"][kept_idx][1::2])
