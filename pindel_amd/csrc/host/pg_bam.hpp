@@ -13,10 +13,16 @@
 // reporters, in the order the reference's single-threaded run emits the records (its OpenMP flush pushes the
 // reads of a 50 000-read buffer in a race: the order here is the deterministic T = 1 order).
 //
-// PARITY STATUS: the snapshot has no BAM fixtures and no htslib, so the rules are restated from the source and
-// checked against an independent restatement plus the round trip "gold reads -> BAM (tests/bam_writer.py) ->
-// this reader == the Pindel-text route, identical gold reports" (tests/test_bam_ingest.py).  Reference-coverage
-// reads (build_record_RefRead, the two per-sample integers of the report headers) are not produced.
+// Reference-supporting reads (isRefRead / build_record_RefRead, src/reader.cpp:620-656, 903-923) are collected by the
+// same pass and become the per-sample coverage integers of the report headers (Caller::update_ref_coverage).
+//
+// PARITY STATUS: pinned on the one BAM the reference ships, demo/simulated_MEI/aln.sorted.bam (bwa + samtools,
+// 24 000 records, with its .bai) and the 20 Pindel-text records `input` its authors derived from it: decoder == an
+// independent decoding, index == scan, all 20 records reproduced field for field, every further record explained by a
+// named rule of fetch_func_SR (tests/test_mei_bam.py).  Beyond that file the rules are checked against an independent
+// restatement on a deliberately messy synthetic BAM and by the round trip "gold reads -> BAM (tests/bam_writer.py) ->
+// this reader == the Pindel-text route, identical gold reports" (tests/test_bam_ingest.py).  The reference binary's
+// BAM path itself cannot be built here (htslib).
 #ifndef PG_BAM_HPP
 #define PG_BAM_HPP
 

@@ -228,6 +228,51 @@ int64_t pgh_rp_events(const char *bam_path, const char *chr_name, int64_t win_st
     return (int64_t)ev.size();
 }
 
+// The window hints of one bin exactly as `pindel_pg -i ... [-b file]` with -R hands them to the far end
+// (run_bam_pipeline): events of the -b file (bd_path may be null / empty) + the read-pair events of this window of
+// this BAM (UpdateBD; [win_start, win_end) = the window as clipped to the chromosome), loadRegion for the bin
+// [win_start, region_end) (the unclipped bin, as main() hands it over), then the cluster of every query position
+// (= last close-end AbsLoc).
+// out_off: n_q + 1 entries, out_win: 3 ints (chr id, start, end) per window.  Returns the number of read-pair
+// events, -1 on a file error, -2 unknown chromosome, -3 out_win too small.
+int64_t pgh_window_hints(const char *bd_path, const char *bam_path, int32_t n_chr, const char *const *names, int32_t chr_id,
+                         int64_t win_start, int64_t win_end, int64_t region_end, int32_t insert_size, const char *tag,
+                         uint32_t min_anchor_quality, uint32_t spacer, uint32_t n_q, const uint32_t *q, uint64_t *out_off, int32_t *out_win, uint64_t cap)
+{
+    pgh::BDHints h;
+    std::string note;
+    if (bd_path && bd_path[0] && h.load_file(bd_path, spacer, note) < 0) {
+        g_err = note;
+        return -1;
+    }
+    std::vector<std::string> nm(names, names + n_chr);
+    pgh::BamFile bam;
+    if (!bam.open(bam_path, g_err)) return -1;
+    std::vector<pgh::RpRead> rp;
+    if (!pgh::rp_discover(bam, nm[chr_id], win_start, win_end, insert_size, tag ? tag : "", min_anchor_quality, rp)) return -1;
+    const std::vector<pgh::RpEvent> ev = pgh::rp_events(rp, spacer, nullptr);
+    std::vector<std::pair<pgh::BDHints::RpSide, pgh::BDHints::RpSide>> sides;
+    for (const pgh::RpEvent &e : ev) {
+        pgh::BDHints::RpSide a = { e.chr1, e.pos1, e.pos1b }, b = { e.chr2, e.pos2, e.pos2b };
+        sides.push_back(std::make_pair(a, b));
+    }
+    h.update_with_rp(sides);
+    if (!h.load_region(nm, chr_id, (unsigned)win_start + spacer, (unsigned)region_end + spacer, g_err)) return -2;
+    uint64_t k = 0;
+    out_off[0] = 0;
+    for (uint32_t i = 0; i < n_q; i++) {
+        for (const pgh::BDWindow &w : h.cluster(q[i])) {
+            if (k >= cap) return -3;
+            out_win[3 * k] = w.chr_id;
+            out_win[3 * k + 1] = (int32_t)w.start;
+            out_win[3 * k + 2] = (int32_t)w.end;
+            k++;
+        }
+        out_off[i + 1] = k;
+    }
+    return (int64_t)ev.size();
+}
+
 // Test hook (tests/test_cpu_suite.py): sorts indices 0..n-1 by keys[] with the reference's O(n^2)
 // exchange sort and with its fast equivalent; the two outputs must be identical.
 void pgh_test_exchange_sort(const int32_t *keys, uint32_t n, uint32_t *out_reference, uint32_t *out_fast)

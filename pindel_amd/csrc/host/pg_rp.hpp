@@ -12,8 +12,9 @@
 // reads that other iterations read; UpdateBD pushes events in completion order): this is the sequential order,
 // and the final event list is sorted anyway.  Interchromosomal pairs (`-I`, default off) are not handled.
 //
-// PARITY STATUS: unpinned -- the snapshot has no BAM fixtures and the reference's BAM path cannot be built here
-// (htslib); checked against an independent restatement on synthetic pairs (tests/test_bam_ingest.py).
+// PARITY STATUS: unpinned -- the reference's BAM path cannot be built here (htslib) and the one BAM it ships
+// (demo/simulated_MEI) has no same-chromosome discordant cluster: checked against an independent restatement on
+// synthetic pairs (tests/test_bam_ingest.py) and on that BAM (tests/test_mei_bam.py: both find no event).
 #ifndef PG_RP_HPP
 #define PG_RP_HPP
 

@@ -1,7 +1,7 @@
 """BAM ingest without htslib (pindel_amd/csrc/host/pg_bam.hpp).
 
-The snapshot holds no BAM files (and no htslib / samtools), so the parity of the read-selection rules against the
-reference binary is UNPINNED; what is checked here:
+The one BAM the reference ships (demo/simulated_MEI) pins the decoder and the selection rules in tests/test_mei_bam.py.
+There is no htslib / samtools in the image, so further BAMs come from the test-side writer; what is checked here:
   * the reference's gold reads (tests/golden/sim1chrVs2, Pindel text) written as read pairs into a BAM by the
     test-side writer (tests/bam_writer.py) come back from the BAM route as exactly the batch the text route
     loads, and (GPU) `pindel_pg -i` reproduces the reference's gold _D/_SI/_TD/_INV reports from that BAM;
@@ -294,7 +294,7 @@ def test_selection_rules_match_the_restatement_and_index_equals_scan(tmp_path, m
 
 @pytest.mark.parametrize("name,n_ref", [("sim1chrVs2.bam.bai", 1), ("simulated_sample_1.bam.bai", 4)])
 def test_reference_bai_files_parse(name, n_ref):
-    """The index files the reference ships (written by samtools; the BAMs themselves are not in the snapshot): the BAI
+    """The index files the reference ships (written by samtools; THESE BAMs are not in the snapshot -- the demo/simulated_MEI one is, see tests/test_mei_bam.py): the BAI
     reader must take the metadata pseudo-bin and the trailing n_no_coor in its stride."""
     import struct
     path = os.path.join(os.path.dirname(gu.GOLD), "bai", name)
