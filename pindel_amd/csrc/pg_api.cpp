@@ -1100,6 +1100,19 @@ int pg_debug_read_alg(pg_ctx *ctx, pg_device_batch *b, uint32_t *out, uint32_t n
     return PG_OK;
 }
 
+// Diagnostics (not in the public header): the `reserved` word of every output record (candidates per read; in a
+// -DPG_DIAG build the packed per-read counters).
+int pg_debug_read_reserved(pg_ctx *ctx, pg_device_batch *b, uint32_t *out, uint32_t n)
+{
+    use_device(ctx);
+    if (!ctx || !b || !out || n > b->n) return PG_E_INVALID;
+    std::vector<PgOutRec> recs(n);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (n) HIP_TRY(ctx, hipMemcpy(recs.data(), b->out_rec, (size_t)n * sizeof(PgOutRec), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; i++) out[i] = recs[i].reserved;
+    return PG_OK;
+}
+
 int pg_last_search_stats(const pg_ctx *ctx, double *kernel_ms, uint64_t *n_runs)
 {
     if (!ctx) return PG_E_INVALID;

@@ -204,6 +204,7 @@ struct Lds {
     uint4 bufA[68];                           // tier A entries {mis0 lo, sne0 lo, id lo, meta}; scratch for the quarter merge
     uint2 bufB[64 * NB];                      // tier B entries: the mismatch bitmap, NB x {mis lo, mis hi} per candidate
     uint2 hdrB[64];                           // ... and their {id lo, meta}
+    u64 ringB[3 * NB];                        // fused far-end ranges: the long-lived candidates of a pass per ring and round
     typename AccB<Id>::T accB[NB > 1 ? 64 * (NB - 1) : 1];   // reduction state of the rounds >= 1 (AccB)
     u64 qp[2 * 4 * NB];                       // the read's bit planes, two orientations
     uint16_t queue[64];                       // survivors of the prefilter for one candidate pass: (window position << 1) | kind
@@ -219,6 +220,7 @@ struct Search {
     uint4 *bufA;
     uint2 *bufB;
     uint2 *hdrB;
+    u64 *ringB;
     void *accB;
     const u32 *mm_bp;
     const u32 *chr_tab;
@@ -230,6 +232,12 @@ struct Search {
     int win_lo, win_hi, wbase;
     int nsurv;           // candidates folded since the state was reset
     int nsurv_total;     // ... since the read started (diagnostics: survivors of the seed filter)
+#ifdef PG_DIAG
+    u32 dg;              // diagnostics build: fills | seed-filter runs << 8 | candidate passes << 16 | evaluations << 24
+#define PG_DG(S, sh) ((S).dg += 1u << (sh))
+#else
+#define PG_DG(S, sh) ((void)0)
+#endif
     int cap_state;       // state-dependent relevance bound for seeds (see evaluate); T - 1 = none
     bool want_cap;       // more window chunks will be filtered after the next evaluation: keep cap_state up to date
     bool tierA;          // the short-lived tier is usable: bps + 16 <= 32 and CheckMismatches' "L > m" test cannot fail
@@ -341,11 +349,80 @@ __device__ __forceinline__ void fetch_lds(const uint4 *win, int wbase, int q, bo
 //     starts.
 // MIXED = both candidate kinds in one search (far end); otherwise the kind is wave-uniform (close end)
 // and the per-lane selects / bit reversals disappear.
+// The nested far-end ranges (128, 512, 2048 positions around the close end) that lie in one LDS chunk go through ONE
+// candidate pass: `on` = the candidates are kept apart by ring (ring 0 = [s0, e0), ring 1 = [s1, e1) minus ring 0,
+// ring 2 = the rest).  Tier A: quarter 0 folds ring 0, quarter 1 ring 1, quarters 2 and 3 share ring 2, so the state of
+// range r is the merge of the quarters up to r (evaluate's qmask).  Tier B: the masks of the long-lived candidates are
+// left in Search::ringB per ring and round; the caller folds them ring by ring (fold_tier_b) before it evaluates a range.
+struct Rings {
+    bool on;
+    int s0, e0, s1, e1;
+};
+
+// tier B: the long-lived candidates `longm[r]` (entries in bufB / hdrB) into round r of the reduction, lanes = lengths
+template <int NB, typename Id>
+__device__ __forceinline__ void fold_tier_b(const Search &S, const Query<NB> &Q, Acc<NB, Id> &A, const u64 *longm, int lane)
+{
+    constexpr int EW = NB;
+#pragma unroll
+    for (int r = 0; r < NB; r++) {
+        const int L0 = S.bps + 64 * r;
+        if (L0 > S.len - 1) break;                        // uniform
+        u64 mask = longm[r];
+        if (mask == 0ull) continue;                       // uniform
+        const int lB = opaque(lane);
+        const int L = L0 + lB;
+        u64 Mk[NB], BP[NB], QN[NB];
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            Mk[b] = low_bits(L - 64 * b);
+            BP[b] = bit_range(L - S.min_perfect - 64 * b, L - 64 * b);
+            QN[b] = q_nn<NB>(Q, b);
+        }
+        u32 m1 = A.m1, m2 = A.m2, ok = A.ok;
+        Id wid = A.id;
+        if (r > 0) {
+            m1 = m2 = PG_BIG; ok = 0u; wid = 0;
+            if ((A.dirty >> r) & 1u) {
+                AccB<Id>::load(S.accB, (r - 1) * 64 + lB, m1, m2, ok, wid);
+            }
+        }
+        while (mask != 0ull) {
+            const int i = __ffsll((long long)mask) - 1;
+            mask &= mask - 1ull;
+            const uint2 *e = S.bufB + i * EW;
+            const uint2 h = S.hdrB[i];
+            u32 k = 0u;
+            u64 bad = 0ull;
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                if (b > r + 1) continue;                  // L <= bps + 64 r + 63 < 64 (r + 2)
+                const uint2 w = e[b];
+                const u64 m = (u64)w.x | ((u64)w.y << 32);
+                k += (u32)__popcll(b < r ? m : (m & Mk[b]));
+                // exact inequality = mismatch with the read's N bits flipped (block_masks); the window lies inside the read
+                if (b + 1 >= r) bad |= (m ^ QN[b]) & BP[b];        // L - m >= 64 r - 64 (m <= 64 <= 64 + bps)
+            }
+            u32 okc = bad == 0ull ? (h.y >> 31) : 0u;
+            if (S.len_check) okc = (u32)L >= ((h.y >> 8) & 0x7fu) ? okc : 0u;   // uniform branch
+            const Id cid = sizeof(Id) == 8 ? (Id)((u64)h.x | ((u64)(h.y & 0xffu) << 32)) : (Id)h.x;
+            fold<Id>(m1, m2, wid, ok, k, cid, okc);
+        }
+        if (r == 0) { A.m1 = m1; A.m2 = m2; A.ok = ok; A.id = wid; }
+        else {
+            AccB<Id>::store(S.accB, (r - 1) * 64 + lB, m1, m2, ok, wid);
+            A.dirty |= 1u << r;
+        }
+    }
+}
+
+// ring_n (rings only): queued candidates per ring
 template <int NB, typename Id, bool MIXED>
 __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB> &Q, Acc<NB, Id> &A, int wbase,
-                                                int origin, u32 region, int n, int lane)
+                                                int origin, u32 region, int n, int lane, const Rings &R, int *ring_n)
 {
     constexpr int EW = NB;                                // 64-base blocks per tier B entry
+    PG_DG(const_cast<Search &>(S), 16);
     bool valid = lane < n;
     int p = 0;
     bool isB = MIXED ? false : Q.allowB;
@@ -402,83 +479,76 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
     const bool sht = valid && !lng;
     const u64 shortm = ballot64(sht);
     u64 longm[NB];
-    longm[0] = ballot64(lng);
+    // tier A lists: the short-lived candidates sit in bufA sorted by ring (one list without rings); a quarter walks its
+    // list from qb in steps of qs up to qe
+    const int nA = __popcll(shortm);
+    int qb, qs, qe, n_iter;
+    {
+        const int qd = opaque(lane) >> 4;
+        if (MIXED && R.on) {
+            const int ring = (p >= R.s0 && p < R.e0) ? 0 : ((p >= R.s1 && p < R.e1) ? 1 : 2);
+            const u64 in0 = ballot64(lane < n && ring == 0), in1 = ballot64(lane < n && ring == 1);
+            ring_n[0] = __popcll(in0);
+            ring_n[1] = __popcll(in1);
+            ring_n[2] = n - ring_n[0] - ring_n[1];
+            const u64 sh0 = shortm & in0, sh1 = shortm & in1, sh2 = shortm & ~(in0 | in1);
+            const int n0 = __popcll(sh0), n1 = __popcll(sh1), n2 = nA - n0 - n1;
+            if (sht) {
+                const u64 mine = ring == 0 ? sh0 : (ring == 1 ? sh1 : sh2);
+                const int rank = __popcll(mine & low_bits(lane)) + (ring == 0 ? 0 : (ring == 1 ? n0 : n0 + n1));
+                S.bufA[rank] = make_uint4(m0lo, s0lo, (u32)id, meta);
+            }
+            qb = qd == 0 ? 0 : (qd == 1 ? n0 : n0 + n1 + (qd - 2));
+            qs = qd < 2 ? 1 : 2;
+            qe = qd == 0 ? n0 : (qd == 1 ? n0 + n1 : nA);
+            const int h2 = (n2 + 1) >> 1;
+            n_iter = n0 > n1 ? n0 : n1;
+            n_iter = n_iter > h2 ? n_iter : h2;
+            const u64 inl[3] = { in0, in1, ~(in0 | in1) };
 #pragma unroll
-    for (int r = 1; r < NB; r++) longm[r] = ballot64(lng && kk[r] < S.T);
-    if (sht) {
-        const int rank = __popcll(shortm & low_bits(lane));
-        S.bufA[rank] = make_uint4(m0lo, s0lo, (u32)id, meta);
+            for (int x = 0; x < 3; x++) {
+                const u64 l0 = ballot64(lng) & inl[x];
+                if (lane == 0) S.ringB[x * NB] = l0;
+#pragma unroll
+                for (int r = 1; r < NB; r++) {
+                    const u64 lr = ballot64(lng && kk[r] < S.T) & inl[x];
+                    if (lane == 0) S.ringB[x * NB + r] = lr;
+                }
+            }
+        } else {
+            if (sht) {
+                const int rank = __popcll(shortm & low_bits(lane));
+                S.bufA[rank] = make_uint4(m0lo, s0lo, (u32)id, meta);
+            }
+            qb = qd;
+            qs = 4;
+            qe = nA;
+            n_iter = (nA + 3) >> 2;
+            longm[0] = ballot64(lng);
+#pragma unroll
+            for (int r = 1; r < NB; r++) longm[r] = ballot64(lng && kk[r] < S.T);
+        }
     }
     if (lng) S.hdrB[lane] = make_uint2((u32)id, meta);
     __syncthreads();
     // ---- tier A
-    const int nA = __popcll(shortm);
     if (nA > 0) {
         const int lA = opaque(lane);
-        const int L = S.bps + (lA & 15), qd = lA >> 4;
+        const int L = S.bps + (lA & 15);
         const u32 mk = low32(L);
         const u32 bpm = mk & ~low32(L - S.min_perfect);               // bits [L - m, L)
-        for (int base = 0; base < nA; base += 4) {
-            const int idx = base + qd;
-            const uint4 e = S.bufA[idx];                               // bufA has 4 spare entries
+        int idx = qb;
+        for (int it = 0; it < n_iter; it++, idx += qs) {
+            const uint4 e = S.bufA[idx < 67 ? idx : 67];                // (an index past the quarter's list is not used)
             u32 k = (u32)__popc(e.x & mk);
-            k = idx < nA ? k : PG_BIG;
+            k = idx < qe ? k : PG_BIG;
             const u32 okc = (e.y & bpm) == 0u ? (e.w >> 31) : 0u;    // (no "L > m" test: tier A is off when it can fail)
             const Id cid = sizeof(Id) == 8 ? (Id)((u64)e.z | ((u64)(e.w & 0xffu) << 32)) : (Id)e.z;
             fold<Id>(A.a1, A.a2, A.aid, A.aok, k, cid, okc);
         }
     }
-    // ---- tier B
-#pragma unroll
-    for (int r = 0; r < NB; r++) {
-        const int L0 = S.bps + 64 * r;
-        if (L0 > S.len - 1) break;                        // uniform
-        u64 mask = longm[r];
-        if (mask == 0ull) continue;                       // uniform
-        const int lB = opaque(lane);
-        const int L = L0 + lB;
-        u64 Mk[NB], BP[NB], QN[NB];
-#pragma unroll
-        for (int b = 0; b < NB; b++) {
-            Mk[b] = low_bits(L - 64 * b);
-            BP[b] = bit_range(L - S.min_perfect - 64 * b, L - 64 * b);
-            QN[b] = q_nn<NB>(Q, b);
-        }
-        u32 m1 = A.m1, m2 = A.m2, ok = A.ok;
-        Id wid = A.id;
-        if (r > 0) {
-            m1 = m2 = PG_BIG; ok = 0u; wid = 0;
-            if ((A.dirty >> r) & 1u) {
-                AccB<Id>::load(S.accB, (r - 1) * 64 + lB, m1, m2, ok, wid);
-            }
-        }
-        while (mask != 0ull) {
-            const int i = __ffsll((long long)mask) - 1;
-            mask &= mask - 1ull;
-            const uint2 *e = S.bufB + i * EW;
-            const uint2 h = S.hdrB[i];
-            u32 k = 0u;
-            u64 bad = 0ull;
-#pragma unroll
-            for (int b = 0; b < NB; b++) {
-                if (b > r + 1) continue;                  // L <= bps + 64 r + 63 < 64 (r + 2)
-                const uint2 w = e[b];
-                const u64 m = (u64)w.x | ((u64)w.y << 32);
-                k += (u32)__popcll(b < r ? m : (m & Mk[b]));
-                // exact inequality = mismatch with the read's N bits flipped (block_masks); the window lies inside the read
-                if (b + 1 >= r) bad |= (m ^ QN[b]) & BP[b];        // L - m >= 64 r - 64 (m <= 64 <= 64 + bps)
-            }
-            u32 okc = bad == 0ull ? (h.y >> 31) : 0u;
-            if (S.len_check) okc = (u32)L >= ((h.y >> 8) & 0x7fu) ? okc : 0u;   // uniform branch
-            const Id cid = sizeof(Id) == 8 ? (Id)((u64)h.x | ((u64)(h.y & 0xffu) << 32)) : (Id)h.x;
-            fold<Id>(m1, m2, wid, ok, k, cid, okc);
-        }
-        if (r == 0) { A.m1 = m1; A.m2 = m2; A.ok = ok; A.id = wid; }
-        else {
-            AccB<Id>::store(S.accB, (r - 1) * 64 + lB, m1, m2, ok, wid);
-            A.dirty |= 1u << r;
-        }
-    }
+    // ---- tier B (with rings: left to the caller, ring by ring)
+    if (!(MIXED && R.on)) fold_tier_b<NB, Id>(S, Q, A, longm, lane);
     __syncthreads();
 }
 
@@ -490,6 +560,7 @@ __device__ __forceinline__ void stage_window(const PgDevRef &ref, Search &S, lon
 {
     const int nw = ((hi - lo + 31) >> 5) + 2;
     const u32 sh = (u32)(lo & 31);
+    PG_DG(S, 0);
     __syncthreads();
     {
         const long long g0 = wo + (long long)(lo >> 5);     // arithmetic shift = floor
@@ -756,6 +827,7 @@ __device__ __forceinline__ void seed_filter(const Search &S, const Query<NB> &Q,
                                             u32 &mF, u32 &mB)
 {
     const int T = S.T;
+    PG_DG(const_cast<Search &>(S), 8);
     // bases inspected: two more in the chunks of wide far-end windows, where survivors cost a whole pass of
     // fold_candidates for a handful of candidates (measured: -4 % time at -x 5, +2 % if used everywhere)
     const int J = seed_depth(S.len, T, wide);
@@ -853,7 +925,7 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
                 S.nsurv += n;
                 S.nsurv_total += n;
                 __syncthreads();
-                fold_candidates<NB, Id, MIXED>(S, Q, A, wb, origin, region, n, lane);
+                fold_candidates<NB, Id, MIXED>(S, Q, A, wb, origin, region, n, lane, Rings{ false, 0, 0, 0, 0 }, nullptr);
                 slot -= n;
                 end -= n;
                 if (end == 0 && h == nh) break;
@@ -926,11 +998,11 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
 #if defined(PG_DUP) && PG_DUP == 4
             {   // diagnostics: the same pass into a throw-away copy of the state
                 Acc<NB, Id> A2 = A;
-                fold_candidates<NB, Id, MIXED>(S, Q, A2, wb, origin, region, n, opaque(lane));
+                fold_candidates<NB, Id, MIXED>(S, Q, A2, wb, origin, region, n, opaque(lane), Rings{ false, 0, 0, 0, 0 }, nullptr);
                 if (A2.m1 == 0x12345u) A.m1 = A2.m2;
             }
 #endif
-            fold_candidates<NB, Id, MIXED>(S, Q, A, wb, origin, region, n, lane);
+            fold_candidates<NB, Id, MIXED>(S, Q, A, wb, origin, region, n, lane, Rings{ false, 0, 0, 0, 0 }, nullptr);
         }
     }
 }
@@ -983,12 +1055,15 @@ __device__ __forceinline__ u32 mm_of(const Search &S, int L)
 // levels up to +ADDITIONAL_MISMATCH hold no other (searcher.cpp:171-191, pindel.cpp:2849-2893), after
 // CheckMismatches (already folded into the state).  mm0 = g_maxMismatch[bps + lane] (round 0).  The
 // reduction itself is not modified.
+// qmask: the tier A quarters that belong to the state (bit q; all four unless the pass kept the rings of the nested
+// far-end ranges apart, see Rings).
 template <int NB, typename Id>
-__device__ __forceinline__ void evaluate(Search &S, const Acc<NB, Id> &A, u32 mm0, Eval<NB, Id> &E, int lane)
+__device__ __forceinline__ void evaluate(Search &S, const Acc<NB, Id> &A, u32 mm0, Eval<NB, Id> &E, int lane, int qmask = 15)
 {
     E.n_runs = 0;
     E.max_len = 0;
     E.id_last = 0;
+    PG_DG(S, 24);
     // tier A lives in four 16-lane quarters: bring quarters 1..3 to quarter 0 through LDS and merge
     u32 t1 = A.m1, t2 = A.m2, tok = A.ok;
     Id tid = A.id;
@@ -1001,6 +1076,7 @@ __device__ __forceinline__ void evaluate(Search &S, const Acc<NB, Id> &A, u32 mm
             a1 = A.a1; a2 = A.a2; aok = A.aok; aid = A.aid;
 #pragma unroll
             for (int q = 1; q < 4; q++) {
+                if (!((qmask >> q) & 1)) continue;            // uniform
                 const uint4 o = S.bufA[lane + 16 * q];
                 const Id oid = sizeof(Id) == 8 ? (Id)((u64)o.z | ((u64)o.w << 32)) : (Id)o.z;
                 merge<Id>(a1, a2, aid, aok, o.x, o.y & 0xffffu, oid, o.y >> 16);
@@ -1199,6 +1275,9 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     S.win_wo = -1;
     S.win_hi = S.wbase = 0;
     S.nsurv_total = 0;
+#ifdef PG_DIAG
+    S.dg = 0u;
+#endif
     S.cap_state = 255;
     S.want_cap = false;
     // the read's packed record (rid is wave-uniform)
@@ -1317,6 +1396,10 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                 if (S.nsurv != nsurv_eval) {
                     nsurv_eval = S.nsurv;
                     Eval<NB, Id> E;
+#if defined(PG_DUP) && PG_DUP == 5
+                    evaluate<NB, Id>(S, A, mm0, E, opaque(lane));
+                    if (E.n_runs == 0x12345) A.m1 = (u32)E.max_len;      // diagnostics: the evaluation twice
+#endif
                     evaluate<NB, Id>(S, A, mm0, E, opaque(lane));
                     close_max = uni(E.max_len);
 #if defined(PG_STOP) && PG_STOP == 6
@@ -1381,9 +1464,13 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
             const int chr_size = chr_size_of(ref, S, chr);
             int far_bases = 0;
             // a search window's result replaces UP_Far if its MaxLen is >= (NewUPFarIsBetter, farend_searcher.cpp:30-44)
-            auto far_update = [&](int origin, const pg_window *bdw) {
+            auto far_update = [&](int origin, const pg_window *bdw, int qmask) {
                 Eval<NB, Id> E;
-                evaluate<NB, Id>(S, A, mm0, E, opaque(lane));
+#if defined(PG_DUP) && PG_DUP == 5
+                evaluate<NB, Id>(S, A, mm0, E, opaque(lane), qmask);
+                if (E.n_runs == 0x12345) A.m1 = (u32)E.max_len;
+#endif
+                evaluate<NB, Id>(S, A, mm0, E, opaque(lane), qmask);
                 const int mx = uni(E.max_len);
                 if (mx >= far_max) {
                     far_max = mx;
@@ -1414,7 +1501,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                     scan_range<NB, Id>(ref, S, Q, A, chr_word_off_of(ref, S, uni(bw.chr_id)), s, s, e, e, 0, 0, st,
                                        (u32)w, opaque(lane), false, unused0, unused1, unused_valid);
                 }
-                if (S.nsurv > 0) far_update(0, bd);
+                if (S.nsurv > 0) far_update(0, bd, 15);
                 done = far_max + close_max >= len;           // goodFarEndFound (pindel.cpp:480-483)
             }
             if (!done) {
@@ -1431,16 +1518,99 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                 else emax = chr_size - (int)prm.spacer;
                 u32 cacheF = 0u, cacheB = 0u;                    // seed-filter masks of the innermost chunk
                 bool cache_valid = false;
-                int ps = 0, pe = 0, span = 64, nsurv_eval = 0;
+                int ps = 0, pe = 0, nsurv_eval = 0;
                 A.reset();
                 S.cap_state = 255;
                 S.want_cap = prm.max_range_index >= 3;     // ranges beyond the cached innermost chunk will be filtered
                 S.nsurv = 0;
-                for (int r = 0; r <= prm.max_range_index; r++, span *= 4) {
-                    int s, e;
+                auto range_of = [&](int span, int &s, int &e) {
                     if ((u32)center > (u32)span + prm.spacer) s = center - span; else s = (int)prm.spacer;
                     if ((u32)center + (u32)span + prm.spacer < (u32)chr_size) e = center + span;
                     else e = chr_size - (int)prm.spacer;
+                };
+                int r_first = 0;
+#ifndef PG_NO_FUSED_RANGES
+                // FUSED RANGES.  The ranges that lie in the innermost chunk (spans 64, 256, 1024) share ONE candidate pass:
+                // the survivors of the whole chunk are queued at once, the pass keeps the rings apart (Rings), and the
+                // ranges are then evaluated one after the other exactly as the reference walks them -- ring r's long-lived
+                // candidates are folded just before range r is evaluated, its short-lived ones sit in their own tier A
+                // quarter(s).  A read that needs all three ranges pays one pass instead of three.
+                {
+                    const int R = prm.max_range_index < 2 ? prm.max_range_index : 2;
+                    int rs[3], re[3];
+#pragma unroll
+                    for (int r = 0; r < 3; r++) {
+                        range_of(64 << (2 * (r < R ? r : R)), rs[r], re[r]);
+                        rs[r] = uni(rs[r]);
+                        re[r] = uni(re[r]);
+                    }
+                    if (rs[R] < re[R]) {
+                        const int wb = g0 - 64 * NB;
+                        const int se = emax < g0 + (int)PG_CHUNK ? emax : g0 + (int)PG_CHUNK;
+                        if (!(chr_wo == S.win_wo && S.wbase == wb && se + 64 * NB <= S.win_hi))
+                            stage_window<NB>(ref, S, chr_wo, wb, se + 64 * NB, lane);
+                        u32 mF = 0u, mB = 0u;
+                        seed_filter<NB, true>(S, Q, false, false, lane, mF, mB);
+                        cacheF = mF;
+                        cacheB = mB;
+                        cache_valid = true;
+                        const int pbase = g0 + 32 * lane;
+                        const u32 rmask = bits32(rs[R] - pbase, re[R] - pbase);
+                        mF &= rmask;
+                        mB &= rmask;
+                        const u32 cnt = (u32)(__popc(mF) + __popc(mB));
+                        const u32 incl = wave_scan(cnt);
+                        const int total = (int)read_lane(incl, 63);
+                        if (total <= WAVE) {
+                            r_first = R + 1;
+                            ps = rs[R];
+                            pe = re[R];
+                            if (total > 0) {
+                                int slot = (int)(incl - cnt);
+                                __syncthreads();
+                                while (mF != 0u) {
+                                    const int bit = __ffs((int)mF) - 1;
+                                    mF &= mF - 1u;
+                                    S.queue[slot] = (uint16_t)((u32)(64 * NB + 32 * lane + bit) << 1);
+                                    slot++;
+                                }
+                                while (mB != 0u) {
+                                    const int bit = __ffs((int)mB) - 1;
+                                    mB &= mB - 1u;
+                                    S.queue[slot] = (uint16_t)(((u32)(64 * NB + 32 * lane + bit) << 1) | 1u);
+                                    slot++;
+                                }
+                                S.nsurv += total;
+                                S.nsurv_total += total;
+                                __syncthreads();
+                                int ring_n[3];
+                                fold_candidates<NB, Id, true>(S, Q, A, wb, origin, 0u, total, lane,
+                                                              Rings{ true, rs[0], re[0], rs[1], re[1] }, ring_n);
+                                for (int r = 0; r <= R; r++) {
+                                    if (uni(ring_n[r]) > 0) {       // (no new candidate: the evaluation would repeat the previous one)
+                                        u64 longm[NB];
+#pragma unroll
+                                        for (int k = 0; k < NB; k++) longm[k] = read_lane(S.ringB[r * NB + k], 0);
+                                        fold_tier_b<NB, Id>(S, Q, A, longm, lane);
+                                        far_update(origin, nullptr, r == 0 ? 1 : (r == 1 ? 3 : 15));
+                                    }
+                                    if (far_max + close_max >= len) {        // goodFarEndFound
+                                        done = true;
+                                        ps = rs[r];
+                                        pe = re[r];
+                                        break;
+                                    }
+                                }
+                                nsurv_eval = S.nsurv;
+                            }
+                        }
+                    }
+                }
+#endif
+                int span = 64 << (2 * r_first);
+                for (int r = r_first; r <= prm.max_range_index && !done; r++, span *= 4) {
+                    int s, e;
+                    range_of(span, s, e);
                     if (s < e) {
                         scan_range<NB, Id>(ref, S, Q, A, chr_wo, g0, s, e, emax, ps, pe, origin, 0u, opaque(lane), true,
                                            cacheF, cacheB, cache_valid);
@@ -1458,7 +1628,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
 #endif
                     if (S.nsurv != nsurv_eval) {
                         nsurv_eval = S.nsurv;
-                        far_update(origin, nullptr);
+                        far_update(origin, nullptr, 15);
                     }
 #if defined(PG_STOP) && PG_STOP == 5
                     break;                            // diagnostics: + first range's evaluation
@@ -1475,7 +1645,11 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
         uint4 *op = (uint4 *)(B.out + rid);
         if (do_close) {
             op[0] = make_uint4(close_base, (u32)n_close, far_base, (u32)n_far);
+#ifdef PG_DIAG
+            op[1] = make_uint4(close_last, (u32)close_max | ((u32)flipped << 16), alg, S.dg);
+#else
             op[1] = make_uint4(close_last, (u32)close_max | ((u32)flipped << 16), alg, (u32)S.nsurv_total);
+#endif
         } else {
             u32 *o = (u32 *)op;
             o[2] = far_base;
@@ -1509,6 +1683,7 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
     S.bufA = lds.bufA;
     S.bufB = lds.bufB;
     S.hdrB = lds.hdrB;
+    S.ringB = lds.ringB;
     S.accB = lds.accB;
     S.mm_bp = lds.mm_bp;
     S.chr_tab = lds.chr_tab;
@@ -1566,6 +1741,9 @@ static void launch(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch
                            *ref, *prm, *batch, max_len, levels);
         return;
     }
+#ifdef PG_ONLY_BENCH
+    abort();          // experiment builds (scripts/build_variant.sh -DPG_ONLY_BENCH): only the fused kernel exists
+#else
     if (mode & PG_MODE_CLOSE)
         hipLaunchKernelGGL((pg_search_kernel<NB, Id, PG_MODE_CLOSE>), grid, block, lds_pad, st,
                            *ref, *prm, *batch, max_len, levels);
@@ -1574,6 +1752,7 @@ static void launch(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch
         hipLaunchKernelGGL((pg_search_kernel<NB, Id, PG_MODE_FAR>), grid, block, lds_pad, st,
                            *ref, *prm, *batch, max_len, levels);
     }
+#endif
 }
 
 // ---------------------------------------------------------------------------------
@@ -1713,6 +1892,12 @@ extern "C" int pg_debug_occupancy(uint32_t max_len, uint32_t levels, int small_i
     (void)levels;
     *lds_bytes = (unsigned)sizeof(Lds<2, u32>);
     hipError_t e1, e2;
+#ifdef PG_ONLY_BENCH
+    (void)small_ids;
+    e1 = e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(far_blocks, pg_search_kernel<2, u32, PG_MODE_BOTH>, WAVE, 0);
+    *close_blocks = *far_blocks;
+    return (int)e1;
+#endif
     if (small_ids) {
         e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(close_blocks, pg_search_kernel<2, u32, PG_MODE_CLOSE>, WAVE, 0);
         e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(far_blocks, pg_search_kernel<2, u32, PG_MODE_BOTH>, WAVE, 0);
@@ -1732,6 +1917,14 @@ extern "C" int pg_launch_search(const PgDevRef *ref, const PgDevParams *prm, con
     static const unsigned lds_pad = getenv("PG_LDS_PAD") ? (unsigned)atoi(getenv("PG_LDS_PAD")) : 0u;
     // 64-base blocks per read: 1/2/3/4/8 with 32-bit candidate ids (the common case), 2/4/8 with 64-bit ids
     const int nb = max_len <= 128 ? 2 : (max_len <= 256 ? 4 : 8);
+#ifdef PG_ONLY_BENCH
+    // experiment builds: only the instantiations of the bench workloads (100 / 150-base reads, 32-bit ids), compiled in a
+    // fraction of the time
+    if (!small_ids || max_len > 192) abort();
+    if (nb == 2 && max_len > 64) launch<2, u32>(ref, prm, batch, mode, max_len, levels, st, lds_pad);
+    else launch<3, u32>(ref, prm, batch, mode, max_len, levels, st, lds_pad);
+    return (int)hipGetLastError();
+#else
     if (small_ids) {
         if (max_len <= 64) launch<1, u32>(ref, prm, batch, mode, max_len, levels, st, lds_pad);
         else if (nb == 2) launch<2, u32>(ref, prm, batch, mode, max_len, levels, st, lds_pad);
@@ -1744,4 +1937,5 @@ extern "C" int pg_launch_search(const PgDevRef *ref, const PgDevParams *prm, con
         else launch<8, u64>(ref, prm, batch, mode, max_len, levels, st, lds_pad);
     }
     return (int)hipGetLastError();
+#endif
 }

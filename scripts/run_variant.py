@@ -1,5 +1,8 @@
 """Diagnostics: run the device-resident search of the bench workload with another build of the library
-(e.g. one compiled with -DPG_STOP_AFTER=n or -DPG_ABL_*), for rocprofv3 counter passes."""
+(e.g. one compiled with -DPG_STOP=n or -DPG_DUP=n), for rocprofv3 counter passes and A/B timing.  Prints the kernel
+time, the candidates per read and a digest of the downloaded result (equal digests = bit-identical results).
+  PG_X=<n> selects -x n, PG_LEN=<bases> the read length."""
+import hashlib
 import os
 import sys
 
@@ -11,13 +14,22 @@ binding.use_library(os.path.abspath(sys.argv[1]))
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 2_000_000
 dev = torch.device("cuda", 0)
 ref = synth.make_reference(62_435_964, seed=20260927, device=dev)
-batch = synth.make_reads(ref, n, seed=20260928, device=dev)
-kw = {}
+kw, rkw = {}, {}
 if os.environ.get("PG_X"):
     kw["max_range_index"] = int(os.environ["PG_X"])
+if os.environ.get("PG_LEN"):
+    rkw["read_len"] = int(os.environ["PG_LEN"])
+batch = synth.make_reads(ref, n, seed=20260928, device=dev, **rkw)
 eng = binding.Engine(**kw)
 eng.load_reference([("20", ref)])
 db = eng.upload(batch)
+ms = []
 for _ in range(3):
     eng.search_device(db)
-print(os.path.basename(sys.argv[1]), "kernel ms", round(eng.last_stats()[0], 2), "candidates per read", round(eng.candidates(db) / n, 1))
+    ms.append(eng.last_stats()[0])
+res = eng.download(db)
+h = hashlib.sha256()
+for a in (res.close_off, res.far_off, res.rc_flag, res.close_runs, res.far_runs):
+    h.update(a.tobytes())
+print(os.path.basename(sys.argv[1]), "kernel ms", round(min(ms), 3), "candidates per read", round(eng.candidates(db) / n, 1),
+      "digest", h.hexdigest()[:16])
