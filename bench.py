@@ -336,9 +336,9 @@ def main():
     if bins is not None:
         eng.search_device(dbatch)                 # the whole batch once, for the accounting below (same reads)
     alg_bytes = eng.algorithmic_bytes(dbatch)     # per launch
-    n_runs = eng.last_stats()[1]
     n_cand = eng.candidates(dbatch)
     res = eng.download(dbatch)
+    n_runs = int(res.close_off[-1]) + int(res.far_off[-1])
     n_close = int((res.close_off[1:] > res.close_off[:-1]).sum())
     n_far = int((res.far_off[1:] > res.far_off[:-1]).sum())
     digests = shard.read_digests(res)

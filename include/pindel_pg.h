@@ -208,7 +208,8 @@ int  pg_device_batch_search(pg_ctx *ctx, pg_device_batch *b);
 int  pg_device_batch_download(pg_ctx *ctx, pg_device_batch *b, pg_result **out);
 void pg_device_batch_free(pg_ctx *ctx, pg_device_batch *b);
 /* HIP-event duration (ms) of the kernel of the last search on this ctx (events recorded on
- * the ctx's own stream around the launch) and the number of runs it produced. */
+ * the ctx's own stream around the launch) and the run-pool slots it took (reserved per read + allocated; the number
+ * of runs is close_off[n] + far_off[n] of the downloaded result). */
 int  pg_last_search_stats(const pg_ctx *ctx, double *kernel_ms, uint64_t *n_runs);
 /* Algorithmic bytes of the last search of this batch (SURVEY.md 8d formula, accumulated per
  * read by the kernel; DESIGN.md "roofline accounting").  Copies n x 4 bytes back: call it

@@ -402,7 +402,8 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, std::vector<
     const uint64_t nseq = n ? reads->seq_off[n] - base0 : 0;
     off.resize(n + 1);
     for (size_t i = 0; i <= n; i++) off[i] = (n ? reads->seq_off[i] : 0) - base0;
-    b->pool_shard_cap = (uint32_t)std::min<uint64_t>((3ull * n) / PG_POOL_SHARDS + 96ull, 0x7fffffffull / PG_POOL_SHARDS);
+    // every read reserves PG_RESERVE slots (one atomic per claim of reads); lists longer than their share allocate more
+    b->pool_shard_cap = (uint32_t)std::min<uint64_t>(((PG_RESERVE + 2ull) * n) / PG_POOL_SHARDS + 512ull, 0x7fffffffull / PG_POOL_SHARDS);
     if (getenv("PG_TEST_TINY_POOL")) b->pool_shard_cap = 1;      // tests: force the overflow/regrow path
     const size_t n1 = std::max<size_t>(n, 1);
     // (pointer, bytes) of every buffer; the zeroed block (outputs) is contiguous in the arena case

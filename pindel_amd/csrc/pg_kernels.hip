@@ -1270,7 +1270,8 @@ __device__ __forceinline__ bool first_base_ok(const Query<NB> &Q)
 //               r = 1 .. MaxRangeIndex+1 until goodFarEndFound                          pindel.cpp:1006-1070
 template <int NB, typename Id, int mode>
 __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevParams &prm, const PgDevBatch &B,
-                                            Search &S, u64 *qplanes, const uint32_t rid, const int slot, const int lane)
+                                            Search &S, u64 *qplanes, const uint32_t rid, const int slot, const int lane,
+                                            const u32 res_base, const bool res_fits)
 {
     S.win_wo = -1;
     S.win_hi = S.wbase = 0;
@@ -1409,7 +1410,12 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                     if (uni(E.n_runs) > 0) {
                         u64 kept[NB];
                         n_close = uni(count_kept<NB, Id>(E, true, kept));
-                        close_base = pool_alloc(B, n_close, lane, fits);
+                        // the read's reserved slots, or (a list longer than that) an allocation of its own
+                        if (n_close <= (int)PG_RES_CLOSE) {
+                            close_base = res_base;
+                            fits = res_fits;
+                        } else
+                            close_base = pool_alloc(B, n_close, lane, fits);
                         if (fits) emit_runs<NB, Id>(S, true, false, chr, w1s, nullptr, E, kept, B.pool + close_base, opaque(lane));
                         // AbsLoc of the last point (getLastAbsLocCloseEnd)
                         const u64 idl = (u64)E.id_last;
@@ -1479,7 +1485,14 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                     if (n_far > 0) {
                         u64 kept[NB];
                         (void)count_kept<NB, Id>(E, false, kept);
-                        far_base = pool_alloc(B, n_far, lane, fits);
+                        if (n_far <= (int)PG_RES_FAR) {          // (a later range's result overwrites an earlier one's slots)
+                            far_base = res_base + PG_RES_CLOSE;
+                            fits = fits && res_fits;
+                        } else {
+                            bool f2 = true;
+                            far_base = pool_alloc(B, n_far, lane, f2);
+                            fits = fits && f2;
+                        }
                         if (fits) emit_runs<NB, Id>(S, false, true, chr, origin, bdw, E, kept, B.pool + far_base, opaque(lane));
                     }
                 }
@@ -1712,8 +1725,18 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
                 ((u32 *)lds.rec)[lane] = ((const u32 *)(B.in + B.first_read + first))[lane];
             __syncthreads();
         }
-        for (uint32_t i = first; i < end; i++)
-            search_read<NB, Id, mode>(ref, prm, B, S, qplanes, B.first_read + i, (int)(i - first), opaque(lane));
+        // run-pool slots of the claim's reads: one atomic per claim (its round trip overlaps the record load above)
+        u32 res = 0u;
+        {
+            const u32 shard = blockIdx.x & (PG_POOL_SHARDS - 1u);
+            if (lane == 0) res = atomicAdd(B.pool_used + shard * 16u, PG_CLAIM * PG_RESERVE);
+            res = (u32)uni((int)res);
+            const bool res_fits = (u64)res + (u64)(PG_CLAIM * PG_RESERVE) <= (u64)B.pool_shard_cap;
+            res += shard * B.pool_shard_cap;
+            for (uint32_t i = first; i < end; i++)
+                search_read<NB, Id, mode>(ref, prm, B, S, qplanes, B.first_read + i, (int)(i - first), opaque(lane),
+                                          res + (i - first) * PG_RESERVE, res_fits);
+        }
     }
 }
 
