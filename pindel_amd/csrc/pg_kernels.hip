@@ -209,6 +209,7 @@ struct Lds {
     u64 qp[2 * 4 * NB];                       // the read's bit planes, two orientations
     uint16_t queue[64];                       // survivors of the prefilter for one candidate pass: (window position << 1) | kind
     u32 mm_bp[PG_MM_BREAKS];                  // breakpoints of g_maxMismatch (copied from the kernel arguments)
+    uint8_t mm_tab[64 * NB + 64];             // g_maxMismatch[L] for every length a lane can own (filled once per workgroup)
     u32 chr_tab[3 * PG_CHR_TAB];              // word offset (lo, hi) and size of the first PG_CHR_TAB chromosomes
     uint4 rec[PG_REC_LDS(NB) ? 2 * PG_CLAIM : 0];   // the packed records of the claimed reads (one coalesced load per claim)
 };
@@ -223,6 +224,7 @@ struct Search {
     u64 *ringB;
     void *accB;
     const u32 *mm_bp;
+    const uint8_t *mm_tab;
     const u32 *chr_tab;
     int mm_j[2];         // g_maxMismatch[J] for the two filter depths J of this read (plain, wide): once per read
     const uint4 *rec;    // PG_REC_LDS: the claim's records in LDS    // LDS copy of PgDevParams::mm_bp
@@ -338,6 +340,21 @@ __device__ __forceinline__ void fetch_lds(const uint4 *win, int wbase, int q, bo
     rnn = funnel64(w0.z, w1.z, w2.z, s);
     if (rev) { rlo = __brevll(rlo); rhi = __brevll(rhi); rnn = __brevll(rnn); }
 }
+// ... when the kind is wave-uniform (close end): a branch instead of six reversals + six selects per block
+__device__ __forceinline__ void fetch_lds_uniform(const uint4 *win, int wbase, int q, bool rev,
+                                                  u64 &rlo, u64 &rhi, u64 &rnn)
+{
+    u32 rel = (u32)(q - wbase);
+    u32 wi = rel >> 5, s = rel & 31u;
+    uint4 w0 = win[wi], w1 = win[wi + 1], w2 = win[wi + 2];
+    rlo = funnel64(w0.x, w1.x, w2.x, s);
+    rhi = funnel64(w0.y, w1.y, w2.y, s);
+    rnn = funnel64(w0.z, w1.z, w2.z, s);
+    if (uni((int)rev)) {
+        asm volatile("" : "+v"(rlo), "+v"(rhi), "+v"(rnn));       // (keeps the compiler from turning the branch into selects)
+        rlo = __brevll(rlo); rhi = __brevll(rhi); rnn = __brevll(rnn);
+    }
+}
 
 // ---------------------------------------------------------------------------------
 // One pass over n (<= 64) queued candidates.
@@ -448,7 +465,8 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
         if (need) {
             u64 rlo, rhi, rnn, m, s;
             int q = isB ? p - 64 * b - 63 : p + 64 * b;
-            fetch_lds(S.win, wbase, q, isB, rlo, rhi, rnn);
+            if (MIXED) fetch_lds(S.win, wbase, q, isB, rlo, rhi, rnn);
+            else fetch_lds_uniform(S.win, wbase, q, isB, rlo, rhi, rnn);
             block_masks<NB>(Q, b, comp, rlo, rhi, rnn, m, s);
             const u64 lm = low_bits(S.len - 64 * b);
             m &= lm;
@@ -1045,9 +1063,7 @@ struct Eval {
 // g_maxMismatch[L] for the lane's L (<= M for L <= len)
 __device__ __forceinline__ u32 mm_of(const Search &S, int L)
 {
-    u32 mmL = 0u;
-    for (int k = 0; k < S.M; k++) mmL += (u32)L >= S.mm_bp[k] ? 1u : 0u;
-    return mmL;
+    return S.mm_tab[L];          // (L <= bps + 64 NB - 1 < the table's size; lanes past the read are masked by the caller)
 }
 
 // The reference's rules for every L (lanes own L): "if (minimumNumberOfMismatches > g_maxMismatch[L]) return"
@@ -1068,22 +1084,24 @@ __device__ __forceinline__ void evaluate(Search &S, const Acc<NB, Id> &A, u32 mm
     u32 t1 = A.m1, t2 = A.m2, tok = A.ok;
     Id tid = A.id;
     if (S.tierA) {
-        S.bufA[lane] = make_uint4(A.a1, A.a2 | (A.aok << 16), (u32)A.aid, (u32)((u64)A.aid >> 32));
-        __syncthreads();
         u32 a1 = PG_BIG, a2 = PG_BIG, aok = 0u;
         Id aid = 0;
-        if (lane < 16) {
-            a1 = A.a1; a2 = A.a2; aok = A.aok; aid = A.aid;
+        if (lane < 16) { a1 = A.a1; a2 = A.a2; aok = A.aok; aid = A.aid; }
+        if (qmask != 1) {                                     // uniform (quarter 0 alone: nothing to fetch)
+            S.bufA[lane] = make_uint4(A.a1, A.a2 | (A.aok << 16), (u32)A.aid, (u32)((u64)A.aid >> 32));
+            __syncthreads();
+            if (lane < 16) {
 #pragma unroll
-            for (int q = 1; q < 4; q++) {
-                if (!((qmask >> q) & 1)) continue;            // uniform
-                const uint4 o = S.bufA[lane + 16 * q];
-                const Id oid = sizeof(Id) == 8 ? (Id)((u64)o.z | ((u64)o.w << 32)) : (Id)o.z;
-                merge<Id>(a1, a2, aid, aok, o.x, o.y & 0xffffu, oid, o.y >> 16);
+                for (int q = 1; q < 4; q++) {
+                    if (!((qmask >> q) & 1)) continue;        // uniform
+                    const uint4 o = S.bufA[lane + 16 * q];
+                    const Id oid = sizeof(Id) == 8 ? (Id)((u64)o.z | ((u64)o.w << 32)) : (Id)o.z;
+                    merge<Id>(a1, a2, aid, aok, o.x, o.y & 0xffffu, oid, o.y >> 16);
+                }
             }
+            __syncthreads();
         }
         merge<Id>(t1, t2, tid, tok, a1, a2, aid, aok);
-        __syncthreads();
     }
     if (S.want_cap) {
         // max over L in [bps, J] of the lowest level present (none present: no bound), + ADD; J as in seed_filter
@@ -1683,6 +1701,7 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
     __shared__ Lds<NB, Id> lds;
     const int lane = threadIdx.x;
     if (lane < PG_MM_BREAKS) lds.mm_bp[lane] = prm.mm_bp[lane];
+    for (int L = lane; L < 64 * NB + 64; L += WAVE) lds.mm_tab[L] = (uint8_t)max_mismatch_at(prm.mm_bp, L);
     if (lane < PG_CHR_TAB && lane < ref.n_chr) {
         const u64 wo = ref.chr_word_off[lane];
         lds.chr_tab[3 * lane] = (u32)wo;
@@ -1699,6 +1718,7 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
     S.ringB = lds.ringB;
     S.accB = lds.accB;
     S.mm_bp = lds.mm_bp;
+    S.mm_tab = lds.mm_tab;
     S.chr_tab = lds.chr_tab;
     S.rec = lds.rec;
     S.add_mm = prm.add_mm;
