@@ -418,7 +418,7 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, std::vector<
         { (void **)&b->close_off, n1 * 4 }, { (void **)&b->close_cnt, (n + 1) * 4 },   // + 1: the CSR scan runs over n + 1 counts
         { (void **)&b->far_off, n1 * 4 }, { (void **)&b->far_cnt, (n + 1) * 4 }, { (void **)&b->alg, n1 * 4 },
         { (void **)&b->out_rec, n1 * sizeof(PgOutRec) },
-        { (void **)&b->pool_used, (PG_POOL_SHARDS * 16 + PG_WORK_CTRS * 16) * 4 },  // run-pool cursors + the launch's read counters
+        { (void **)&b->pool_used, (PG_POOL_SHARDS * 16 + PG_WORK_CTRS * 16 + PG_DIAG_WORDS * 2) * 4 },  // run-pool cursors + the launch's read counters
     };
     const size_t n_items = sizeof items / sizeof items[0], first_zero = 8;
     auto drop = [&](int code) {
@@ -572,7 +572,7 @@ int launch_range(pg_ctx *ctx, pg_device_batch *b, int mode, uint32_t lo, uint32_
     d.first_read = lo;
     d.n_reads = cnt;
     // the persistent launch claims its reads from these counters
-    HIP_TRY(ctx, hipMemsetAsync(d.work_ctr, 0, PG_WORK_CTRS * 16 * sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(d.work_ctr, 0, (PG_WORK_CTRS * 16 + PG_DIAG_WORDS * 2) * sizeof(uint32_t), ctx->stream));
     int lrc = pg_launch_search(&ref, &prm, &d, mode, b->max_len, b->levels, small_ids(ctx, b) ? 1 : 0, ctx->stream);
     if (lrc != 0) return fail(ctx, PG_E_DEVICE, std::string("kernel launch: ") + hipGetErrorString((hipError_t)lrc));
     return PG_OK;
@@ -1111,6 +1111,16 @@ int pg_debug_read_reserved(pg_ctx *ctx, pg_device_batch *b, uint32_t *out, uint3
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (n) HIP_TRY(ctx, hipMemcpy(recs.data(), b->out_rec, (size_t)n * sizeof(PgOutRec), hipMemcpyDeviceToHost));
     for (uint32_t i = 0; i < n; i++) out[i] = recs[i].reserved;
+    return PG_OK;
+}
+
+// Diagnostics (-DPG_TIMING builds of the kernel): wave-cycles per phase of the last launch on this batch.
+int pg_debug_read_phase_cycles(pg_ctx *ctx, pg_device_batch *b, uint64_t *out, uint32_t n)
+{
+    use_device(ctx);
+    if (!ctx || !b || !out || n > PG_DIAG_WORDS) return PG_E_INVALID;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, b->pool_used + PG_POOL_SHARDS * 16 + PG_WORK_CTRS * 16, (size_t)n * 8, hipMemcpyDeviceToHost));
     return PG_OK;
 }
 

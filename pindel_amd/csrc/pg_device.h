@@ -105,6 +105,7 @@ struct PgSoaOut {
 #define PG_MM_BREAKS 16
 #define PG_POOL_SHARDS 1024u
 #define PG_WORK_CTRS 8u           // per-XCD read counters of the persistent launch, 64 bytes apart
+#define PG_DIAG_WORDS 64u         // behind the read counters: cycle accumulators of a -DPG_TIMING diagnostics build
 // Run-pool slots a workgroup reserves per claimed read with ONE atomic per claim (instead of one or two dependent
 // atomic round trips inside every read): the first PG_RES_CLOSE for the read's UP_Close runs, the rest for its UP_Far
 // runs (1.04 / 1.03 runs on average); a list that does not fit takes an allocation of its own.

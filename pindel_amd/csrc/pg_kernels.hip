@@ -212,6 +212,10 @@ struct Lds {
     uint8_t mm_tab[64 * NB + 64];             // g_maxMismatch[L] for every length a lane can own (filled once per workgroup)
     u32 chr_tab[3 * PG_CHR_TAB];              // word offset (lo, hi) and size of the first PG_CHR_TAB chromosomes
     uint4 rec[PG_REC_LDS(NB) ? 2 * PG_CLAIM : 0];   // the packed records of the claimed reads (one coalesced load per claim)
+#ifdef PG_TIMING
+    u64 t_last;
+    u32 t_acc[12];
+#endif
 };
 
 struct Search {
@@ -234,6 +238,14 @@ struct Search {
     int win_lo, win_hi, wbase;
     int nsurv;           // candidates folded since the state was reset
     int nsurv_total;     // ... since the read started (diagnostics: survivors of the seed filter)
+#ifdef PG_TIMING
+    u64 *t_last;         // diagnostics build (LDS): s_memtime at the last phase boundary, cycles per phase so far
+    u32 *t_acc;
+    int t_base;
+#define PG_T(S, k) do { if (threadIdx.x == 0) { const u64 t_ = __builtin_readcyclecounter(); (S).t_acc[k] += (u32)(t_ - *(S).t_last); *(S).t_last = t_; } } while (0)
+#else
+#define PG_T(S, k) ((void)0)
+#endif
 #ifdef PG_DIAG
     u32 dg;              // diagnostics build: fills | seed-filter runs << 8 | candidate passes << 16 | evaluations << 24
 #define PG_DG(S, sh) ((S).dg += 1u << (sh))
@@ -943,7 +955,9 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
                 S.nsurv += n;
                 S.nsurv_total += n;
                 __syncthreads();
+                PG_T(S, S.t_base);
                 fold_candidates<NB, Id, MIXED>(S, Q, A, wb, origin, region, n, lane, Rings{ false, 0, 0, 0, 0 }, nullptr);
+                PG_T(S, S.t_base + 1);
                 slot -= n;
                 end -= n;
                 if (end == 0 && h == nh) break;
@@ -1020,7 +1034,9 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
                 if (A2.m1 == 0x12345u) A.m1 = A2.m2;
             }
 #endif
+            PG_T(S, S.t_base);
             fold_candidates<NB, Id, MIXED>(S, Q, A, wb, origin, region, n, lane, Rings{ false, 0, 0, 0, 0 }, nullptr);
+            PG_T(S, S.t_base + 1);
         }
     }
 }
@@ -1294,6 +1310,9 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     S.win_wo = -1;
     S.win_hi = S.wbase = 0;
     S.nsurv_total = 0;
+#ifdef PG_TIMING
+    S.t_base = 1;
+#endif
 #ifdef PG_DIAG
     S.dg = 0u;
 #endif
@@ -1348,6 +1367,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
 #if defined(PG_STOP) && PG_STOP == 1
     return;                                           // diagnostics: instruction count up to here
 #endif
+    PG_T(S, 0);
     const bool do_close = (mode & PG_MODE_CLOSE) != 0, do_far = (mode & PG_MODE_FAR) != 0;
     int flipped = 0, close_max = 0, n_close = 0;
     u32 close_last = 0, close_base = 0, alg = 0u;
@@ -1378,6 +1398,10 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
             int ps = 0, pe = 0, nsurv_eval = 0;
             for (int att = 0; att < 4; att++) {
                 const int Rg = att >> 1;
+#ifdef PG_TIMING
+                PG_T(S, S.t_base + 2);
+                S.t_base = att == 0 ? 1 : 4;
+#endif
                 flipped = (att == 1 || att == 2) ? 1 : 0;
                 // '+' anchor: CurrentReadSeq = RC(cur), grown left to right (pindel.cpp:2271-2291)
                 // '-' anchor: CurrentReadSeq = cur, grown right to left     (pindel.cpp:2298-2319)
@@ -1467,6 +1491,10 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     return;
 #endif
     // ------------------------------------------------------------------------------- far end
+#ifdef PG_TIMING
+    PG_T(S, S.t_base + 2);
+    S.t_base = 7;
+#endif
     int n_far = 0, far_max = 0;
     u32 far_base = 0;
     // "if (CurrentBase == 'N' || MaxLenCloseEnd() == 0) return;" (farend_searcher.cpp:60-66)
@@ -1615,8 +1643,10 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                                 S.nsurv_total += total;
                                 __syncthreads();
                                 int ring_n[3];
+                                PG_T(S, 7);
                                 fold_candidates<NB, Id, true>(S, Q, A, wb, origin, 0u, total, lane,
                                                               Rings{ true, rs[0], re[0], rs[1], re[1] }, ring_n);
+                                PG_T(S, 8);
                                 for (int r = 0; r <= R; r++) {
                                     if (uni(ring_n[r]) > 0) {       // (no new candidate: the evaluation would repeat the previous one)
                                         u64 longm[NB];
@@ -1671,6 +1701,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
             alg += (u32)(3 * far_bases + 96 * n_far);
         }
     }
+    PG_T(S, 9);
     alg = (alg + 4u) >> 3;
     if (lane == 0) {
         uint4 *op = (uint4 *)(B.out + rid);
@@ -1724,6 +1755,15 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
     S.add_mm = prm.add_mm;
     S.min_perfect = prm.min_perfect;
     u64 *qplanes = lds.qp;                        // [0]: forward, [1]: reversed consumption order
+#ifdef PG_TIMING
+    S.t_acc = lds.t_acc;
+    S.t_last = &lds.t_last;
+    if (lane == 0) {
+        for (int k = 0; k < 12; k++) S.t_acc[k] = 0u;
+        *S.t_last = __builtin_readcyclecounter();
+    }
+    S.t_base = 1;
+#endif
 
     const uint32_t n = B.n_reads;
     const uint32_t per = n / PG_N_XCD;
@@ -1745,6 +1785,7 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
                 ((u32 *)lds.rec)[lane] = ((const u32 *)(B.in + B.first_read + first))[lane];
             __syncthreads();
         }
+        PG_T(S, 11);
         // run-pool slots of the claim's reads: one atomic per claim (its round trip overlaps the record load above)
         u32 res = 0u;
         {
@@ -1756,8 +1797,15 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
             for (uint32_t i = first; i < end; i++)
                 search_read<NB, Id, mode>(ref, prm, B, S, qplanes, B.first_read + i, (int)(i - first), opaque(lane),
                                           res + (i - first) * PG_RESERVE, res_fits);
+            PG_T(S, 10);
         }
     }
+#ifdef PG_TIMING
+    if (lane == 0) {
+        u64 *dg = (u64 *)(B.work_ctr + PG_WORK_CTRS * 16u);
+        for (int k = 0; k < 12; k++) atomicAdd((unsigned long long *)(dg + k), (unsigned long long)S.t_acc[k]);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------

@@ -1,6 +1,5 @@
-"""Diagnostics: per-phase wave cycles of the search kernels.  Needs pindel_amd/libpindel_pg_timing.so
-(built with -DPG_PHASE_TIMING: the kernels store s_memtime deltas of the first 65536 reads at the end
-of the alg-bytes array)."""
+"""Diagnostics: wave-cycles per phase of the search kernel (a -DPG_TIMING build: s_memtime at the phase boundaries,
+summed over all waves) on the bench workload:  python scripts/phase_timing.py <lib.so> [reads]   (PG_X / PG_LEN as usual)"""
 import ctypes as C
 import os
 import sys
@@ -10,24 +9,30 @@ import numpy as np
 import torch
 from pindel_amd import binding, synth
 
-binding.LIB_PATH = os.path.join(os.path.dirname(binding.LIB_PATH), "libpindel_pg_timing.so")
+binding.use_library(os.path.abspath(sys.argv[1]))
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
 dev = torch.device("cuda", 0)
 ref = synth.make_reference(62_435_964, seed=20260927, device=dev)
-n = 4_000_000
-batch = synth.make_reads(ref, n, seed=20260928, device=dev)
-eng = binding.Engine()
+kw, rkw = {}, {}
+if os.environ.get("PG_X"):
+    kw["max_range_index"] = int(os.environ["PG_X"])
+if os.environ.get("PG_LEN"):
+    rkw["read_len"] = int(os.environ["PG_LEN"])
+batch = synth.make_reads(ref, n, seed=20260928, device=dev, **rkw)
+eng = binding.Engine(**kw)
 eng.load_reference([("20", ref)])
 db = eng.upload(batch)
 eng.search_device(db)
 eng.search_device(db)
 L = binding.lib()
-raw = np.zeros(n, dtype=np.uint32)
-L.pg_debug_read_alg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
-assert L.pg_debug_read_alg(eng._h, db, raw.ctypes.data, n) == 0
-d = raw[n - 65536 * 16:].reshape(65536, 16).astype(np.float64)
-names = ["load planes", "scan (stage+filter+dense)", "evaluate", "publish/clean", "zero hist", "configure", "tail", "-"]
-for k, kern in ((0, "close kernel"), (8, "far kernel")):
-    tot = d[:, k:k + 8].sum(axis=1)
-    print(kern, "mean cycles per read", round(tot.mean()))
-    for j in range(8):
-        print(f"   {names[j]:32s} {d[:, k + j].mean():10.0f}  {100 * d[:, k + j].mean() / tot.mean():5.1f} %")
+L.pg_debug_read_phase_cycles.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+out = np.zeros(12, dtype=np.uint64)
+assert L.pg_debug_read_phase_cycles(eng._h, db, out.ctypes.data, 12) == 0
+names = ["record, bases, planes, first window", "close 1st attempt: fill + filter + queue", "close 1st attempt: candidate pass",
+         "close 1st attempt: evaluate + emit", "close retries: fill + filter + queue", "close retries: candidate passes",
+         "close retries: evaluate + emit", "far: fill + filter + queue", "far: candidate pass(es)",
+         "far: tier B folds + evaluations + emits", "output record", "claim + record load"]
+tot = float(out.sum())
+for nm, v in zip(names, out):
+    print(f"{nm:46s} {float(v) / n:9.0f} cycles/read  {100.0 * float(v) / tot:5.1f} %")
+print("total", round(tot / n), "cycles per read and wave; kernel ms", round(eng.last_stats()[0], 2))
