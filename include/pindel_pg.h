@@ -40,7 +40,6 @@ extern "C" {
 
 #define PG_ABI_VERSION 1
 #define PG_MAX_READ_LEN 499      /* g_maxMismatch has 500 entries (pindel.cpp:801) */
-#define PG_MAX_BD_WINDOWS 127    /* windows per BreakDancer cluster handled on device */
 
 typedef enum {
     PG_OK = 0,

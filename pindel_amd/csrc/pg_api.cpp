@@ -167,6 +167,7 @@ struct pg_device_batch {
     uint32_t max_len = 0, levels = 0;
     int32_t max_isz = 0;
     int64_t max_bd_window = 0;         // largest BreakDancer window attached (positions)
+    uint64_t max_bd_cluster = 0;       // most windows attached to one read
     uint8_t *seq = nullptr;
     uint64_t *seq_off = nullptr;
     uint8_t *strand = nullptr;
@@ -320,7 +321,7 @@ PgDevParams dev_params(const pg_ctx *ctx)
     p.min_close = ctx->prm.min_close;
     p.spacer = ctx->prm.spacer;
     // breakpoints of the (monotone, checked in pg_create) g_maxMismatch table
-    for (int k = 0; k < 16; k++) {
+    for (int k = 0; k < (int)PG_MM_BREAKS; k++) {
         p.mm_bp[k] = 0xffffffffu;
         for (unsigned L = 0; L < 500; L++)
             if (ctx->mm[L] >= (unsigned)(k + 1)) {
@@ -378,7 +379,7 @@ int validate_and_measure(pg_ctx *ctx, const pg_read_batch *reads, uint32_t *max_
     uint32_t lv = ctx->mm[ml] + (uint32_t)ctx->prm.additional_mismatch + 1;
     for (uint32_t l = 0; l <= ml; l++)
         lv = std::max<uint32_t>(lv, ctx->mm[l] + (uint32_t)ctx->prm.additional_mismatch + 1);
-    if (lv > PG_MAX_LEVELS) return fail(ctx, PG_E_UNSUPPORTED, "more than 16 mismatch levels");
+    if (lv > PG_MAX_LEVELS) return fail(ctx, PG_E_UNSUPPORTED, "more than 32 mismatch levels");
     *levels = lv;
     return PG_OK;
 }
@@ -560,7 +561,7 @@ bool small_ids(const pg_ctx *ctx, const pg_device_batch *b)
     // 32-bit candidate ids when every window of this launch has <= 2^24 positions: ranges 128 * 4^x
     // (x <= 8), close windows 3 * InsertSize (a short), BreakDancer windows as attached
     return ctx->prm.max_range_index <= 8 && (long long)b->max_bd_window <= PG_SMALL_MAX_WINDOW &&
-           !getenv("PG_FORCE_WIDE_CELLS");
+           b->max_bd_cluster <= PG_SMALL_MAX_CLUSTER && !getenv("PG_FORCE_WIDE_CELLS");
 }
 
 // Launches the search for reads [lo, lo + cnt) of the batch on the ctx stream.
@@ -1337,34 +1338,67 @@ int pg_search_batch_multi(pg_ctx *const *ctxs, int32_t n_ctx, const pg_read_batc
     return rc;
 }
 
-// Validates per-read window clusters and uploads them to the batch (replacing earlier ones).
+// Validates per-read window clusters and uploads them to the batch (replacing earlier ones).  Nothing the reference
+// accepts is refused: BDData::getCorrespondingSearchWindowCluster (src/bddata.cpp:949-979) has no cap on the windows of
+// a cluster -- clusters of more than 127 windows switch the launch to 64-bit candidate ids (29 bits of window index) --
+// and a window of 2^26 positions or more (the width of the position field) is searched as consecutive pieces: the
+// reduction over candidates is additive over disjoint position sets.
 static int attach_windows(pg_ctx *ctx, pg_device_batch *b, const pg_windows *bd_hints)
 {
     const size_t n = b->n;
     if (b->bd_off) { (void)hipFree(b->bd_off); b->bd_off = nullptr; }
     if (b->bd) { (void)hipFree(b->bd); b->bd = nullptr; }
     b->max_bd_window = 0;
+    b->max_bd_cluster = 0;
     if (!(bd_hints && bd_hints->offset && n)) return n ? pack_reads(ctx, b, 0, b->n) : PG_OK;
     const uint64_t nw = bd_hints->offset[n];
-    for (size_t i = 0; i < n; i++) {
-        if (bd_hints->offset[i + 1] < bd_hints->offset[i] ||
-            bd_hints->offset[i + 1] - bd_hints->offset[i] > PG_MAX_BD_WINDOWS)
-            return fail(ctx, PG_E_UNSUPPORTED, "more than 127 windows in a BreakDancer cluster");
-    }
+    const long long piece = (1ll << PG_REL_BITS) - 1;
+    bool split = false;
+    for (size_t i = 0; i < n; i++)
+        if (bd_hints->offset[i + 1] < bd_hints->offset[i]) return fail(ctx, PG_E_INVALID, "window offsets not monotone");
+    if (nw && !bd_hints->windows) return fail(ctx, PG_E_INVALID, "null window array");
     for (uint64_t k = 0; k < nw; k++) {
         const pg_window &w = bd_hints->windows[k];
         if (w.chr_id < 0 || w.chr_id >= (int)ctx->names.size())
             return fail(ctx, PG_E_INVALID, "BreakDancer window on unknown chromosome");
-        long long st = w.start < 0 ? (long long)w.end - 1 : w.start;
-        if ((long long)w.end - st >= (1ll << PG_REL_BITS))
-            return fail(ctx, PG_E_UNSUPPORTED, "BreakDancer window larger than 2^26 bases");
-        b->max_bd_window = std::max<int64_t>(b->max_bd_window, (long long)w.end - st);
+        const long long st = w.start < 0 ? (long long)w.end - 1 : w.start;
+        if ((long long)w.end - st > piece) split = true;
+    }
+    const uint64_t *off = bd_hints->offset;
+    const pg_window *win = bd_hints->windows;
+    std::vector<uint64_t> off2;
+    std::vector<pg_window> win2;
+    if (split) {
+        off2.reserve(n + 1);
+        off2.push_back(0);
+        for (size_t i = 0; i < n; i++) {
+            for (uint64_t k = bd_hints->offset[i]; k < bd_hints->offset[i + 1]; k++) {
+                const pg_window &w = bd_hints->windows[k];
+                const long long st = w.start < 0 ? (long long)w.end - 1 : w.start;       // farend_searcher.cpp:69-71
+                if ((long long)w.end - st <= piece) {
+                    win2.push_back(w);
+                    continue;
+                }
+                for (long long s0 = st; s0 < (long long)w.end; s0 += piece) {
+                    pg_window p = { w.chr_id, (int32_t)s0, (int32_t)std::min<long long>(s0 + piece, w.end) };
+                    win2.push_back(p);
+                }
+            }
+            off2.push_back(win2.size());
+        }
+        off = off2.data();
+        win = win2.data();
+    }
+    const uint64_t nw2 = off[n];
+    if (nw2 > 0xffffffffull) return fail(ctx, PG_E_UNSUPPORTED, "more than 2^32 BreakDancer windows in a batch");
+    for (size_t i = 0; i < n; i++) b->max_bd_cluster = std::max<uint64_t>(b->max_bd_cluster, off[i + 1] - off[i]);
+    if (b->max_bd_cluster >= (1ull << 29)) return fail(ctx, PG_E_UNSUPPORTED, "more than 2^29 windows in a BreakDancer cluster");
+    for (uint64_t k = 0; k < nw2; k++) {
+        const long long st = win[k].start < 0 ? (long long)win[k].end - 1 : win[k].start;
+        b->max_bd_window = std::max<int64_t>(b->max_bd_window, (long long)win[k].end - st);
     }
     int rc;
-    if (nw > 0xffffffffull) return fail(ctx, PG_E_UNSUPPORTED, "more than 2^32 BreakDancer windows in a batch");
-    if ((rc = dev_upload(ctx, &b->bd_off, bd_hints->offset, n + 1)) ||
-        (rc = dev_upload(ctx, &b->bd, bd_hints->windows, (size_t)nw)))
-        return rc;
+    if ((rc = dev_upload(ctx, &b->bd_off, off, n + 1)) || (rc = dev_upload(ctx, &b->bd, win, (size_t)nw2))) return rc;
     return pack_reads(ctx, b, 0, b->n);
 }
 

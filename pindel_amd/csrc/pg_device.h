@@ -22,6 +22,7 @@ struct PgDevRef {
     int32_t n_chr;
 };
 
+#define PG_MM_BREAKS_N 32
 struct PgDevParams {
     int32_t max_range_index;
     int32_t add_mm;          // ADDITIONAL_MISMATCH
@@ -29,7 +30,7 @@ struct PgDevParams {
     int32_t min_close;       // g_MinClose
     uint32_t spacer;
     // g_maxMismatch as breakpoints (the table is monotone): mm(L) = #{k : L >= mm_bp[k]}
-    uint32_t mm_bp[16];
+    uint32_t mm_bp[PG_MM_BREAKS_N];
 };
 
 enum PgMode { PG_MODE_CLOSE = 1, PG_MODE_FAR = 2, PG_MODE_BOTH = 3 };
@@ -101,8 +102,9 @@ struct PgSoaOut {
 #define PG_REL_BITS 26
 #define PG_REL_BITS_SMALL 24
 #define PG_SMALL_MAX_WINDOW (1 << 24)
-#define PG_MAX_LEVELS 16
-#define PG_MM_BREAKS 16
+#define PG_SMALL_MAX_CLUSTER 127u   // windows per read the 32-bit ids can tell apart
+#define PG_MAX_LEVELS 32
+#define PG_MM_BREAKS 32
 #define PG_POOL_SHARDS 1024u
 #define PG_WORK_CTRS 8u           // per-XCD read counters of the persistent launch, 64 bytes apart
 #define PG_DIAG_WORDS 64u         // behind the read counters: cycle accumulators of a -DPG_TIMING diagnostics build

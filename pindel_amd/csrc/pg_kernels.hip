@@ -135,8 +135,9 @@ __device__ __forceinline__ u32 med3(u32 a, u32 b, u32 c)
 }
 
 // Candidate ids: position relative to the search's origin, kind (F/B) and window index (BreakDancer cluster).
-//   32-bit: rel(24) | kind << 24 | region << 25   -- every window of the launch has <= 2^24 positions
-//   64-bit: rel(26) | kind << 26 | region << 27   -- anything the ABI accepts
+//   32-bit: rel(24) | kind << 24 | region << 25   -- every window of the launch has <= 2^24 positions, clusters <= 127 windows
+//   64-bit: rel(26) | kind << 26 | region << 27   -- anything the ABI accepts (56 bits are kept: clusters of up to 2^29
+//                                                    windows; windows of 2^26 positions or more are split by the host)
 template <typename Id> struct IdFmt;
 template <> struct IdFmt<u32> { static constexpr int RB = PG_REL_BITS_SMALL; };
 template <> struct IdFmt<u64> { static constexpr int RB = PG_REL_BITS; };
@@ -433,8 +434,8 @@ __device__ __forceinline__ void fold_tier_b(const Search &S, const Query<NB> &Q,
                 if (b + 1 >= r) bad |= (m ^ QN[b]) & BP[b];        // L - m >= 64 r - 64 (m <= 64 <= 64 + bps)
             }
             u32 okc = bad == 0ull ? (h.y >> 31) : 0u;
-            if (S.len_check) okc = (u32)L >= ((h.y >> 8) & 0x7fu) ? okc : 0u;   // uniform branch
-            const Id cid = sizeof(Id) == 8 ? (Id)((u64)h.x | ((u64)(h.y & 0xffu) << 32)) : (Id)h.x;
+            if (S.len_check) okc = (u32)L >= ((h.y >> 24) & 0x7fu) ? okc : 0u;   // uniform branch
+            const Id cid = sizeof(Id) == 8 ? (Id)((u64)h.x | ((u64)(h.y & 0xffffffu) << 32)) : (Id)h.x;
             fold<Id>(m1, m2, wid, ok, k, cid, okc);
         }
         if (r == 0) { A.m1 = m1; A.m2 = m2; A.ok = ok; A.id = wid; }
@@ -505,7 +506,7 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
     if (S.tierA) lng = valid && kA < S.T;
     const Id id = make_id<Id>((u32)(p - origin), isB, region);
     const u32 lenthr = (u32)(S.min_perfect + (isB ? 0 : 1));           // FORWARD: L > m, BACKWARD: L >= m
-    const u32 meta = (u32)((u64)id >> 32) | (lenthr << 8) | hamok;
+    const u32 meta = (u32)((u64)id >> 32) | (lenthr << 24) | hamok;     // id bits 32..55 | CheckMismatches' length bound | Hamming verdict
     const bool sht = valid && !lng;
     const u64 shortm = ballot64(sht);
     u64 longm[NB];
@@ -573,7 +574,7 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
             u32 k = (u32)__popc(e.x & mk);
             k = idx < qe ? k : PG_BIG;
             const u32 okc = (e.y & bpm) == 0u ? (e.w >> 31) : 0u;    // (no "L > m" test: tier A is off when it can fail)
-            const Id cid = sizeof(Id) == 8 ? (Id)((u64)e.z | ((u64)(e.w & 0xffu) << 32)) : (Id)e.z;
+            const Id cid = sizeof(Id) == 8 ? (Id)((u64)e.z | ((u64)(e.w & 0xffffffu) << 32)) : (Id)e.z;
             fold<Id>(A.a1, A.a2, A.aid, A.aok, k, cid, okc);
         }
     }
@@ -628,21 +629,22 @@ __device__ __forceinline__ int seed_depth(int len, int T, bool wide)
     return J > jt ? jt : J;
 }
 
-// positions whose bit-sliced mismatch count (c3 c2 c1 c0, ov = overflowed) is <= thr (wave-uniform)
-__device__ __forceinline__ u32 count_le(u32 c0, u32 c1, u32 c2, u32 c3, u32 ov, int thr)
+// positions whose bit-sliced mismatch count (c[NS-1] .. c0, ov = overflowed) is <= thr (wave-uniform)
+template <int NS>
+__device__ __forceinline__ u32 count_le(const u32 *c, u32 ov, int thr)
 {
-    const u32 c[4] = { c0, c1, c2, c3 };
     u32 eq = ~ov, lt = 0u;
 #pragma unroll
-    for (int i = 3; i >= 0; i--) {
+    for (int i = NS - 1; i >= 0; i--) {
         const u32 ti = ((thr >> i) & 1) ? ~0u : 0u;
         lt |= eq & ~c[i] & ti;
         eq &= ~(c[i] ^ ti);
     }
-    return thr >= 15 ? ~ov : (lt | eq);
+    return thr >= (1 << NS) - 1 ? ~ov : (lt | eq);
 }
 
-// Bit-sliced mismatch counter of the seed filter: NS slices + a sticky overflow bit per position.  Bases are
+// Bit-sliced mismatch counter of the seed filter: NS slices (3: up to 8 levels, 4: up to 16, 5: up to 32) + a sticky
+// overflow bit per position.  Bases are
 // added one, two or three at a time (carry-save: the sum bits of two or three match masks first, then one
 // ripple through the slices -- 7, 4.5 and 3.7 VALU instructions per base).  Each add is ONE asm statement that
 // also takes the base(s) off the wave-uniform set (s_ff1 / s_bitset0) and shifts the planes (v_alignbit):
@@ -667,16 +669,21 @@ __device__ __forceinline__ u32 count_le(u32 c0, u32 c1, u32 c2, u32 c3, u32 ov, 
 #define PG_UP3 "v_and_or_b32 %[ov], %[c2], %[k1], %[ov]\n\tv_xor_b32 %[c2], %[c2], %[k1]"
 #define PG_UP4 "v_and_b32 %[k0], %[c2], %[k1]\n\tv_xor_b32 %[c2], %[c2], %[k1]\n\t" \
                "v_and_or_b32 %[ov], %[c3], %[k0], %[ov]\n\tv_xor_b32 %[c3], %[c3], %[k0]"
+#define PG_UP5 "v_and_b32 %[k0], %[c2], %[k1]\n\tv_xor_b32 %[c2], %[c2], %[k1]\n\t" \
+               "v_and_b32 %[k1], %[c3], %[k0]\n\tv_xor_b32 %[c3], %[c3], %[k0]\n\t" \
+               "v_and_or_b32 %[ov], %[c4], %[k1], %[ov]\n\tv_xor_b32 %[c4], %[c4], %[k1]"
 template <int NS>
 struct Counter {
-    u32 c0, c1, c2, c3, ov;
-    __device__ __forceinline__ void reset() { c0 = c1 = c2 = c3 = ov = 0u; }
+    u32 c0, c1, c2, c3, c4, ov;
+    __device__ __forceinline__ void reset() { c0 = c1 = c2 = c3 = c4 = ov = 0u; }
     __device__ __forceinline__ u32 le(int thr) const
     {
-        return thr < 0 ? 0u : count_le(c0, c1, c2, NS == 4 ? c3 : 0u, ov, thr);
+        const u32 c[5] = { c0, c1, c2, c3, c4 };
+        return thr < 0 ? 0u : count_le<NS>(c, ov, thr);
     }
 #define PG_CTR3 [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2), [ov] "+v"(ov)
 #define PG_CTR4 [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2), [c3] "+v"(c3), [ov] "+v"(ov)
+#define PG_CTR5 [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2), [c3] "+v"(c3), [c4] "+v"(c4), [ov] "+v"(ov)
 #define PG_PLANES [lo] "v"(lo), [hi] "v"(hi)
     // --- the lowest base(s) of pm (removed from it), planes shifted by the base's bit: returns the bit(s)
     __device__ __forceinline__ void take1(u32 &pm, u32 lo, u32 hi, u32 &ja)
@@ -685,9 +692,12 @@ struct Counter {
         if (NS == 3)
             asm(PG_TAKE("ja") PG_SHIFT("ma", "ja") PG_ADD1 PG_UP3
                 : PG_CTR3, [pm] "+s"(pm), [ja] "=&s"(ja), [ma] "=&v"(ma), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES);
-        else
+        else if (NS == 4)
             asm(PG_TAKE("ja") PG_SHIFT("ma", "ja") PG_ADD1 PG_UP4
                 : PG_CTR4, [pm] "+s"(pm), [ja] "=&s"(ja), [ma] "=&v"(ma), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES);
+        else
+            asm(PG_TAKE("ja") PG_SHIFT("ma", "ja") PG_ADD1 PG_UP5
+                : PG_CTR5, [pm] "+s"(pm), [ja] "=&s"(ja), [ma] "=&v"(ma), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES);
     }
     __device__ __forceinline__ void take2(u32 &pm, u32 lo, u32 hi, u32 &ja, u32 &jb)
     {
@@ -696,9 +706,13 @@ struct Counter {
             asm(PG_TAKE("ja") PG_TAKE("jb") PG_SHIFT("ma", "ja") PG_SHIFT("mb", "jb") PG_ADD2 PG_UP3
                 : PG_CTR3, [pm] "+s"(pm), [ja] "=&s"(ja), [jb] "=&s"(jb), [ma] "=&v"(ma), [mb] "=&v"(mb), [s0] "=&v"(s0),
                   [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES);
-        else
+        else if (NS == 4)
             asm(PG_TAKE("ja") PG_TAKE("jb") PG_SHIFT("ma", "ja") PG_SHIFT("mb", "jb") PG_ADD2 PG_UP4
                 : PG_CTR4, [pm] "+s"(pm), [ja] "=&s"(ja), [jb] "=&s"(jb), [ma] "=&v"(ma), [mb] "=&v"(mb), [s0] "=&v"(s0),
+                  [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES);
+        else
+            asm(PG_TAKE("ja") PG_TAKE("jb") PG_SHIFT("ma", "ja") PG_SHIFT("mb", "jb") PG_ADD2 PG_UP5
+                : PG_CTR5, [pm] "+s"(pm), [ja] "=&s"(ja), [jb] "=&s"(jb), [ma] "=&v"(ma), [mb] "=&v"(mb), [s0] "=&v"(s0),
                   [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES);
     }
     __device__ __forceinline__ void take3(u32 &pm, u32 lo, u32 hi, u32 &ja, u32 &jb, u32 &jc)
@@ -709,10 +723,15 @@ struct Counter {
                 PG_ADD3 PG_UP3
                 : PG_CTR3, [pm] "+s"(pm), [ja] "=&s"(ja), [jb] "=&s"(jb), [jc] "=&s"(jc), [ma] "=&v"(ma), [mb] "=&v"(mb),
                   [mc] "=&v"(mc), [s0] "=&v"(s0), [s1] "=&v"(s1), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES);
-        else
+        else if (NS == 4)
             asm(PG_TAKE("ja") PG_TAKE("jb") PG_TAKE("jc") PG_SHIFT("ma", "ja") PG_SHIFT("mb", "jb") PG_SHIFT("mc", "jc")
                 PG_ADD3 PG_UP4
                 : PG_CTR4, [pm] "+s"(pm), [ja] "=&s"(ja), [jb] "=&s"(jb), [jc] "=&s"(jc), [ma] "=&v"(ma), [mb] "=&v"(mb),
+                  [mc] "=&v"(mc), [s0] "=&v"(s0), [s1] "=&v"(s1), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES);
+        else
+            asm(PG_TAKE("ja") PG_TAKE("jb") PG_TAKE("jc") PG_SHIFT("ma", "ja") PG_SHIFT("mb", "jb") PG_SHIFT("mc", "jc")
+                PG_ADD3 PG_UP5
+                : PG_CTR5, [pm] "+s"(pm), [ja] "=&s"(ja), [jb] "=&s"(jb), [jc] "=&s"(jc), [ma] "=&v"(ma), [mb] "=&v"(mb),
                   [mc] "=&v"(mc), [s0] "=&v"(s0), [s1] "=&v"(s1), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES);
     }
     // --- the same base(s) for the other kind: planes shifted by 32 - bit
@@ -722,9 +741,12 @@ struct Counter {
         if (NS == 3)
             asm(PG_MIRROR("ta", "ja") PG_SHIFT("ma", "ta") PG_ADD1 PG_UP3
                 : PG_CTR3, [ta] "=&s"(ta), [ma] "=&v"(ma), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES, [ja] "s"(ja) : "scc");
-        else
+        else if (NS == 4)
             asm(PG_MIRROR("ta", "ja") PG_SHIFT("ma", "ta") PG_ADD1 PG_UP4
                 : PG_CTR4, [ta] "=&s"(ta), [ma] "=&v"(ma), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES, [ja] "s"(ja) : "scc");
+        else
+            asm(PG_MIRROR("ta", "ja") PG_SHIFT("ma", "ta") PG_ADD1 PG_UP5
+                : PG_CTR5, [ta] "=&s"(ta), [ma] "=&v"(ma), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES, [ja] "s"(ja) : "scc");
     }
     __device__ __forceinline__ void mirror2(u32 lo, u32 hi, u32 ja, u32 jb)
     {
@@ -733,9 +755,13 @@ struct Counter {
             asm(PG_MIRROR("ta", "ja") PG_MIRROR("tb", "jb") PG_SHIFT("ma", "ta") PG_SHIFT("mb", "tb") PG_ADD2 PG_UP3
                 : PG_CTR3, [ta] "=&s"(ta), [tb] "=&s"(tb), [ma] "=&v"(ma), [mb] "=&v"(mb), [s0] "=&v"(s0), [k0] "=&v"(k0),
                   [k1] "=&v"(k1) : PG_PLANES, [ja] "s"(ja), [jb] "s"(jb) : "scc");
-        else
+        else if (NS == 4)
             asm(PG_MIRROR("ta", "ja") PG_MIRROR("tb", "jb") PG_SHIFT("ma", "ta") PG_SHIFT("mb", "tb") PG_ADD2 PG_UP4
                 : PG_CTR4, [ta] "=&s"(ta), [tb] "=&s"(tb), [ma] "=&v"(ma), [mb] "=&v"(mb), [s0] "=&v"(s0), [k0] "=&v"(k0),
+                  [k1] "=&v"(k1) : PG_PLANES, [ja] "s"(ja), [jb] "s"(jb) : "scc");
+        else
+            asm(PG_MIRROR("ta", "ja") PG_MIRROR("tb", "jb") PG_SHIFT("ma", "ta") PG_SHIFT("mb", "tb") PG_ADD2 PG_UP5
+                : PG_CTR5, [ta] "=&s"(ta), [tb] "=&s"(tb), [ma] "=&v"(ma), [mb] "=&v"(mb), [s0] "=&v"(s0), [k0] "=&v"(k0),
                   [k1] "=&v"(k1) : PG_PLANES, [ja] "s"(ja), [jb] "s"(jb) : "scc");
     }
     __device__ __forceinline__ void mirror3(u32 lo, u32 hi, u32 ja, u32 jb, u32 jc)
@@ -746,10 +772,15 @@ struct Counter {
                 PG_SHIFT("mc", "tc") PG_ADD3 PG_UP3
                 : PG_CTR3, [ta] "=&s"(ta), [tb] "=&s"(tb), [tc] "=&s"(tc), [ma] "=&v"(ma), [mb] "=&v"(mb), [mc] "=&v"(mc),
                   [s0] "=&v"(s0), [s1] "=&v"(s1), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES, [ja] "s"(ja), [jb] "s"(jb), [jc] "s"(jc) : "scc");
-        else
+        else if (NS == 4)
             asm(PG_MIRROR("ta", "ja") PG_MIRROR("tb", "jb") PG_MIRROR("tc", "jc") PG_SHIFT("ma", "ta") PG_SHIFT("mb", "tb")
                 PG_SHIFT("mc", "tc") PG_ADD3 PG_UP4
                 : PG_CTR4, [ta] "=&s"(ta), [tb] "=&s"(tb), [tc] "=&s"(tc), [ma] "=&v"(ma), [mb] "=&v"(mb), [mc] "=&v"(mc),
+                  [s0] "=&v"(s0), [s1] "=&v"(s1), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES, [ja] "s"(ja), [jb] "s"(jb), [jc] "s"(jc) : "scc");
+        else
+            asm(PG_MIRROR("ta", "ja") PG_MIRROR("tb", "jb") PG_MIRROR("tc", "jc") PG_SHIFT("ma", "ta") PG_SHIFT("mb", "tb")
+                PG_SHIFT("mc", "tc") PG_ADD3 PG_UP5
+                : PG_CTR5, [ta] "=&s"(ta), [tb] "=&s"(tb), [tc] "=&s"(tc), [ma] "=&v"(ma), [mb] "=&v"(mb), [mc] "=&v"(mc),
                   [s0] "=&v"(s0), [s1] "=&v"(s1), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES, [ja] "s"(ja), [jb] "s"(jb), [jc] "s"(jc) : "scc");
     }
 };
@@ -868,9 +899,11 @@ __device__ __forceinline__ void seed_filter(const Search &S, const Query<NB> &Q,
     // (lowest level present at L) + ADD for every L in [bps, J] cannot be the lowest there nor within ADD of it
     // (levels only grow with L); later lengths are covered by the "alive after J bases" test
     if (cap0 > S.cap_state) cap0 = S.cap_state;
-    // counts up to 7 decide everything when T <= 8 (cap0 <= T - 1 <= 7): three slices + overflow
+    // counts up to 7 decide everything when T <= 8 (cap0 <= T - 1 <= 7): three slices + overflow; four up to 16 levels,
+    // five up to 32 (-e 0.05 on 300-base reads)
     if (T <= 8) seed_filter_run<NB, 3, DUAL>(S, Q, kindB, lane, J, jb, cap0, mF, mB);
-    else seed_filter_run<NB, 4, DUAL>(S, Q, kindB, lane, J, jb, cap0, mF, mB);
+    else if (T <= 16) seed_filter_run<NB, 4, DUAL>(S, Q, kindB, lane, J, jb, cap0, mF, mB);
+    else seed_filter_run<NB, 5, DUAL>(S, Q, kindB, lane, J, jb, cap0, mF, mB);
 }
 
 // Scan the positions of [s, e) outside [xs, xe) (wo = word index of AbsLoc 0 of the chromosome).

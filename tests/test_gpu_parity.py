@@ -399,23 +399,21 @@ def test_rejections_are_loud(engine_factory, small_ref, tmp_path):
     # unknown chromosome, anchor outside the padded chromosome
     assert code(lambda: eng.search_batch(hostio.batch_from_lists([b"ACGT" * 25], [b"+"], [200000], [500], [3]))) == E_INVALID
     assert code(lambda: eng.search_batch(hostio.batch_from_lists([b"ACGT" * 25], [b"+"], [5_000_000], [500], [0]))) == E_INVALID
-    # more than 16 mismatch levels for the longest read of the batch (-e 0.05 at 300 bp)
-    noisy = engine_factory(seq_error_rate=0.05)
+    # more than 32 mismatch levels for the longest read of the batch (-e 0.08 at 450 bp; up to 32 are searched, see
+    # test_more_than_16_mismatch_levels)
+    noisy = engine_factory(seq_error_rate=0.08)
     noisy.load_reference(small_ref)
-    assert code(lambda: noisy.search_batch(synth.make_reads(small_ref[0][1], 20, seed=23, read_len=300))) == E_UNSUPPORTED
+    assert code(lambda: noisy.search_batch(synth.make_reads(small_ref[0][1], 20, seed=23, read_len=450))) == E_UNSUPPORTED
     noisy.search_batch(synth.make_reads(small_ref[0][1], 20, seed=23, read_len=100)).free()
-    # BreakDancer clusters: more than 127 windows, a window of 2^26 bases, an unknown chromosome
+    # BreakDancer windows: an unknown chromosome, offsets that go backwards
     db = eng.upload(batch)
     off = np.zeros(batch.n + 1, dtype=np.uint64)
-    off[1:] = 128
-    win = np.zeros(128, dtype=binding.WINDOW_DTYPE)
-    win["start"], win["end"] = 100000, 100100
-    assert code(lambda: eng.set_windows(db, win, off)) == E_UNSUPPORTED
     off[1:] = 1
     big = np.zeros(1, dtype=binding.WINDOW_DTYPE)
-    big["start"], big["end"] = 0, 1 << 26
-    assert code(lambda: eng.set_windows(db, big, off)) == E_UNSUPPORTED
-    big["end"], big["chr_id"] = 1000, 7
+    big["start"], big["end"], big["chr_id"] = 0, 1000, 7
+    assert code(lambda: eng.set_windows(db, big, off)) == E_INVALID
+    off[3] = 0
+    big["chr_id"] = 0
     assert code(lambda: eng.set_windows(db, big, off)) == E_INVALID
     eng.free_device_batch(db)
     # a chromosome of 2^31 bases or more: refused before a single base is read (positions are signed 32-bit)
@@ -497,3 +495,72 @@ def test_far_end_seam_on_the_filtered_union_of_flushes(engine_factory, small_ref
     cnt = points_per_read(half.far_off, half.far_runs)
     assert not cnt[::2].any()
     np.testing.assert_array_equal(cnt[1::2], orc["far_cnt"][kept_idx][1::2])
+
+
+def test_more_than_127_windows_in_a_cluster(engine_factory):
+    """BDData::getCorrespondingSearchWindowCluster has no cap on the windows of a cluster (src/bddata.cpp:949-979): 300
+    windows per read, on two chromosomes, some with Start < 0 -- searched with 64-bit candidate ids -- == the oracle."""
+    from pindel_amd import binding
+    ref = [("chrA", synth.make_reference(700_000, seed=41)), ("chrB", synth.make_reference(500_000, seed=42))]
+    eng = engine_factory()
+    eng.load_reference(ref)
+    batch = synth.make_reads(ref[0][1], 600, seed=43)
+    rng = np.random.default_rng(44)
+    per = 300
+    bd = np.zeros(batch.n * per, dtype=binding.WINDOW_DTYPE)
+    bd["chr_id"] = rng.integers(0, 2, len(bd))
+    size = np.where(bd["chr_id"] == 0, 700_000, 500_000)
+    st = rng.integers(100_000, size - 100_400)
+    bd["start"] = st
+    bd["end"] = st + rng.integers(50, 400, len(bd))
+    # every read's own far-end neighbourhood is among its windows, so that the clusters do find far ends
+    ap = batch.anchor_pos.astype(np.int64) + 100_000
+    bd["chr_id"][::per] = 0
+    bd["start"][::per] = np.clip(ap - 3000, 100_000, 590_000)
+    bd["end"][::per] = bd["start"][::per] + 6000
+    neg = rng.random(len(bd)) < 0.02
+    bd["start"][neg] = -1                                   # Start < 0: the window is End - 1 (farend_searcher.cpp:69-71)
+    bd_off = (np.arange(batch.n + 1) * per).astype(np.uint64)
+    orc = run_oracle({}, ref, batch, bd=bd, bd_off=bd_off)
+    close = eng.close_end_batch(batch)
+    both = eng.far_end_batch(batch, close, bd, bd_off)
+    compare_result(both, orc, batch.n)
+    assert (orc["far_cnt"] > 0).sum() > 200
+    # far-end points that lie in windows with an index beyond 127
+    far = binding.expand_runs(both.far_runs)
+    assert len(far) > 1000
+
+
+def test_window_of_more_than_2_26_positions(engine_factory):
+    """A search window wider than the 26-bit position field of a candidate id is searched as consecutive pieces (the
+    reduction is additive over disjoint position sets): same points as the oracle on the whole window."""
+    from pindel_amd import binding
+    n_bases = (1 << 26) + 700_000
+    ref = [("chrW", synth.make_reference(n_bases, seed=51))]
+    eng = engine_factory()
+    eng.load_reference(ref)
+    batch = synth.make_reads(ref[0][1], 6, seed=52)
+    bd = np.zeros(batch.n, dtype=binding.WINDOW_DTYPE)
+    bd["start"] = 100_000 + 1000
+    bd["end"] = 100_000 + 1000 + (1 << 26) + 5000
+    bd_off = np.arange(batch.n + 1).astype(np.uint64)
+    orc = run_oracle({}, ref, batch, bd=bd, bd_off=bd_off)
+    close = eng.close_end_batch(batch)
+    both = eng.far_end_batch(batch, close, bd, bd_off)
+    compare_result(both, orc, batch.n)
+    assert (orc["close_cnt"] > 0).sum() >= 3
+
+
+def test_more_than_16_mismatch_levels(engine_factory, small_ref):
+    """-e 0.05 on 300-base reads: g_maxMismatch[300] + ADDITIONAL_MISMATCH + 1 > 16 levels (the five-slice counter of the
+    seed filter); the reference has no such limit below 500-base reads."""
+    from oracle import pyoracle
+    kw = dict(seq_error_rate=0.05)
+    eng = engine_factory(**kw)
+    eng.load_reference(small_ref)
+    assert int(eng.max_mismatch_table()[300]) + 2 > 16
+    batch = synth.make_reads(small_ref[0][1], 1200, seed=61, read_lens=[300, 250, 120], error_rate=0.04)
+    gpu = eng.search_batch(batch)
+    orc = run_oracle(kw, small_ref, batch)
+    assert (orc["close_cnt"] > 0).sum() > 400 and (orc["far_cnt"] > 0).sum() > 200
+    compare_result(gpu, orc, batch.n)
