@@ -118,6 +118,28 @@ struct HostBuf {
     }
 };
 
+// A plain host array that is NOT zero-filled on allocation (std::vector::resize writes every element first: 3 ms for the
+// 32 MB of offsets of a 4 M-read batch)
+template <typename T>
+struct PodVec {
+    T *p = nullptr;
+    size_t n = 0;
+    PodVec() {}
+    PodVec(const PodVec &) = delete;
+    PodVec &operator=(const PodVec &) = delete;
+    ~PodVec() { free(p); }
+    void resize(size_t k)
+    {
+        free(p);
+        p = (T *)malloc(std::max<size_t>(k, 1) * sizeof(T));
+        n = p ? k : 0;
+    }
+    T *data() { return p; }
+    const T *data() const { return p; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+};
+
 // Grow-only device arena of a ctx: the buffers of a host-path batch (pg_search_batch & co) are carved out of
 // it instead of ~25 hipMalloc / hipFree per call.
 struct DevArena {
@@ -146,6 +168,9 @@ struct pg_ctx {
     uint16_t *d_thr = nullptr;
     uint32_t *d_mm = nullptr;
     hipStream_t stream = nullptr, copy_stream = nullptr;   // kernels / host-to-device input copies
+    hipStream_t dl_stream = nullptr;                       // device-to-host result copies of the chunked host path
+    hipStream_t stream2 = nullptr;                         // second kernel stream of the chunked host path (odd chunks)
+    std::vector<hipEvent_t> events;                        // reused by the chunked host path (no timing)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // reference
     std::vector<std::string> names;
@@ -350,7 +375,23 @@ void free_batch_buffers(pg_device_batch *b)
         if (p) (void)hipFree(p);
 }
 
-int validate_and_measure(pg_ctx *ctx, const pg_read_batch *reads, uint32_t *max_len, uint32_t *levels)
+// fn(lo, hi) over [0, n) in contiguous ranges on a few host threads (one for small n)
+template <class Fn>
+void host_ranges(size_t n, Fn fn)
+{
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned nt = (unsigned)std::min<size_t>(std::min(hw, 16u), n >> 16);
+    if (nt <= 1) {
+        fn((size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++) th.emplace_back(fn, n * t / nt, n * (t + 1) / nt);
+    for (std::thread &x : th) x.join();
+}
+
+// max_isz (nullable): largest insert size of the batch
+int validate_and_measure(pg_ctx *ctx, const pg_read_batch *reads, uint32_t *max_len, uint32_t *levels, int32_t *max_isz = nullptr)
 {
     if (!reads || (reads->n_reads && (!reads->seq_off || !reads->anchor_strand || !reads->anchor_pos ||
                                       !reads->insert_size || !reads->chr_id)))
@@ -358,24 +399,55 @@ int validate_and_measure(pg_ctx *ctx, const pg_read_batch *reads, uint32_t *max_
     if (reads->n_reads && !reads->seq && reads->seq_off[reads->n_reads] > reads->seq_off[0])
         return fail(ctx, PG_E_INVALID, "null seq in pg_read_batch");
     if (ctx->names.empty()) return fail(ctx, PG_E_NO_REFERENCE, "no reference loaded");
-    uint32_t ml = 1;
     const int n_chr = (int)ctx->names.size();
-    for (uint32_t i = 0; i < reads->n_reads; i++) {
-        if (reads->seq_off[i + 1] < reads->seq_off[i])
-            return fail(ctx, PG_E_INVALID, "seq_off not monotone");
-        uint64_t len = reads->seq_off[i + 1] - reads->seq_off[i];
-        if (len > PG_MAX_READ_LEN) return fail(ctx, PG_E_READ_TOO_LONG, "read longer than 499 bases");
-        ml = std::max<uint32_t>(ml, (uint32_t)len);
-        int c = reads->chr_id[i];
-        if (c < 0 || c >= n_chr) return fail(ctx, PG_E_INVALID, "chr_id out of range");
-        // the close-end windows (pindel.cpp:2272-2274, 2301-2302) must lie inside the padded string
-        long long apos = (long long)reads->anchor_pos[i] + ctx->prm.spacer;
-        long long isz = reads->insert_size[i];
-        long long lo = apos - 2 * std::max<long long>(isz, 0) - 2, hi = apos + 2 * std::max<long long>(isz, 0) + 2;
-        if (lo < 0 || hi > (long long)ctx->comp_size[c])
-            return fail(ctx, PG_E_INVALID, "anchor position/insert size reach outside the padded chromosome");
+    // per range: first problem found (0 = none; the lowest code wins, as in a sequential scan the first one would), longest read
+    struct Part { int code = 0; uint32_t ml = 1; int32_t isz = 0; };
+    std::mutex mu;
+    Part all;
+    size_t first_bad = (size_t)-1;
+    host_ranges(reads->n_reads, [&](size_t lo, size_t hi) {
+        Part p;
+        size_t bad = (size_t)-1;
+        for (size_t i = lo; i < hi; i++) {
+            int code = 0;
+            if (reads->seq_off[i + 1] < reads->seq_off[i]) code = 1;
+            const uint64_t len = reads->seq_off[i + 1] - reads->seq_off[i];
+            if (!code && len > PG_MAX_READ_LEN) code = 2;
+            const int c = reads->chr_id[i];
+            if (!code && (c < 0 || c >= n_chr)) code = 3;
+            if (!code) {
+                // the close-end windows (pindel.cpp:2272-2274, 2301-2302) must lie inside the padded string
+                const long long apos = (long long)reads->anchor_pos[i] + ctx->prm.spacer;
+                const long long isz = reads->insert_size[i];
+                const long long wlo = apos - 2 * std::max<long long>(isz, 0) - 2, whi = apos + 2 * std::max<long long>(isz, 0) + 2;
+                if (wlo < 0 || whi > (long long)ctx->comp_size[c]) code = 4;
+            }
+            if (code) {
+                p.code = code;
+                bad = i;
+                break;
+            }
+            p.ml = std::max<uint32_t>(p.ml, (uint32_t)len);
+            p.isz = std::max<int32_t>(p.isz, reads->insert_size[i]);
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        all.ml = std::max(all.ml, p.ml);
+        all.isz = std::max(all.isz, p.isz);
+        if (p.code && bad < first_bad) {
+            first_bad = bad;
+            all.code = p.code;
+        }
+    });
+    switch (all.code) {
+    case 1: return fail(ctx, PG_E_INVALID, "seq_off not monotone");
+    case 2: return fail(ctx, PG_E_READ_TOO_LONG, "read longer than 499 bases");
+    case 3: return fail(ctx, PG_E_INVALID, "chr_id out of range");
+    case 4: return fail(ctx, PG_E_INVALID, "anchor position/insert size reach outside the padded chromosome");
+    default: break;
     }
+    const uint32_t ml = all.ml;
     *max_len = ml;
+    if (max_isz) *max_isz = all.isz;
     uint32_t lv = ctx->mm[ml] + (uint32_t)ctx->prm.additional_mismatch + 1;
     for (uint32_t l = 0; l <= ml; l++)
         lv = std::max<uint32_t>(lv, ctx->mm[l] + (uint32_t)ctx->prm.additional_mismatch + 1);
@@ -384,25 +456,35 @@ int validate_and_measure(pg_ctx *ctx, const pg_read_batch *reads, uint32_t *max_
     return PG_OK;
 }
 
+// Runs per list the chunked delivery of search_host has room for (1.04 per read on average; a batch that needs more
+// falls back to the whole-batch download).
+static size_t deliver_cap(size_t n) { return 3 * n + 1024; }
+
 // Validates the batch and allocates its device buffers.  copy = true also copies the inputs
 // (synchronously); otherwise the caller streams them in (search_host).  off = read offsets rebased to 0.
 // use_arena: carve the buffers out of the ctx arena (host-path calls: the batch dies with the call).
-int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, std::vector<uint64_t> &off, pg_device_batch **out,
+int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, PodVec<uint64_t> &off, pg_device_batch **out,
                 bool use_arena = false)
 {
     uint32_t max_len = 0, levels = 0;
-    int rc = validate_and_measure(ctx, reads, &max_len, &levels);
+    int32_t max_isz = 0;
+    int rc = validate_and_measure(ctx, reads, &max_len, &levels, &max_isz);
     if (rc) return rc;
     pg_device_batch *b = new pg_device_batch();
     b->n = reads->n_reads;
     b->max_len = max_len;
     b->levels = levels;
-    for (uint32_t i = 0; i < reads->n_reads; i++) b->max_isz = std::max<int32_t>(b->max_isz, reads->insert_size[i]);
+    b->max_isz = max_isz;
     const size_t n = b->n;
     const uint64_t base0 = n ? reads->seq_off[0] : 0;
     const uint64_t nseq = n ? reads->seq_off[n] - base0 : 0;
     off.resize(n + 1);
-    for (size_t i = 0; i <= n; i++) off[i] = (n ? reads->seq_off[i] : 0) - base0;
+    if (!off.data()) {
+        delete b;
+        return fail(ctx, PG_E_NOMEM, "host memory for the read offsets");
+    }
+    if (n) host_ranges(n + 1, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) off[i] = reads->seq_off[i] - base0; });
+    else off[0] = 0;
     // every read reserves PG_RESERVE slots (one atomic per claim of reads); lists longer than their share allocate more
     b->pool_shard_cap = (uint32_t)std::min<uint64_t>(((PG_RESERVE + 2ull) * n) / PG_POOL_SHARDS + 512ull, 0x7fffffffull / PG_POOL_SHARDS);
     if (getenv("PG_TEST_TINY_POOL")) b->pool_shard_cap = 1;      // tests: force the overflow/regrow path
@@ -419,7 +501,7 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, std::vector<
         { (void **)&b->close_off, n1 * 4 }, { (void **)&b->close_cnt, (n + 1) * 4 },   // + 1: the CSR scan runs over n + 1 counts
         { (void **)&b->far_off, n1 * 4 }, { (void **)&b->far_cnt, (n + 1) * 4 }, { (void **)&b->alg, n1 * 4 },
         { (void **)&b->out_rec, n1 * sizeof(PgOutRec) },
-        { (void **)&b->pool_used, (PG_POOL_SHARDS * 16 + PG_WORK_CTRS * 16 + PG_DIAG_WORDS * 2) * 4 },  // run-pool cursors + the launch's read counters
+        { (void **)&b->pool_used, (PG_POOL_SHARDS * 16 + 2 * PG_WORK_CTRS * 16 + PG_DIAG_WORDS * 2) * 4 },   // + a second set of read counters  // run-pool cursors + the launch's read counters
     };
     const size_t n_items = sizeof items / sizeof items[0], first_zero = 8;
     auto drop = [&](int code) {
@@ -433,6 +515,9 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, std::vector<
         // room for the download's temporaries too: CSR offsets, gathered runs, scan scratch
         need += 2 * (((n + 1) * 4 + 511) & ~(size_t)255) + (size_t)b->pool_shard_cap * PG_POOL_SHARDS * sizeof(pg_run) +
                 pg_scan_tmp_bytes((uint32_t)n) + 4096;
+        // ... and for the chunk-by-chunk delivery of search_host: gathered runs (2 lists), 64-bit offsets (2 lists), scratch
+        need += 2 * (deliver_cap(n) * sizeof(pg_run) + 512) + 2 * ((n + 1) * 8 + 512) + PG_DELIVER_CHUNK * 8 + 1024 * 8 +
+                (n / PG_DELIVER_CHUNK + 2) * 32 + 8192;
         if (need > ctx->arena.cap) {
             if (ctx->arena.base) (void)hipFree(ctx->arena.base);
             ctx->arena.base = nullptr;
@@ -507,10 +592,10 @@ PgSoaOut soa_out(const pg_device_batch *b)
 }
 
 // Builds the packed records of reads [lo, lo + cnt) from the SoA inputs (on the ctx stream).
-int pack_reads(pg_ctx *ctx, pg_device_batch *b, uint32_t lo, uint32_t cnt)
+int pack_reads(pg_ctx *ctx, pg_device_batch *b, uint32_t lo, uint32_t cnt, hipStream_t st = nullptr)
 {
     const PgSoaIn a = soa_in(ctx, b);
-    int rc = pg_pack_reads(&a, b->in_rec, lo, cnt, ctx->stream);
+    int rc = pg_pack_reads(&a, b->in_rec, lo, cnt, st ? st : ctx->stream);
     if (rc) return fail(ctx, PG_E_DEVICE, std::string("pack kernel: ") + hipGetErrorString((hipError_t)rc));
     return PG_OK;
 }
@@ -529,7 +614,7 @@ int unpack_results(pg_ctx *ctx, pg_device_batch *b)
 
 int upload_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_device_batch **out)
 {
-    std::vector<uint64_t> off;
+    PodVec<uint64_t> off;
     int rc = alloc_batch(ctx, reads, true, off, out);
     if (rc) return rc;
     if ((rc = pack_reads(ctx, *out, 0, (*out)->n))) {
@@ -565,16 +650,23 @@ bool small_ids(const pg_ctx *ctx, const pg_device_batch *b)
 }
 
 // Launches the search for reads [lo, lo + cnt) of the batch on the ctx stream.
-int launch_range(pg_ctx *ctx, pg_device_batch *b, int mode, uint32_t lo, uint32_t cnt)
+// st / set: the stream to launch on and the set of read counters to use (launches that may overlap need their own)
+int launch_range(pg_ctx *ctx, pg_device_batch *b, int mode, uint32_t lo, uint32_t cnt, hipStream_t st = nullptr, int set = 0)
 {
     PgDevRef ref = dev_ref(ctx);
     PgDevParams prm = dev_params(ctx);
     PgDevBatch d = dev_batch(b);
     d.first_read = lo;
     d.n_reads = cnt;
-    // the persistent launch claims its reads from these counters
-    HIP_TRY(ctx, hipMemsetAsync(d.work_ctr, 0, (PG_WORK_CTRS * 16 + PG_DIAG_WORDS * 2) * sizeof(uint32_t), ctx->stream));
-    int lrc = pg_launch_search(&ref, &prm, &d, mode, b->max_len, b->levels, small_ids(ctx, b) ? 1 : 0, ctx->stream);
+    if (!st) st = ctx->stream;
+    // the persistent launch claims its reads from these counters (set 1 lies behind set 0 and the diagnostics words)
+    size_t bytes = (PG_WORK_CTRS * 16 + PG_DIAG_WORDS * 2) * sizeof(uint32_t);
+    if (set) {
+        d.work_ctr += PG_WORK_CTRS * 16 + PG_DIAG_WORDS * 2;
+        bytes = PG_WORK_CTRS * 16 * sizeof(uint32_t);
+    }
+    HIP_TRY(ctx, hipMemsetAsync(d.work_ctr, 0, bytes, st));
+    int lrc = pg_launch_search(&ref, &prm, &d, mode, b->max_len, b->levels, small_ids(ctx, b) ? 1 : 0, st);
     if (lrc != 0) return fail(ctx, PG_E_DEVICE, std::string("kernel launch: ") + hipGetErrorString((hipError_t)lrc));
     return PG_OK;
 }
@@ -810,6 +902,9 @@ void pg_destroy(pg_ctx *ctx)
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->dl_stream) (void)hipStreamDestroy(ctx->dl_stream);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
     delete ctx;
 }
 
@@ -1164,23 +1259,28 @@ int pg_device_batch_algorithmic_bytes(pg_ctx *ctx, pg_device_batch *b, double *b
 }
 
 // ---------------------------------------------------------------- host in / host out
-// Host buffers in, host results out.  The inputs are streamed to the GPU in chunks on a second stream
-// while the kernel already searches the previous chunk (the kernel takes a read range of the batch);
-// results come back as device-built CSR.
+// Host buffers in, host results out, as a three-stage pipeline over chunks of PG_DELIVER_CHUNK reads:
+//   copy stream      the chunk's inputs, host -> HBM
+//   compute stream   pack, search (the kernel takes a read range of the batch), delivery kernels: the chunk's runs
+//                    gathered in read order behind the earlier chunks', its 64-bit CSR offsets (pg_deliver_chunk)
+//   download stream  the chunk's slice of every result array -> pinned host memory, while the next chunk is searched
+// The host only waits for "chunk k delivered", reads the chunk's base and run counts (32 bytes) and queues its copies.
 static int search_host(pg_ctx *ctx, const pg_read_batch *reads, int mode, pg_result **out)
 {
     use_device(ctx);
     if (!ctx || !out) return PG_E_INVALID;
     *out = nullptr;
     pg_device_batch *b = nullptr;
-    std::vector<uint64_t> off;
+    PodVec<uint64_t> off;
     const double t_start = now_ms();
     int rc = alloc_batch(ctx, reads, false, off, &b, true);
     if (rc) return rc;
-    const double t_alloc = now_ms();
+    double t_alloc = now_ms();
+    pg_result *r = nullptr;
     auto bail = [&](int code) {
         free_batch_buffers(b);
         delete b;
+        if (code && r) delete r;
         return code;
     };
 #define TRY3(call)                                                                           \
@@ -1191,16 +1291,50 @@ static int search_host(pg_ctx *ctx, const pg_read_batch *reads, int mode, pg_res
                              std::string(#call) + ": " + hipGetErrorString(e_)));            \
     } while (0)
     const uint32_t n = b->n;
+    r = new pg_result();
+    r->n = n;
+    const size_t cap = deliver_cap(n);
+    if (!r->close_off.resize((size_t)n + 1) || !r->far_off.resize((size_t)n + 1) || !r->rc_flag.resize(n) ||
+        !r->close_last.resize(n) || !r->close_max.resize(n) || !r->close_runs.resize(n ? cap : 0) || !r->far_runs.resize(n ? cap : 0))
+        return bail(fail(ctx, PG_E_NOMEM, "pinned host memory for the result"));
+    const double t_res = now_ms();
+    double t_search = t_res;
+    bool whole_batch = false;                // fall back to run_search + download (pool or delivery overflow)
     if (n) {
         if (!ctx->copy_stream) TRY3(hipStreamCreate(&ctx->copy_stream));
-        static const uint32_t chunk = getenv("PG_HOST_CHUNK") ? (uint32_t)std::max(1, atoi(getenv("PG_HOST_CHUNK"))) : (1u << 18);
+        if (!ctx->dl_stream) TRY3(hipStreamCreate(&ctx->dl_stream));
+        if (!ctx->stream2) TRY3(hipStreamCreate(&ctx->stream2));
+        static const uint32_t chunk = getenv("PG_HOST_CHUNK") ? (uint32_t)std::min<long>(std::max(1, atoi(getenv("PG_HOST_CHUNK"))), PG_DELIVER_CHUNK)
+                                                               : PG_DELIVER_CHUNK;
+        const uint32_t n_chunks = (n + chunk - 1) / chunk;
+        while (ctx->events.size() < 2 * (size_t)n_chunks + 1) {
+            hipEvent_t ev = nullptr;
+            TRY3(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            ctx->events.push_back(ev);
+        }
+        // delivery buffers (arena): gathered runs, 64-bit offsets, scratch, per-chunk info; pinned mirror of the info
+        pg_run *d_runs[2];
+        unsigned long long *d_off[2], *d_tot, *d_info;
+        void *d_local, *d_blk;
+        uint32_t *d_ovf;
+        if (!(d_runs[0] = (pg_run *)ctx->arena.take(cap * sizeof(pg_run))) || !(d_runs[1] = (pg_run *)ctx->arena.take(cap * sizeof(pg_run))) ||
+            !(d_off[0] = (unsigned long long *)ctx->arena.take(((size_t)n + 1) * 8)) ||
+            !(d_off[1] = (unsigned long long *)ctx->arena.take(((size_t)n + 1) * 8)) ||
+            !(d_local = ctx->arena.take((size_t)PG_DELIVER_CHUNK * 8)) || !(d_blk = ctx->arena.take(1024 * 8)) ||
+            !(d_tot = (unsigned long long *)ctx->arena.take(64)) || !(d_info = (unsigned long long *)ctx->arena.take((size_t)n_chunks * 32)) ||
+            !(d_ovf = (uint32_t *)ctx->arena.take(64)))
+            return bail(fail(ctx, PG_E_NOMEM, "device arena too small for the delivery buffers"));
+        HostBuf<unsigned long long> info;
+        if (!info.resize((size_t)n_chunks * 4)) return bail(fail(ctx, PG_E_NOMEM, "pinned host memory"));
         const uint64_t base0 = reads->seq_off[0];
-        std::vector<hipEvent_t> evs;
         TRY3(hipMemsetAsync(b->pool_used, 0, PG_POOL_SHARDS * 16 * sizeof(uint32_t), ctx->stream));
+        TRY3(hipMemsetAsync(d_tot, 0, 64, ctx->stream));
+        TRY3(hipMemsetAsync(d_ovf, 0, 64, ctx->stream));
         TRY3(hipEventRecord(ctx->ev0, ctx->stream));
+        TRY3(hipEventRecord(ctx->events[2 * n_chunks], ctx->stream));
         hipError_t e = hipSuccess;
-        for (uint32_t lo = 0; lo < n && e == hipSuccess && rc == PG_OK; lo += chunk) {
-            const uint32_t hi = (uint32_t)std::min<uint64_t>((uint64_t)lo + chunk, n), cn = hi - lo;
+        for (uint32_t k = 0; k < n_chunks && e == hipSuccess && rc == PG_OK; k++) {
+            const uint32_t lo = k * chunk, hi = (uint32_t)std::min<uint64_t>((uint64_t)lo + chunk, n), cn = hi - lo;
             hipStream_t cs = ctx->copy_stream;
             if (off[hi] > off[lo])
                 e = hipMemcpyAsync(b->seq + off[lo], reads->seq + base0 + off[lo], (size_t)(off[hi] - off[lo]), hipMemcpyHostToDevice, cs);
@@ -1209,49 +1343,94 @@ static int search_host(pg_ctx *ctx, const pg_read_batch *reads, int mode, pg_res
             if (e == hipSuccess) e = hipMemcpyAsync(b->pos + lo, reads->anchor_pos + lo, (size_t)cn * sizeof(int32_t), hipMemcpyHostToDevice, cs);
             if (e == hipSuccess) e = hipMemcpyAsync(b->isz + lo, reads->insert_size + lo, (size_t)cn * sizeof(int16_t), hipMemcpyHostToDevice, cs);
             if (e == hipSuccess) e = hipMemcpyAsync(b->chr + lo, reads->chr_id + lo, (size_t)cn * sizeof(int32_t), hipMemcpyHostToDevice, cs);
-            hipEvent_t ev = nullptr;
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-            if (e == hipSuccess) {
-                evs.push_back(ev);
-                e = hipEventRecord(ev, cs);
+            if (e == hipSuccess) e = hipEventRecord(ctx->events[2 * k], cs);
+            // even chunks on one kernel stream, odd chunks on the other: the next chunk's workgroups move in while this
+            // chunk's persistent launch drains; the deliveries stay in chunk order (running totals, shared scratch)
+            hipStream_t ks = (k & 1u) ? ctx->stream2 : ctx->stream;
+            if (e == hipSuccess && k == 1) e = hipStreamWaitEvent(ks, ctx->events[2 * n_chunks], 0);     // (the memsets above)
+            if (e == hipSuccess) e = hipStreamWaitEvent(ks, ctx->events[2 * k], 0);
+            if (e == hipSuccess) rc = pack_reads(ctx, b, lo, cn, ks);
+            if (e == hipSuccess && rc == PG_OK) rc = launch_range(ctx, b, mode, lo, cn, ks, (int)(k & 1u));
+            if (e == hipSuccess && rc == PG_OK) {
+                if (k > 0) e = hipStreamWaitEvent(ks, ctx->events[2 * (k - 1) + 1], 0);
+                if (e == hipSuccess)
+                    e = (hipError_t)pg_deliver_chunk(b->out_rec + lo, cn, b->rc_flag + lo, b->close_last + lo, b->close_max + lo, d_local,
+                                                     d_blk, d_tot, d_info + 4 * k, b->pool, d_runs[0], d_runs[1], cap, d_off[0] + lo,
+                                                     d_off[1] + lo, d_ovf, ks);
+                if (e == hipSuccess) e = hipMemcpyAsync(info.data() + 4 * k, d_info + 4 * k, 32, hipMemcpyDeviceToHost, ks);
+                if (e == hipSuccess) e = hipEventRecord(ctx->events[2 * k + 1], ks);
             }
-            if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ev, 0);
-            if (e == hipSuccess) rc = pack_reads(ctx, b, lo, cn);
-            if (e == hipSuccess && rc == PG_OK) rc = launch_range(ctx, b, mode, lo, cn);
         }
+        // (the last delivery waited for every earlier one, so its stream's end is the end of the batch)
+        hipStream_t last = ((n_chunks - 1) & 1u) ? ctx->stream2 : ctx->stream;
+        if (e == hipSuccess && last != ctx->stream) e = hipStreamWaitEvent(ctx->stream, ctx->events[2 * (n_chunks - 1) + 1], 0);
         if (e == hipSuccess) e = hipEventRecord(ctx->ev1, ctx->stream);
+        // as the chunks get delivered: their slices to the host
+        unsigned long long tot[2] = { 0, 0 };
+        for (uint32_t k = 0; k < n_chunks && e == hipSuccess && rc == PG_OK && !whole_batch; k++) {
+            const uint32_t lo = k * chunk, hi = (uint32_t)std::min<uint64_t>((uint64_t)lo + chunk, n), cn = hi - lo;
+            e = hipEventSynchronize(ctx->events[2 * k + 1]);
+            if (e != hipSuccess) break;
+            const unsigned long long *in = info.data() + 4 * k;
+            if (in[0] + in[2] > cap || in[1] + in[3] > cap) {
+                whole_batch = true;
+                break;
+            }
+            hipStream_t ds = ctx->dl_stream;
+            if (in[2]) e = hipMemcpyAsync(r->close_runs.data() + in[0], d_runs[0] + in[0], (size_t)in[2] * sizeof(pg_run), hipMemcpyDeviceToHost, ds);
+            if (e == hipSuccess && in[3])
+                e = hipMemcpyAsync(r->far_runs.data() + in[1], d_runs[1] + in[1], (size_t)in[3] * sizeof(pg_run), hipMemcpyDeviceToHost, ds);
+            if (e == hipSuccess) e = hipMemcpyAsync(r->close_off.data() + lo, d_off[0] + lo, (size_t)cn * 8, hipMemcpyDeviceToHost, ds);
+            if (e == hipSuccess) e = hipMemcpyAsync(r->far_off.data() + lo, d_off[1] + lo, (size_t)cn * 8, hipMemcpyDeviceToHost, ds);
+            if (e == hipSuccess) e = hipMemcpyAsync(r->rc_flag.data() + lo, b->rc_flag + lo, cn, hipMemcpyDeviceToHost, ds);
+            if (e == hipSuccess) e = hipMemcpyAsync(r->close_last.data() + lo, b->close_last + lo, (size_t)cn * 4, hipMemcpyDeviceToHost, ds);
+            if (e == hipSuccess) e = hipMemcpyAsync(r->close_max.data() + lo, b->close_max + lo, (size_t)cn * 2, hipMemcpyDeviceToHost, ds);
+            tot[0] = in[0] + in[2];
+            tot[1] = in[1] + in[3];
+        }
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        for (hipEvent_t ev : evs) (void)hipEventDestroy(ev);
         if (rc) return bail(rc);
         TRY3(e);
         float ms = 0.f;
         TRY3(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-        uint32_t worst = 0;
+        t_search = now_ms();
+        uint32_t worst = 0, ovf = 0;
         uint64_t total = 0;
         if ((rc = read_cursors(ctx, b, &worst, &total))) return bail(rc);
-        if (worst <= b->pool_shard_cap) {
+        TRY3(hipMemcpy(&ovf, d_ovf, 4, hipMemcpyDeviceToHost));
+        if (worst > b->pool_shard_cap || ovf) whole_batch = true;
+        if (!whole_batch) {
             ctx->last_ms = ms;
             ctx->last_runs = total;
             b->runs_used = total;
             b->modes_done |= mode;
+            TRY3(hipStreamSynchronize(ctx->dl_stream));
+            r->close_off[n] = tot[0];
+            r->far_off[n] = tot[1];
+            r->close_runs.resize((size_t)tot[0]);
+            r->far_runs.resize((size_t)tot[1]);
+        } else {
+            // a pool shard overflowed, or the lists outgrew the delivery buffers: the whole batch again, with the
+            // regrown pool where needed, and the whole-batch download
+            TRY3(hipStreamSynchronize(ctx->dl_stream));
+            if (worst > b->pool_shard_cap) {
+                if ((rc = run_search(ctx, b, mode))) return bail(rc);
+            } else {
+                b->modes_done |= mode;
+                b->runs_used = total;
+                ctx->last_ms = ms;
+                ctx->last_runs = total;
+            }
             b->unpacked = false;
-        } else if ((rc = run_search(ctx, b, mode))) {      // a pool shard overflowed: regrow and search again
-            return bail(rc);
+            if ((rc = download(ctx, b, r))) return bail(rc);
         }
     } else {
-        b->modes_done |= mode;
+        r->close_off[0] = r->far_off[0] = 0;
     }
 #undef TRY3
-    const double t_search = now_ms();
-    pg_result *r = new pg_result();
-    rc = download(ctx, b, r);
     if (g_host_timing)
-        fprintf(stderr, "pg_search_batch: %u reads: validate+alloc %.1f ms, copy+search %.1f ms, download %.1f ms\n",
-                b->n, t_alloc - t_start, t_search - t_alloc, now_ms() - t_search);
-    if (rc) {
-        delete r;
-        return bail(rc);
-    }
+        fprintf(stderr, "pg_search_batch: %u reads: validate+alloc %.2f ms, result buffers %.2f ms, copy+search+delivery %.2f ms, tail %.2f ms%s\n",
+                b->n, t_alloc - t_start, t_res - t_alloc, t_search - t_res, now_ms() - t_search, whole_batch ? " (whole-batch fallback)" : "");
     *out = r;
     return bail(PG_OK);
 }
@@ -1408,7 +1587,7 @@ static int far_end_impl(pg_ctx *ctx, const pg_read_batch *reads, const uint8_t *
                         const uint16_t *close_max, const pg_windows *bd_hints, pg_result *dst)
 {
     pg_device_batch *b = nullptr;
-    std::vector<uint64_t> off0;
+    PodVec<uint64_t> off0;
     int rc = alloc_batch(ctx, reads, true, off0, &b, true);
     if (rc) return rc;
     auto bail = [&](int code) {

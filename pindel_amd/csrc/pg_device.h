@@ -139,6 +139,14 @@ int pg_pack_reads(const PgSoaIn *soa, PgInRec *in, uint32_t lo, uint32_t cnt, vo
 // close-end summary (rc flag, last AbsLoc, max length) of a host result into the output records
 int pg_pack_close_summary(const PgSoaOut *soa, PgOutRec *out, uint32_t n, void *stream);
 int pg_unpack_results(const PgOutRec *out, const PgSoaOut *soa, uint32_t n, void *stream);
+// One chunk (cnt <= PG_DELIVER_CHUNK reads) of a searched batch to read-order CSR behind the earlier chunks: see the
+// delivery kernels in pg_kernels.hip.  local / blk: scratch of cnt and 1024 uint2; run_tot: 2 running totals (zeroed
+// per batch); info: 4 values for the host {close base, far base, close runs, far runs}.
+#define PG_DELIVER_CHUNK (1u << 18)
+int pg_deliver_chunk(const PgOutRec *out, uint32_t cnt, uint8_t *rc_flag, uint32_t *close_last, uint16_t *close_max,
+                     void *local, void *blk, unsigned long long *run_tot, unsigned long long *info,
+                     const pg_run *pool, pg_run *close_runs, pg_run *far_runs, unsigned long long cap,
+                     unsigned long long *close_off, unsigned long long *far_off, uint32_t *overflow, void *stream);
 int pg_compact_runs(const pg_run *pool, const uint32_t *off, const uint32_t *cnt, uint32_t *csr,
                     pg_run *out, uint32_t n, void *tmp, size_t tmp_bytes, int gather, void *stream);
 #ifdef __cplusplus

@@ -2063,3 +2063,93 @@ extern "C" int pg_launch_search(const PgDevRef *ref, const PgDevParams *prm, con
     return (int)hipGetLastError();
 #endif
 }
+
+// ---------------------------------------------------------------------------------
+// Delivery of a searched read range to the host, chunk by chunk (pg_search_batch & co): three small kernels turn the
+// pooled runs of reads [0, cnt) of a chunk (cnt <= PG_DELIVER_CHUNK) into their slice of the batch-wide CSR -- 64-bit
+// offsets exactly as the C ABI hands them out, runs gathered in read order behind the runs of the earlier chunks -- so
+// that a chunk's result can cross PCIe while the next chunk is still being searched and the host does no per-read work.
+//   scan1   per 256-read block: per-read summaries to SoA, block-local exclusive sums of the two run counts, block sums
+//   scan2   one block: exclusive sums of the block sums; takes the chunk's base from the running totals and advances them
+//   gather  offsets = chunk base + block base + local sum; copies the runs; raises *overflow if a list outgrows `cap`
+#include <hipcub/block/block_scan.hpp>
+
+__global__ __launch_bounds__(256) void pg_deliver_scan1(const PgOutRec *out, uint32_t cnt, uint8_t *rc_flag, uint32_t *close_last,
+                                                        uint16_t *close_max, uint2 *local, uint2 *blk)
+{
+    typedef hipcub::BlockScan<uint32_t, 256> Scan;
+    __shared__ typename Scan::TempStorage tc, tf;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    uint32_t c = 0, f = 0;
+    if (i < cnt) {
+        const PgOutRec r = out[i];
+        rc_flag[i] = r.rc_flag;
+        close_last[i] = r.close_last;
+        close_max[i] = r.close_max;
+        c = r.close_cnt;
+        f = r.far_cnt;
+    }
+    uint32_t ec, ef, sc, sf;
+    Scan(tc).ExclusiveSum(c, ec, sc);
+    Scan(tf).ExclusiveSum(f, ef, sf);
+    if (i < cnt) local[i] = make_uint2(ec, ef);
+    if (threadIdx.x == 0) blk[blockIdx.x] = make_uint2(sc, sf);
+}
+
+// run_tot[0..1]: runs (close, far) of the chunks delivered so far; info[0..3] = {close base, far base, close runs, far runs} of this chunk
+__global__ __launch_bounds__(1024) void pg_deliver_scan2(uint2 *blk, uint32_t nblk, unsigned long long *run_tot, unsigned long long *info)
+{
+    typedef hipcub::BlockScan<uint32_t, 1024> Scan;
+    __shared__ typename Scan::TempStorage tc, tf;
+    uint2 v = make_uint2(0u, 0u);
+    if (threadIdx.x < nblk) v = blk[threadIdx.x];
+    uint32_t ec, ef, sc, sf;
+    Scan(tc).ExclusiveSum(v.x, ec, sc);
+    Scan(tf).ExclusiveSum(v.y, ef, sf);
+    if (threadIdx.x < nblk) blk[threadIdx.x] = make_uint2(ec, ef);
+    if (threadIdx.x == 0) {
+        info[0] = run_tot[0];
+        info[1] = run_tot[1];
+        info[2] = sc;
+        info[3] = sf;
+        run_tot[0] += sc;
+        run_tot[1] += sf;
+    }
+}
+
+__global__ __launch_bounds__(256) void pg_deliver_gather(const PgOutRec *out, uint32_t cnt, const uint2 *local, const uint2 *blk,
+                                                         const unsigned long long *info, const pg_run *pool, pg_run *close_runs,
+                                                         pg_run *far_runs, unsigned long long cap, unsigned long long *close_off,
+                                                         unsigned long long *far_off, uint32_t *overflow)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= cnt) return;
+    const PgOutRec r = out[i];
+    const uint2 l = local[i], b = blk[blockIdx.x];
+    const unsigned long long oc = info[0] + b.x + l.x, of = info[1] + b.y + l.y;
+    close_off[i] = oc;
+    far_off[i] = of;
+    if (oc + r.close_cnt > cap || of + r.far_cnt > cap) {
+        *overflow = 1u;
+        return;
+    }
+    const u32 *sc = (const u32 *)(pool + r.close_off), *sf = (const u32 *)(pool + r.far_off);
+    u32 *dc = (u32 *)(close_runs + oc), *df = (u32 *)(far_runs + of);
+    for (uint32_t k = 0; k < 3u * r.close_cnt; k++) dc[k] = sc[k];
+    for (uint32_t k = 0; k < 3u * r.far_cnt; k++) df[k] = sf[k];
+}
+
+extern "C" int pg_deliver_chunk(const PgOutRec *out, uint32_t cnt, uint8_t *rc_flag, uint32_t *close_last, uint16_t *close_max,
+                                void *local, void *blk, unsigned long long *run_tot, unsigned long long *info,
+                                const pg_run *pool, pg_run *close_runs, pg_run *far_runs, unsigned long long cap,
+                                unsigned long long *close_off, unsigned long long *far_off, uint32_t *overflow, void *stream)
+{
+    if (!cnt || cnt > PG_DELIVER_CHUNK) return cnt ? (int)hipErrorInvalidValue : 0;
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t nblk = (cnt + 255u) / 256u;
+    pg_deliver_scan1<<<nblk, 256, 0, st>>>(out, cnt, rc_flag, close_last, close_max, (uint2 *)local, (uint2 *)blk);
+    pg_deliver_scan2<<<1, 1024, 0, st>>>((uint2 *)blk, nblk, run_tot, info);
+    pg_deliver_gather<<<nblk, 256, 0, st>>>(out, cnt, (const uint2 *)local, (const uint2 *)blk, info, pool, close_runs, far_runs,
+                                           cap, close_off, far_off, overflow);
+    return (int)hipGetLastError();
+}
