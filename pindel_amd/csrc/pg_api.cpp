@@ -517,7 +517,7 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, PodVec<uint6
                 pg_scan_tmp_bytes((uint32_t)n) + 4096;
         // ... and for the chunk-by-chunk delivery of search_host: gathered runs (2 lists), 64-bit offsets (2 lists), scratch
         need += 2 * (deliver_cap(n) * sizeof(pg_run) + 512) + 2 * ((n + 1) * 8 + 512) + PG_DELIVER_CHUNK * 8 + 1024 * 8 +
-                (n / PG_DELIVER_CHUNK + 2) * 32 + 8192;
+                (n / PG_DELIVER_CHUNK + 2) * 64 + 8192;
         if (need > ctx->arena.cap) {
             if (ctx->arena.base) (void)hipFree(ctx->arena.base);
             ctx->arena.base = nullptr;
@@ -1316,20 +1316,17 @@ static int search_host(pg_ctx *ctx, const pg_read_batch *reads, int mode, pg_res
         pg_run *d_runs[2];
         unsigned long long *d_off[2], *d_tot, *d_info;
         void *d_local, *d_blk;
-        uint32_t *d_ovf;
         if (!(d_runs[0] = (pg_run *)ctx->arena.take(cap * sizeof(pg_run))) || !(d_runs[1] = (pg_run *)ctx->arena.take(cap * sizeof(pg_run))) ||
             !(d_off[0] = (unsigned long long *)ctx->arena.take(((size_t)n + 1) * 8)) ||
             !(d_off[1] = (unsigned long long *)ctx->arena.take(((size_t)n + 1) * 8)) ||
             !(d_local = ctx->arena.take((size_t)PG_DELIVER_CHUNK * 8)) || !(d_blk = ctx->arena.take(1024 * 8)) ||
-            !(d_tot = (unsigned long long *)ctx->arena.take(64)) || !(d_info = (unsigned long long *)ctx->arena.take((size_t)n_chunks * 32)) ||
-            !(d_ovf = (uint32_t *)ctx->arena.take(64)))
+            !(d_tot = (unsigned long long *)ctx->arena.take(64)) || !(d_info = (unsigned long long *)ctx->arena.take((size_t)n_chunks * 64)))
             return bail(fail(ctx, PG_E_NOMEM, "device arena too small for the delivery buffers"));
         HostBuf<unsigned long long> info;
-        if (!info.resize((size_t)n_chunks * 4)) return bail(fail(ctx, PG_E_NOMEM, "pinned host memory"));
+        if (!info.resize((size_t)n_chunks * 8)) return bail(fail(ctx, PG_E_NOMEM, "pinned host memory"));
         const uint64_t base0 = reads->seq_off[0];
         TRY3(hipMemsetAsync(b->pool_used, 0, PG_POOL_SHARDS * 16 * sizeof(uint32_t), ctx->stream));
         TRY3(hipMemsetAsync(d_tot, 0, 64, ctx->stream));
-        TRY3(hipMemsetAsync(d_ovf, 0, 64, ctx->stream));
         TRY3(hipEventRecord(ctx->ev0, ctx->stream));
         TRY3(hipEventRecord(ctx->events[2 * n_chunks], ctx->stream));
         hipError_t e = hipSuccess;
@@ -1355,9 +1352,9 @@ static int search_host(pg_ctx *ctx, const pg_read_batch *reads, int mode, pg_res
                 if (k > 0) e = hipStreamWaitEvent(ks, ctx->events[2 * (k - 1) + 1], 0);
                 if (e == hipSuccess)
                     e = (hipError_t)pg_deliver_chunk(b->out_rec + lo, cn, b->rc_flag + lo, b->close_last + lo, b->close_max + lo, d_local,
-                                                     d_blk, d_tot, d_info + 4 * k, b->pool, d_runs[0], d_runs[1], cap, d_off[0] + lo,
-                                                     d_off[1] + lo, d_ovf, ks);
-                if (e == hipSuccess) e = hipMemcpyAsync(info.data() + 4 * k, d_info + 4 * k, 32, hipMemcpyDeviceToHost, ks);
+                                                     d_blk, d_tot, d_info + 8 * k, b->pool, d_runs[0], d_runs[1], cap, d_off[0] + lo,
+                                                     d_off[1] + lo, b->pool_used, ks);
+                if (e == hipSuccess) e = hipMemcpyAsync(info.data() + 8 * k, d_info + 8 * k, 64, hipMemcpyDeviceToHost, ks);
                 if (e == hipSuccess) e = hipEventRecord(ctx->events[2 * k + 1], ks);
             }
         }
@@ -1371,8 +1368,8 @@ static int search_host(pg_ctx *ctx, const pg_read_batch *reads, int mode, pg_res
             const uint32_t lo = k * chunk, hi = (uint32_t)std::min<uint64_t>((uint64_t)lo + chunk, n), cn = hi - lo;
             e = hipEventSynchronize(ctx->events[2 * k + 1]);
             if (e != hipSuccess) break;
-            const unsigned long long *in = info.data() + 4 * k;
-            if (in[0] + in[2] > cap || in[1] + in[3] > cap) {
+            const unsigned long long *in = info.data() + 8 * k;
+            if (in[0] + in[2] > cap || in[1] + in[3] > cap || in[5] || in[4] > b->pool_shard_cap) {
                 whole_batch = true;
                 break;
             }
@@ -1383,8 +1380,10 @@ static int search_host(pg_ctx *ctx, const pg_read_batch *reads, int mode, pg_res
             if (e == hipSuccess) e = hipMemcpyAsync(r->close_off.data() + lo, d_off[0] + lo, (size_t)cn * 8, hipMemcpyDeviceToHost, ds);
             if (e == hipSuccess) e = hipMemcpyAsync(r->far_off.data() + lo, d_off[1] + lo, (size_t)cn * 8, hipMemcpyDeviceToHost, ds);
             if (e == hipSuccess) e = hipMemcpyAsync(r->rc_flag.data() + lo, b->rc_flag + lo, cn, hipMemcpyDeviceToHost, ds);
-            if (e == hipSuccess) e = hipMemcpyAsync(r->close_last.data() + lo, b->close_last + lo, (size_t)cn * 4, hipMemcpyDeviceToHost, ds);
-            if (e == hipSuccess) e = hipMemcpyAsync(r->close_max.data() + lo, b->close_max + lo, (size_t)cn * 2, hipMemcpyDeviceToHost, ds);
+            if (mode == PG_MODE_CLOSE) {          // the close-end summary: only a later pg_far_end_batch on this result reads it
+                if (e == hipSuccess) e = hipMemcpyAsync(r->close_last.data() + lo, b->close_last + lo, (size_t)cn * 4, hipMemcpyDeviceToHost, ds);
+                if (e == hipSuccess) e = hipMemcpyAsync(r->close_max.data() + lo, b->close_max + lo, (size_t)cn * 2, hipMemcpyDeviceToHost, ds);
+            }
             tot[0] = in[0] + in[2];
             tot[1] = in[1] + in[3];
         }
@@ -1394,11 +1393,10 @@ static int search_host(pg_ctx *ctx, const pg_read_batch *reads, int mode, pg_res
         float ms = 0.f;
         TRY3(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         t_search = now_ms();
-        uint32_t worst = 0, ovf = 0;
-        uint64_t total = 0;
-        if ((rc = read_cursors(ctx, b, &worst, &total))) return bail(rc);
-        TRY3(hipMemcpy(&ovf, d_ovf, 4, hipMemcpyDeviceToHost));
-        if (worst > b->pool_shard_cap || ovf) whole_batch = true;
+        // (the last chunk's info saw every launch's pool cursors: its delivery waited for all the earlier ones)
+        const uint32_t worst = (uint32_t)std::min<unsigned long long>(info[8 * (size_t)(n_chunks - 1) + 4], 0xffffffffull);
+        const uint64_t total = tot[0] + tot[1];
+        if (worst > b->pool_shard_cap) whole_batch = true;
         if (!whole_batch) {
             ctx->last_ms = ms;
             ctx->last_runs = total;
@@ -1409,6 +1407,10 @@ static int search_host(pg_ctx *ctx, const pg_read_batch *reads, int mode, pg_res
             r->far_off[n] = tot[1];
             r->close_runs.resize((size_t)tot[0]);
             r->far_runs.resize((size_t)tot[1]);
+            if (mode != PG_MODE_CLOSE) {                  // not downloaded: pg_far_end_batch refuses such a result
+                r->close_last.resize(0);
+                r->close_max.resize(0);
+            }
         } else {
             // a pool shard overflowed, or the lists outgrew the delivery buffers: the whole batch again, with the
             // regrown pool where needed, and the whole-batch download
@@ -1492,6 +1494,7 @@ int pg_search_batch_multi(pg_ctx *const *ctxs, int32_t n_ctx, const pg_read_batc
     if (r) {
         uint64_t bc = 0, bf = 0;
         size_t at = 0;
+        bool summaries = true;
         for (pg_result *p : parts) {
             const size_t m = p->n;
             for (size_t i = 0; i < m; i++) {
@@ -1500,8 +1503,11 @@ int pg_search_batch_multi(pg_ctx *const *ctxs, int32_t n_ctx, const pg_read_batc
             }
             if (m) {
                 memcpy(r->rc_flag.data() + at, p->rc_flag.data(), m);
-                memcpy(r->close_last.data() + at, p->close_last.data(), m * 4);
-                memcpy(r->close_max.data() + at, p->close_max.data(), m * 2);
+                if (p->close_last.size() == m && p->close_max.size() == m) {
+                    memcpy(r->close_last.data() + at, p->close_last.data(), m * 4);
+                    memcpy(r->close_max.data() + at, p->close_max.data(), m * 2);
+                } else
+                    summaries = false;
             }
             if (p->close_runs.size()) memcpy(r->close_runs.data() + bc, p->close_runs.data(), p->close_runs.size() * sizeof(pg_run));
             if (p->far_runs.size()) memcpy(r->far_runs.data() + bf, p->far_runs.data(), p->far_runs.size() * sizeof(pg_run));
@@ -1511,6 +1517,10 @@ int pg_search_batch_multi(pg_ctx *const *ctxs, int32_t n_ctx, const pg_read_batc
         }
         r->close_off[n] = bc;
         r->far_off[n] = bf;
+        if (!summaries) {
+            r->close_last.resize(0);
+            r->close_max.resize(0);
+        }
     }
     for (pg_result *p : parts) delete p;
     *out = r;

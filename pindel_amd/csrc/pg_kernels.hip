@@ -1799,19 +1799,23 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
 #endif
 
     const uint32_t n = B.n_reads;
+    // reads claimed per atomic: PG_CLAIM, fewer when the launch is small (a 50 000-read flush is ten reads per resident
+    // wave: with claims of eight some waves would search sixteen reads and most eight)
+    const uint32_t per_wg = n / gridDim.x;
+    const uint32_t claim = per_wg >= 24u ? PG_CLAIM : (per_wg >= 6u ? 2u : 1u);
     const uint32_t per = n / PG_N_XCD;
     uint32_t part = blockIdx.x % PG_N_XCD, tried = 0;
     while (tried < PG_N_XCD) {
         const uint32_t lo = part * per, hi = part + 1 == PG_N_XCD ? n : lo + per;
         uint32_t got = 0;
-        if (lane == 0) got = atomicAdd(B.work_ctr + part * 16u, PG_CLAIM);
+        if (lane == 0) got = atomicAdd(B.work_ctr + part * 16u, claim);
         got = (u32)uni((int)got);
         if (got >= hi - lo) {                             // this part is exhausted
             part = part + 1 == PG_N_XCD ? 0 : part + 1;
             tried++;
             continue;
         }
-        const uint32_t first = lo + got, end = hi - first < PG_CLAIM ? hi : first + PG_CLAIM;
+        const uint32_t first = lo + got, end = hi - first < claim ? hi : first + claim;
         if (PG_REC_LDS(NB)) {
             __syncthreads();
             if ((uint32_t)lane < 8u * (end - first))
@@ -1823,9 +1827,9 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
         u32 res = 0u;
         {
             const u32 shard = blockIdx.x & (PG_POOL_SHARDS - 1u);
-            if (lane == 0) res = atomicAdd(B.pool_used + shard * 16u, PG_CLAIM * PG_RESERVE);
+            if (lane == 0) res = atomicAdd(B.pool_used + shard * 16u, claim * PG_RESERVE);
             res = (u32)uni((int)res);
-            const bool res_fits = (u64)res + (u64)(PG_CLAIM * PG_RESERVE) <= (u64)B.pool_shard_cap;
+            const bool res_fits = (u64)res + (u64)(claim * PG_RESERVE) <= (u64)B.pool_shard_cap;
             res += shard * B.pool_shard_cap;
             for (uint32_t i = first; i < end; i++)
                 search_read<NB, Id, mode>(ref, prm, B, S, qplanes, B.first_read + i, (int)(i - first), opaque(lane),
@@ -2073,6 +2077,7 @@ extern "C" int pg_launch_search(const PgDevRef *ref, const PgDevParams *prm, con
 //   scan2   one block: exclusive sums of the block sums; takes the chunk's base from the running totals and advances them
 //   gather  offsets = chunk base + block base + local sum; copies the runs; raises *overflow if a list outgrows `cap`
 #include <hipcub/block/block_scan.hpp>
+#include <hipcub/block/block_reduce.hpp>
 
 __global__ __launch_bounds__(256) void pg_deliver_scan1(const PgOutRec *out, uint32_t cnt, uint8_t *rc_flag, uint32_t *close_last,
                                                         uint16_t *close_max, uint2 *local, uint2 *blk)
@@ -2097,10 +2102,16 @@ __global__ __launch_bounds__(256) void pg_deliver_scan1(const PgOutRec *out, uin
 }
 
 // run_tot[0..1]: runs (close, far) of the chunks delivered so far; info[0..3] = {close base, far base, close runs, far runs} of this chunk
-__global__ __launch_bounds__(1024) void pg_deliver_scan2(uint2 *blk, uint32_t nblk, unsigned long long *run_tot, unsigned long long *info)
+// ... info[4] = the fullest run-pool shard's cursor so far (pool overflow check without another copy), info[5] = 0 (the
+// gather sets it if a list outgrows the delivery buffers)
+__global__ __launch_bounds__(1024) void pg_deliver_scan2(uint2 *blk, uint32_t nblk, unsigned long long *run_tot, unsigned long long *info,
+                                                         const uint32_t *pool_used)
 {
     typedef hipcub::BlockScan<uint32_t, 1024> Scan;
+    typedef hipcub::BlockReduce<uint32_t, 1024> Reduce;
     __shared__ typename Scan::TempStorage tc, tf;
+    __shared__ typename Reduce::TempStorage tr;
+    const uint32_t worst = Reduce(tr).Reduce(threadIdx.x < PG_POOL_SHARDS ? pool_used[threadIdx.x * 16u] : 0u, hipcub::Max());
     uint2 v = make_uint2(0u, 0u);
     if (threadIdx.x < nblk) v = blk[threadIdx.x];
     uint32_t ec, ef, sc, sf;
@@ -2112,6 +2123,8 @@ __global__ __launch_bounds__(1024) void pg_deliver_scan2(uint2 *blk, uint32_t nb
         info[1] = run_tot[1];
         info[2] = sc;
         info[3] = sf;
+        info[4] = worst;
+        info[5] = 0ull;
         run_tot[0] += sc;
         run_tot[1] += sf;
     }
@@ -2120,7 +2133,7 @@ __global__ __launch_bounds__(1024) void pg_deliver_scan2(uint2 *blk, uint32_t nb
 __global__ __launch_bounds__(256) void pg_deliver_gather(const PgOutRec *out, uint32_t cnt, const uint2 *local, const uint2 *blk,
                                                          const unsigned long long *info, const pg_run *pool, pg_run *close_runs,
                                                          pg_run *far_runs, unsigned long long cap, unsigned long long *close_off,
-                                                         unsigned long long *far_off, uint32_t *overflow)
+                                                         unsigned long long *far_off, unsigned long long *overflow)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= cnt) return;
@@ -2130,7 +2143,7 @@ __global__ __launch_bounds__(256) void pg_deliver_gather(const PgOutRec *out, ui
     close_off[i] = oc;
     far_off[i] = of;
     if (oc + r.close_cnt > cap || of + r.far_cnt > cap) {
-        *overflow = 1u;
+        *overflow = 1ull;
         return;
     }
     const u32 *sc = (const u32 *)(pool + r.close_off), *sf = (const u32 *)(pool + r.far_off);
@@ -2142,14 +2155,14 @@ __global__ __launch_bounds__(256) void pg_deliver_gather(const PgOutRec *out, ui
 extern "C" int pg_deliver_chunk(const PgOutRec *out, uint32_t cnt, uint8_t *rc_flag, uint32_t *close_last, uint16_t *close_max,
                                 void *local, void *blk, unsigned long long *run_tot, unsigned long long *info,
                                 const pg_run *pool, pg_run *close_runs, pg_run *far_runs, unsigned long long cap,
-                                unsigned long long *close_off, unsigned long long *far_off, uint32_t *overflow, void *stream)
+                                unsigned long long *close_off, unsigned long long *far_off, const uint32_t *pool_used, void *stream)
 {
     if (!cnt || cnt > PG_DELIVER_CHUNK) return cnt ? (int)hipErrorInvalidValue : 0;
     hipStream_t st = (hipStream_t)stream;
     const uint32_t nblk = (cnt + 255u) / 256u;
     pg_deliver_scan1<<<nblk, 256, 0, st>>>(out, cnt, rc_flag, close_last, close_max, (uint2 *)local, (uint2 *)blk);
-    pg_deliver_scan2<<<1, 1024, 0, st>>>((uint2 *)blk, nblk, run_tot, info);
+    pg_deliver_scan2<<<1, 1024, 0, st>>>((uint2 *)blk, nblk, run_tot, info, pool_used);
     pg_deliver_gather<<<nblk, 256, 0, st>>>(out, cnt, (const uint2 *)local, (const uint2 *)blk, info, pool, close_runs, far_runs,
-                                           cap, close_off, far_off, overflow);
+                                           cap, close_off, far_off, info + 5);
     return (int)hipGetLastError();
 }
