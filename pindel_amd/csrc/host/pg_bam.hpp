@@ -588,45 +588,166 @@ public:
             struct Part {
                 std::vector<uint8_t> bytes;        // the records that start in the sub-range, back to back
                 std::vector<uint64_t> ends;        // end offset of each in `bytes`
+                std::vector<uint32_t> hash;        // hash of each record's read name
             };
             std::vector<Part> parts(nt);
-            if (!bam.query_split(tid, win_start, win_end, nt, [&](unsigned t, const BamRecord &, const BamFile &reader) {
+            if (!bam.query_split(tid, win_start, win_end, nt, [&](unsigned t, const BamRecord &rec, const BamFile &reader) {
                     const std::vector<uint8_t> &raw = reader.last_raw();
                     parts[t].bytes.insert(parts[t].bytes.end(), raw.begin(), raw.end());
                     parts[t].ends.push_back(parts[t].bytes.size());
+                    uint32_t h = 2166136261u;                          // FNV-1a
+                    for (unsigned char ch : rec.qname) h = (h ^ ch) * 16777619u;
+                    parts[t].hash.push_back(h);
                 })) {
                 error = "BAM read failed";
                 return false;
             }
-            // the same pairing on the records' bytes, which stay where they are: the name is a view into them and the
-            // first mate is decoded again when the second one arrives (no per-record copies)
-            struct Raw { const uint8_t *p; size_t n; };
-            std::unordered_map<std::string_view, Raw> waiting_raw;
-            BamRecord r, r2;
-            for (const Part &part : parts) {
-                uint64_t from = 0;
-                for (uint64_t to : part.ends) {
-                    const uint8_t *p = part.bytes.data() + from;
-                    const size_t n = (size_t)(to - from);
-                    from = to;
-                    if (!ok) continue;
-                    if (!BamFile::decode(p, n, r)) {
-                        error = "BAM read failed";
-                        return false;
+            // The selection runs on the records' bytes, which stay where they are (the name is a view into them, the
+            // first mate is decoded again when the second one arrives), on several threads: a pair meets in the thread
+            // that owns its name's hash, every thread walks the records in file order and notes which record (the
+            // "trigger") produced each of its reads, and the reads are then laid out in trigger order -- the order
+            // of the sequential pass.
+            struct Raw { const uint8_t *p; uint32_t n, hash; };
+            std::vector<Raw> recs;
+            {
+                size_t total = 0;
+                for (const Part &part : parts) total += part.ends.size();
+                recs.reserve(total);
+                for (const Part &part : parts) {
+                    uint64_t from = 0;
+                    for (size_t k = 0; k < part.ends.size(); k++) {
+                        recs.push_back(Raw{ part.bytes.data() + from, (uint32_t)(part.ends[k] - from), part.hash[k] });
+                        from = part.ends[k];
                     }
-                    const std::string_view name((const char *)p + 32, r.qname.size());
-                    auto it = waiting_raw.find(name);
-                    if (it == waiting_raw.end()) {
-                        waiting_raw.emplace(name, Raw{ p, n });
-                        first_of_name(r);
-                        continue;
-                    }
-                    (void)BamFile::decode(it->second.p, it->second.n, r2);
-                    waiting_raw.erase(it);
-                    pair_complete(r, r2);
                 }
             }
-            return ok;
+            const size_t N = recs.size();
+            const unsigned T2 = (unsigned)std::max<size_t>(1, std::min<size_t>(BamFile::worker_threads(), N / 20000 + 1));
+            struct Emit {
+                IngestedReads out;
+                std::vector<uint32_t> read_trig, ref_trig;       // trigger record of every read / reference read
+                std::string error;
+                bool ok = true;
+            };
+            std::vector<Emit> em(T2);
+            auto select = [&](unsigned t) {
+                Emit &e = em[t];
+                e.out.clear();
+                e.out.ref_tags = out.ref_tags;                     // (tag indices of the reference reads: same table in every thread)
+                std::unordered_map<std::string_view, const Raw *> waiting_raw;
+                BamRecord r, r2;
+                BamIngest me(S);                                   // (build_record reports the fatal case through .error)
+                for (size_t i = 0; i < N && e.ok; i++) {
+                    const Raw &x = recs[i];
+                    if (x.hash % T2 != t) continue;
+                    if (!BamFile::decode(x.p, x.n, r)) {
+                        e.ok = false;
+                        e.error = "BAM read failed";
+                        break;
+                    }
+                    const std::string_view name((const char *)x.p + 32, r.qname.size());
+                    auto it = waiting_raw.find(name);
+                    if (it == waiting_raw.end()) {
+                        waiting_raw.emplace(name, &x);
+                        if (is_weird(r)) e.ok = e.ok && me.build_record(bam, r, r, chr_id, chr_padded_size, insert_size, tag, e.out);
+                    } else {
+                        (void)BamFile::decode(it->second->p, it->second->n, r2);
+                        waiting_raw.erase(it);
+                        const BamRecord &b1 = r, &b2 = r2;
+                        if (is_weird(b2)) e.ok = e.ok && me.build_record(bam, b2, b2, chr_id, chr_padded_size, insert_size, tag, e.out);
+                        if (is_good_anchor(b1) && is_weird(b2)) e.ok = e.ok && me.build_record(bam, b1, b2, chr_id, chr_padded_size, insert_size, tag, e.out);
+                        if (is_good_anchor(b1) && is_ref_read(b2)) add_ref_read(b2, tag, e.out);
+                        if (is_good_anchor(b2) && is_weird(b1)) e.ok = e.ok && me.build_record(bam, b2, b1, chr_id, chr_padded_size, insert_size, tag, e.out);
+                        if (is_good_anchor(b2) && is_ref_read(b1)) add_ref_read(b1, tag, e.out);
+                    }
+                    while (e.read_trig.size() < e.out.size()) e.read_trig.push_back((uint32_t)i);
+                    while (e.ref_trig.size() < e.out.ref_reads.size()) e.ref_trig.push_back((uint32_t)i);
+                }
+                if (!e.ok && e.error.empty()) e.error = me.error;
+            };
+            {
+                std::vector<std::thread> th;
+                for (unsigned t = 1; t < T2; t++) th.emplace_back(select, t);
+                select(0);
+                for (std::thread &x : th) x.join();
+            }
+            for (const Emit &e : em)
+                if (!e.ok) {
+                    error = e.error;
+                    return false;
+                }
+            // layout in trigger order: reads (and reference reads) per trigger, prefix sums, every thread moves its own
+            std::vector<uint32_t> rstart(N + 1, 0), fstart(N + 1, 0);
+            for (const Emit &e : em) {
+                for (uint32_t i : e.read_trig) rstart[i + 1]++;
+                for (uint32_t i : e.ref_trig) fstart[i + 1]++;
+            }
+            for (size_t i = 0; i < N; i++) {
+                rstart[i + 1] += rstart[i];
+                fstart[i + 1] += fstart[i];
+            }
+            const size_t base = out.size(), M = rstart[N], fbase = out.ref_reads.size(), FM = fstart[N];
+            // (a reference read's tag index refers to out.ref_tags; a thread that met a new tag appended it to its copy)
+            for (const Emit &e : em)
+                for (size_t k = out.ref_tags.size(); k < e.out.ref_tags.size(); k++)
+                    if (std::find(out.ref_tags.begin(), out.ref_tags.end(), e.out.ref_tags[k]) == out.ref_tags.end())
+                        out.ref_tags.push_back(e.out.ref_tags[k]);
+            out.names.resize(base + M);
+            out.ms.resize(base + M);
+            out.tags.resize(base + M);
+            out.batch.strand.resize(base + M);
+            out.batch.pos.resize(base + M);
+            out.batch.isz.resize(base + M);
+            out.batch.chr.resize(base + M);
+            out.batch.off.resize(base + M + 1);
+            out.ref_reads.resize(fbase + FM);
+            std::vector<uint32_t> lens(M);
+            auto place = [&](unsigned t, bool bases) {
+                Emit &e = em[t];
+                uint32_t prev = 0xffffffffu, sub = 0;
+                for (size_t k = 0; k < e.read_trig.size(); k++) {
+                    const uint32_t i = e.read_trig[k];
+                    sub = i == prev ? sub + 1 : 0;
+                    prev = i;
+                    const size_t g = rstart[i] + sub;
+                    if (!bases) {
+                        out.names[base + g].swap(e.out.names[k]);
+                        out.ms[base + g] = e.out.ms[k];
+                        out.tags[base + g].swap(e.out.tags[k]);
+                        out.batch.strand[base + g] = e.out.batch.strand[k];
+                        out.batch.pos[base + g] = e.out.batch.pos[k];
+                        out.batch.isz[base + g] = e.out.batch.isz[k];
+                        out.batch.chr[base + g] = e.out.batch.chr[k];
+                        lens[g] = (uint32_t)(e.out.batch.off[k + 1] - e.out.batch.off[k]);
+                    } else {
+                        std::copy(e.out.batch.seq.begin() + (long)e.out.batch.off[k], e.out.batch.seq.begin() + (long)e.out.batch.off[k + 1],
+                                  out.batch.seq.begin() + (long)out.batch.off[base + g]);
+                    }
+                }
+                if (bases) return;
+                prev = 0xffffffffu;
+                sub = 0;
+                for (size_t k = 0; k < e.ref_trig.size(); k++) {
+                    const uint32_t i = e.ref_trig[k];
+                    sub = i == prev ? sub + 1 : 0;
+                    prev = i;
+                    RefRead rr = e.out.ref_reads[k];
+                    const std::string &tg = e.out.ref_tags[rr.tag];
+                    rr.tag = (uint16_t)(std::find(out.ref_tags.begin(), out.ref_tags.end(), tg) - out.ref_tags.begin());
+                    out.ref_reads[fbase + fstart[i] + sub] = rr;
+                }
+            };
+            auto on_threads = [&](bool bases) {
+                std::vector<std::thread> th;
+                for (unsigned t = 1; t < T2; t++) th.emplace_back(place, t, bases);
+                place(0, bases);
+                for (std::thread &x : th) x.join();
+            };
+            on_threads(false);
+            for (size_t g = 0; g < M; g++) out.batch.off[base + g + 1] = out.batch.off[base + g] + lens[g];
+            out.batch.seq.resize((size_t)out.batch.off[base + M]);
+            on_threads(true);
+            return true;
         }
         const bool q = bam.query(tid, win_start, win_end, take);
         if (!q) error = "BAM read failed";

@@ -9,6 +9,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <functional>
+#include <future>
+#include <memory>
 #include <string>
 #include <utility>
 #include <vector>
@@ -162,13 +165,34 @@ struct BamSource {
     int insert_size = 0;
 };
 
+// The close end of one window of the BAM path, straight on the ingested structure-of-arrays batch (no SplitRead per
+// candidate): what comes back per contiguous part of the batch (one part per device).
+struct ClosePart {
+    size_t first = 0, n = 0;              // reads [first, first + n) of the batch
+    const uint8_t *rc_flag = nullptr;     // per read of the part
+    const uint64_t *close_off = nullptr;  // n + 1 offsets into close_runs
+    const pg_run *close_runs = nullptr;
+};
+struct CloseView {
+    std::vector<ClosePart> parts;
+    std::function<void()> release;        // frees what the pointers point into
+};
+
 // bd != null && search_rp: before the reads of a window are taken, its discordant read pairs become BreakDancer-like
 // events (get_RP_Reads_Discovery + BDData::UpdateBD, src/pindel.cpp:1838-1848; -R, default on) next to the events of
 // a -b file; the search step then looks their windows up per read (loadRegion / getCorrespondingSearchWindowCluster).
-template <class Search, class FarSearch>
+//
+//   close_soa(chrom, chr_id, batch, view)   ReadBuffer::flush on the window's candidates as ingested (SoA): the close
+//                                           ends as run lists + rc flags; only the reads that have one become SplitReads
+//                                           (UnmatchedSeq reverse-complemented where GetCloseEnd did, UP_Close filled)
+//   far_search(chrom, chr_id, kept)         SearchFarEnds on those reads
+//
+// The windows are a three-stage pipeline on the host: while window k is searched and classified, a second thread
+// already reads window k + 1 from the BAMs (read-pair discovery + ingest, the stage that dominates a BAM-fed run).
+template <class CloseSoa, class FarSearch>
 int run_bam_pipeline(const std::vector<Chromosome> &genome, const std::vector<unsigned> &fai,
                      const std::vector<BamSource> &bams, const BamIngestSettings &ingest, const Settings &S,
-                     const std::string &prefix, Search search, FarSearch far_search, std::string &err, size_t *n_reads_total = nullptr,
+                     const std::string &prefix, CloseSoa close_soa, FarSearch far_search, std::string &err, size_t *n_reads_total = nullptr,
                      BDHints *bd = nullptr, bool search_rp = false, size_t *n_rp_events = nullptr)
 {
     Caller caller(S, &genome, prefix, true);
@@ -182,45 +206,110 @@ int run_bam_pipeline(const std::vector<Chromosome> &genome, const std::vector<un
     std::vector<BamFile> files(bams.size());
     for (size_t k = 0; k < bams.size(); k++)
         if (!files[k].open(bams[k].path, err)) return -1;
+    // PGH_TIMING=1: wall-clock seconds per stage of this loop on stderr (diagnostics)
+    const bool timing = getenv("PGH_TIMING") != nullptr;
+    double t_wait = 0, t_close = 0, t_keep = 0, t_far = 0, t_cov = 0, t_call = 0, t_free = 0;
+    double t_rp = 0, t_ingest = 0;                         // (on the reader thread)
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+
+    struct Win { size_t c; unsigned ws, we; };
+    std::vector<Win> wins;
     for (size_t c = 0; c < genome.size(); c++) {
+        const unsigned biol = (unsigned)(genome[c].seq.size() - 2 * S.spacer);
+        const unsigned bed_end = fai[c] ? fai[c] : biol;
+        const unsigned global_end = std::min(biol, bed_end + 10000u);
+        for (unsigned ws = 0; !(ws > global_end); ws += WINDOW) wins.push_back({ c, ws, std::min(ws + WINDOW, global_end) });
+    }
+    // what the reader thread hands over for one window
+    struct WinData {
+        IngestedReads in;
+        std::vector<std::pair<BDHints::RpSide, BDHints::RpSide>> sides;   // read-pair events of the window
+        size_t n_events = 0;
+        std::string error;
+    };
+    // (only this function touches `files` and `rp_out`, one window at a time, in window order)
+    auto read_win = [&](size_t w) {
+        std::unique_ptr<WinData> d(new WinData());
+        const Win &win = wins[w];
+        const Chromosome &chrom = genome[win.c];
+        double t0 = now();
+        if (bd && search_rp) {
+            std::vector<RpRead> rp;
+            for (size_t k = 0; k < bams.size(); k++)
+                if (!rp_discover(files[k], chrom.name, win.ws, win.we, bams[k].insert_size, bams[k].tag, ingest.min_anchor_quality, rp)) {
+                    d->error = bams[k].path + ": BAM read failed";
+                    return d;
+                }
+            const std::vector<RpEvent> ev = rp_events(rp, S.spacer, &rp_out);
+            for (const RpEvent &e : ev) {
+                BDHints::RpSide a = { e.chr1, e.pos1, e.pos1b }, b = { e.chr2, e.pos2, e.pos2b };
+                d->sides.push_back(std::make_pair(a, b));
+            }
+            d->n_events = ev.size();
+        }
+        t_rp += now() - t0; t0 = now();
+        d->in.clear();
+        BamIngest ing(ingest);
+        for (size_t k = 0; k < bams.size(); k++)
+            if (!ing.read_window(files[k], chrom.name, (int)win.c, chrom.seq.size(), win.ws, win.we, bams[k].insert_size, bams[k].tag, d->in)) {
+                d->error = bams[k].path + ": " + ing.error;
+                return d;
+            }
+        t_ingest += now() - t0;
+        return d;
+    };
+    std::future<std::unique_ptr<WinData>> ahead;
+    if (!wins.empty()) ahead = std::async(std::launch::async, read_win, (size_t)0);
+    int status = 0;
+    for (size_t w = 0; w < wins.size(); w++) {
+        double t0 = now();
+        std::unique_ptr<WinData> d = ahead.get();
+        if (w + 1 < wins.size() && d->error.empty()) ahead = std::async(std::launch::async, read_win, w + 1);
+        t_wait += now() - t0; t0 = now();
+        if (!d->error.empty()) {
+            err = d->error;
+            return -1;
+        }
+        const Win &win = wins[w];
+        const size_t c = win.c;
         const Chromosome &chrom = genome[c];
         const unsigned biol = (unsigned)(chrom.seq.size() - 2 * S.spacer);
         const unsigned bed_start = 1, bed_end = fai[c] ? fai[c] : biol;
-        const unsigned global_end = std::min(biol, bed_end + 10000u);
-        for (unsigned ws = 0; !(ws > global_end); ws += WINDOW) {
-            const unsigned we = std::min(ws + WINDOW, global_end);
-            if (bd && search_rp) {
-                std::vector<RpRead> rp;
-                for (size_t k = 0; k < bams.size(); k++)
-                    if (!rp_discover(files[k], chrom.name, ws, we, bams[k].insert_size, bams[k].tag, ingest.min_anchor_quality, rp)) {
-                        err = bams[k].path + ": BAM read failed";
-                        return -1;
-                    }
-                const std::vector<RpEvent> ev = rp_events(rp, S.spacer, &rp_out);
-                std::vector<std::pair<BDHints::RpSide, BDHints::RpSide>> sides;
-                for (const RpEvent &e : ev) {
-                    BDHints::RpSide a = { e.chr1, e.pos1, e.pos1b }, b = { e.chr2, e.pos2, e.pos2b };
-                    sides.push_back(std::make_pair(a, b));
+        if (bd && search_rp) {
+            bd->update_with_rp(d->sides);
+            if (n_rp_events) *n_rp_events += d->n_events;
+        }
+        IngestedReads &in = d->in;
+        if (n_reads_total) *n_reads_total += in.size();
+        if (in.size() == 0) continue;
+        CloseView view;
+        int rc = close_soa(chrom, (int)c, in.batch, view);
+        if (rc) {
+            err = "search step failed";
+            status = rc;
+            break;
+        }
+        t_close += now() - t0; t0 = now();
+        // the reads that kept a close end (ReadBuffer::flush, src/read_buffer.cpp:55-64), in input order
+        std::vector<uint32_t> kept_idx;
+        std::vector<const ClosePart *> kept_part;
+        for (const ClosePart &p : view.parts)
+            for (size_t i = 0; i < p.n; i++)
+                if (p.close_off[i + 1] > p.close_off[i]) {
+                    kept_idx.push_back((uint32_t)(p.first + i));
+                    kept_part.push_back(&p);
                 }
-                bd->update_with_rp(sides);
-                if (n_rp_events) *n_rp_events += ev.size();
-            }
-            IngestedReads in;
-            in.clear();
-            BamIngest ing(ingest);
-            for (size_t k = 0; k < bams.size(); k++)
-                if (!ing.read_window(files[k], chrom.name, (int)c, chrom.seq.size(), ws, we, bams[k].insert_size, bams[k].tag, in)) {
-                    err = bams[k].path + ": " + ing.error;
-                    return -1;
-                }
-            if (n_reads_total) *n_reads_total += in.size();
-            if (in.size() == 0) continue;
-            std::vector<SplitRead> reads(in.size());
-            std::vector<uint32_t> index(in.size());
-            for (size_t i = 0; i < in.size(); i++) {
-                SplitRead &r = reads[i];
+        std::vector<SplitRead> kept(kept_idx.size());
+        pg_adapter::parallel_ranges(kept.size(), [&](size_t lo, size_t hi) {
+            for (size_t k = lo; k < hi; k++) {
+                const size_t i = kept_idx[k];
+                const ClosePart &p = *kept_part[k];
+                const size_t j = i - p.first;
+                SplitRead &r = kept[k];
                 r.Name = in.names[i];
                 r.UnmatchedSeq.assign((const char *)in.batch.seq.data() + in.batch.off[i], (size_t)(in.batch.off[i + 1] - in.batch.off[i]));
+                if (p.rc_flag[j]) pg_adapter::rc_in_place(r.UnmatchedSeq);          // setUnmatchedSeq(RC), pindel.cpp:2545
                 r.ReadLength = (short)r.UnmatchedSeq.size();
                 r.MatchedD = (char)in.batch.strand[i];
                 r.MatchedRelPos = (unsigned)in.batch.pos[i];
@@ -230,41 +319,50 @@ int run_bam_pipeline(const std::vector<Chromosome> &genome, const std::vector<un
                 r.FragName = chrom.name;
                 r.chr_id = (int)c;
                 r.MAX_SNP_ERROR = (short)S.max_mismatch[std::min<int>(r.ReadLength, 499)];
-                index[i] = (uint32_t)i;
+                pg_adapter::fill_points(r.UP_Close, p.close_runs, p.close_off[j], p.close_off[j + 1], [](const pg_point &q) {
+                    UniquePoint u;
+                    u.chr = q.chr_id;
+                    u.LengthStr = q.length;
+                    u.AbsLoc = q.abs_loc;
+                    u.Direction = q.direction;
+                    u.Strand = q.strand;
+                    u.Mismatches = q.mismatches;
+                    return u;
+                });
             }
-            int rc = search(chrom, (int)c, reads, index);
-            if (rc) {
-                err = "search step failed";
-                return rc;
-            }
-            caller.note_close_mapped_all(reads);
-            std::vector<SplitRead> kept;
-            {
-                size_t n_kept = 0;
-                for (const SplitRead &r : reads) n_kept += r.UP_Close.empty() ? 0 : 1;
-                kept.reserve(n_kept);
-            }
-            for (SplitRead &r : reads)
-                if (!r.UP_Close.empty()) kept.push_back(std::move(r));
-            if (!kept.empty() && (rc = far_search(chrom, (int)c, kept))) {
-                err = "far-end search step failed";
-                return rc;
-            }
-            {   // UpdateRefReadCoverage, after the close ends (sample names) and before the classifiers
-                std::vector<Caller::RefReadSpan> spans(in.ref_reads.size());
-                for (size_t i = 0; i < spans.size(); i++) {
-                    spans[i].pos = in.ref_reads[i].pos;
-                    spans[i].length = in.ref_reads[i].length;
-                    spans[i].tag = in.ref_reads[i].tag;
-                }
-                caller.update_ref_coverage(spans, in.ref_tags, ws, we);
-            }
-            if (!kept.empty()) caller.process_window(chrom, kept, ws, we, bed_start, bed_end);
-            release_reads(kept);
-            release_reads(reads);
+        });
+        if (view.release) view.release();
+        caller.note_close_mapped_all(kept);
+        t_keep += now() - t0; t0 = now();
+        if (!kept.empty() && (rc = far_search(chrom, (int)c, kept))) {
+            err = "far-end search step failed";
+            status = rc;
+            break;
         }
+        t_far += now() - t0; t0 = now();
+        {   // UpdateRefReadCoverage, after the close ends (sample names) and before the classifiers
+            std::vector<Caller::RefReadSpan> spans(in.ref_reads.size());
+            for (size_t i = 0; i < spans.size(); i++) {
+                spans[i].pos = in.ref_reads[i].pos;
+                spans[i].length = in.ref_reads[i].length;
+                spans[i].tag = in.ref_reads[i].tag;
+            }
+            caller.update_ref_coverage(spans, in.ref_tags, win.ws, win.we);
+        }
+        t_cov += now() - t0; t0 = now();
+        if (!kept.empty()) caller.process_window(chrom, kept, win.ws, win.we, bed_start, bed_end);
+        t_call += now() - t0; t0 = now();
+        release_reads(kept);
+        d.reset();
+        t_free += now() - t0;
     }
-    return 0;
+    if (ahead.valid()) ahead.wait();                      // (an early exit must not leave the reader running on dead objects)
+    if (timing)
+        fprintf(stderr, "pgh timing: BAM pipeline %.3f s wall: waiting for the reader %.3f s, close end %.3f s, keep + SplitReads %.3f s, "
+                        "far end %.3f s, reference coverage %.3f s, classify + report %.3f s, free %.3f s | reader thread: read-pair "
+                        "discovery %.3f s, ingest %.3f s\n",
+                now() - t_begin, t_wait, t_close, t_keep, t_far, t_cov, t_call, t_free, t_rp, t_ingest);
+    return status;
 }
 
 }  // namespace pgh

@@ -372,7 +372,54 @@ int main(int argc, char **argv)
         // BAM input: with -R (default) the window hints are live -- the events of a -b file plus the read-pair events of
         // every window; without -R the reference never hands any event to the search (UpdateBD is not called)
         use_bd = search_rp;
-        rc = run_bam_pipeline(genome, fai, bams, ing, S, prefix, close_search, far_search, err, &n_bam_reads, &bd, search_rp, &n_rp_events);
+        // seam 1 on the ingested structure-of-arrays batch: one pg_close_end_batch per device on a contiguous part
+        auto close_soa = [&](const Chromosome &, int, const pg_adapter::Batch &batch, CloseView &view) {
+            const double t0 = now_s();
+            const size_t nd = ctxs.size(), n = batch.strand.size();
+            const size_t np = (nd == 1 || n < 2 * nd) ? 1 : nd;
+            std::vector<pg_result *> res(np, nullptr);
+            std::vector<int> rcs(np, 0);
+            auto part = [&](size_t d) {
+                const size_t lo = n * d / np, hi = n * (d + 1) / np;
+                pg_read_batch v = batch.view();
+                v.n_reads = (uint32_t)(hi - lo);
+                v.seq_off += lo;
+                v.anchor_strand += lo;
+                v.anchor_pos += lo;
+                v.insert_size += lo;
+                v.chr_id += lo;
+                rcs[d] = pg_close_end_batch(ctxs[d], &v, &res[d]);
+            };
+            if (np == 1) part(0);
+            else {
+                std::vector<std::thread> th;
+                for (size_t d = 0; d < np; d++) th.emplace_back(part, d);
+                for (std::thread &x : th) x.join();
+            }
+            int r = 0;
+            for (size_t d = 0; d < np; d++)
+                if (rcs[d]) r = rcs[d];
+            view.release = [res]() { for (pg_result *x : res) pg_result_free(x); };
+            if (r) {
+                view.release();
+                view.release = nullptr;
+                return r;
+            }
+            for (size_t d = 0; d < np; d++) {
+                pg_result_view rv;
+                pg_result_view_get(res[d], &rv);
+                ClosePart p;
+                p.first = n * d / np;
+                p.n = rv.n_reads;
+                p.rc_flag = rv.rc_flag;
+                p.close_off = rv.close_off;
+                p.close_runs = rv.close_runs;
+                view.parts.push_back(p);
+            }
+            t_search += now_s() - t0;
+            return 0;
+        };
+        rc = run_bam_pipeline(genome, fai, bams, ing, S, prefix, close_soa, far_search, err, &n_bam_reads, &bd, search_rp, &n_rp_events);
         if (search_rp) printf("pindel_pg: read-pair events added as window hints: %zu\n", n_rp_events);
     } else
         rc = run_pipeline(genome, fai, all, S, prefix, close_search, far_search, err);
