@@ -173,13 +173,25 @@ void Caller::update_ref_coverage(const std::vector<RefReadSpan> &reads, const st
         for (size_t i = 0; i < names.size(); i++)
             if (names[i] == tags[t]) sample_of[t] = (int)i;
     const size_t length = (size_t)end - start + 1;
+    // every read adds one to the positions pos + 1 .. pos + length - 2: as +1 / -1 marks and one running sum per sample
+    // (the same integers as incrementing position by position)
     for (const RefReadSpan &r : reads) {
         if (r.pos < start || (unsigned)(r.pos + r.length) > end) continue;
         const int s = r.tag < sample_of.size() ? sample_of[r.tag] : -1;
         if (s < 0) continue;           // a sample without any mapped split read yet (the reference dereferences end())
         std::vector<int> &cov = ref_cov_[(size_t)s];
         if (cov.empty()) cov.assign(length, 0);
-        for (unsigned k = 1; k + 1 < r.length; k++) cov[r.pos - start + k]++;
+        if (r.length < 3) continue;
+        cov[r.pos - start + 1]++;
+        const size_t stop = (size_t)(r.pos - start) + r.length - 1;       // first position not covered any more
+        if (stop < length) cov[stop]--;
+    }
+    for (std::vector<int> &cov : ref_cov_) {
+        int run = 0;
+        for (int &v : cov) {
+            run += v;
+            v = run;
+        }
     }
 }
 

@@ -64,6 +64,7 @@ typedef unsigned int u32;
 // reads of up to 256 bases: the records of a claim are fetched at once into LDS (longer reads have no LDS to spare)
 #define PG_REC_LDS(nb) ((nb) <= 4)
 #define PG_CHR_TAB 24       // chromosomes whose word offset / size are kept in LDS (a read's first dependent load otherwise)
+#define PG_MM_IN_WIN(nb) ((nb) <= 4)
 
 __device__ __forceinline__ u64 ballot64(bool p) { return __ballot(p); }
 // DPP lane shifts (no LDS round trip).  row_shr:n moves lane i-n -> i inside each 16-lane row and
@@ -209,8 +210,10 @@ struct Lds {
     typename AccB<Id>::T accB[NB > 1 ? 64 * (NB - 1) : 1];   // reduction state of the rounds >= 1 (AccB)
     u64 qp[2 * 4 * NB];                       // the read's bit planes, two orientations
     uint16_t queue[64];                       // survivors of the prefilter for one candidate pass: (window position << 1) | kind
-    u32 mm_bp[PG_MM_BREAKS];                  // breakpoints of g_maxMismatch (copied from the kernel arguments)
-    uint8_t mm_tab[64 * NB + 64];             // g_maxMismatch[L] for every length a lane can own (filled once per workgroup)
+    // g_maxMismatch[L] for every length a lane can own (filled once per workgroup).  Up to 256-base reads the table
+    // lives in the fourth dword of the window entries (four lengths per dword; the fills write three dwords): the LDS
+    // it would take costs a resident workgroup per CU at NB = 3 and 4.
+    uint8_t mm_tab[PG_MM_IN_WIN(NB) ? 4 : 64 * NB + 64];
     u32 chr_tab[3 * PG_CHR_TAB];              // word offset (lo, hi) and size of the first PG_CHR_TAB chromosomes
     uint4 rec[PG_REC_LDS(NB) ? 2 * PG_CLAIM : 0];   // the packed records of the claimed reads (one coalesced load per claim)
 #ifdef PG_TIMING
@@ -228,7 +231,6 @@ struct Search {
     uint2 *hdrB;
     u64 *ringB;
     void *accB;
-    const u32 *mm_bp;
     const uint8_t *mm_tab;
     const u32 *chr_tab;
     int mm_j[2];         // g_maxMismatch[J] for the two filter depths J of this read (plain, wide): once per read
@@ -600,7 +602,7 @@ __device__ __forceinline__ void stage_window(const PgDevRef &ref, Search &S, lon
             const u32 x = __builtin_amdgcn_alignbit(glo[i + 1], glo[i], sh);
             const u32 y = __builtin_amdgcn_alignbit(ghi[i + 1], ghi[i], sh);
             const u32 z = __builtin_amdgcn_alignbit(gnn[i + 1], gnn[i], sh);
-            S.win[i] = make_uint4(x, y, z, 0u);
+            *(uint3 *)__builtin_assume_aligned(&S.win[i], 16) = make_uint3(x, y, z);        // (the fourth dword holds the table above)
         }
     }
     __syncthreads();
@@ -1110,9 +1112,12 @@ struct Eval {
 };
 
 // g_maxMismatch[L] for the lane's L (<= M for L <= len)
+template <int NB>
 __device__ __forceinline__ u32 mm_of(const Search &S, int L)
 {
-    return S.mm_tab[L];          // (L <= bps + 64 NB - 1 < the table's size; lanes past the read are masked by the caller)
+    // (L <= bps + 64 NB - 1 < the table's size; lanes past the read are masked by the caller)
+    if (PG_MM_IN_WIN(NB)) return (S.win[L >> 2].w >> (8 * (L & 3))) & 0xffu;
+    return S.mm_tab[L];
 }
 
 // The reference's rules for every L (lanes own L): "if (minimumNumberOfMismatches > g_maxMismatch[L]) return"
@@ -1185,7 +1190,7 @@ __device__ __forceinline__ void evaluate(Search &S, const Acc<NB, Id> &A, u32 mm
         Id wid = tid;
         if (r > 0) {
             m1 = m2 = PG_BIG; ok = 0u; wid = 0;
-            mmL = mm_of(S, L);
+            mmL = mm_of<NB>(S, L);
             if ((A.dirty >> r) & 1u) {                    // uniform
                 AccB<Id>::load(S.accB, (r - 1) * 64 + lane, m1, m2, ok, wid);
             }
@@ -1371,10 +1376,8 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     // g_maxMismatch at the two filter depths (<= M: the breakpoints from index M on lie beyond the read)
     {
         const int j0 = seed_depth(len, S.T, false), j1 = seed_depth(len, S.T, true);
-        const int bp = (int)S.mm_bp[lane & (PG_MM_BREAKS - 1)];          // lane k < M: breakpoint k
-        const bool mine = lane < S.M;
-        S.mm_j[0] = __popcll(ballot64(mine && j0 >= bp));
-        S.mm_j[1] = __popcll(ballot64(mine && j1 >= bp));
+        S.mm_j[0] = uni((int)mm_of<NB>(S, j0));
+        S.mm_j[1] = uni((int)mm_of<NB>(S, j1));
     }
     // The record is the read's first memory round trip; its bases and the window of the first close-end attempt are
     // the second: both are requested before either is used (the scan below finds the window resident).
@@ -1419,7 +1422,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
             S.bps = prm.min_close;
             S.len_check = prm.min_perfect >= S.bps;        // Min_Perfect_Match_Around_BP >= the first evaluated length
             S.tierA = S.bps + 16 <= 32 && !S.len_check;
-            const u32 mm0 = mm_of(S, S.bps + lane);
+            const u32 mm0 = mm_of<NB>(S, S.bps + lane);
             // Attempt 0 (the one that succeeds for most reads) stages and filters exactly its own window.  The
             // retries share work: the window of the attempts with R = 1 contains the one with R = 0, so from
             // attempt 1 on the chunk grid is anchored at the R = 1 window, which is staged once; attempts 1 and 2
@@ -1545,7 +1548,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
         Q.antisenseB = true;      // BACKWARD, ANTISENSE
         Q.first_ok = first_base_ok<NB>(Q);
         if (Q.first_ok) {
-            const u32 mm0 = mm_of(S, 10 + lane);
+            const u32 mm0 = mm_of<NB>(S, 10 + lane);
             const int chr_size = chr_size_of(ref, S, chr);
             int far_bases = 0;
             // a search window's result replaces UP_Far if its MaxLen is >= (NewUPFarIsBetter, farend_searcher.cpp:30-44)
@@ -1764,8 +1767,15 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
 {
     __shared__ Lds<NB, Id> lds;
     const int lane = threadIdx.x;
-    if (lane < PG_MM_BREAKS) lds.mm_bp[lane] = prm.mm_bp[lane];
-    for (int L = lane; L < 64 * NB + 64; L += WAVE) lds.mm_tab[L] = (uint8_t)max_mismatch_at(prm.mm_bp, L);
+    if (PG_MM_IN_WIN(NB)) {
+        for (int w = lane; w < 16 * NB + 16; w += WAVE) {
+            u32 v = 0u;
+#pragma unroll
+            for (int k = 0; k < 4; k++) v |= (u32)max_mismatch_at(prm.mm_bp, 4 * w + k) << (8 * k);
+            lds.win[w].w = v;
+        }
+    } else
+        for (int L = lane; L < 64 * NB + 64; L += WAVE) lds.mm_tab[L] = (uint8_t)max_mismatch_at(prm.mm_bp, L);
     if (lane < PG_CHR_TAB && lane < ref.n_chr) {
         const u64 wo = ref.chr_word_off[lane];
         lds.chr_tab[3 * lane] = (u32)wo;
@@ -1781,7 +1791,6 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
     S.hdrB = lds.hdrB;
     S.ringB = lds.ringB;
     S.accB = lds.accB;
-    S.mm_bp = lds.mm_bp;
     S.mm_tab = lds.mm_tab;
     S.chr_tab = lds.chr_tab;
     S.rec = lds.rec;
