@@ -30,7 +30,7 @@ if ROOT not in sys.path:
 
 CHR20_LEN = 62_435_964       # demo/hs_ref_chr20.fa.fai:1
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
 TRAFFIC_FILE = "hbm_traffic.json"
 PMC_FILE = "pmc_sq.txt"
 
@@ -100,14 +100,16 @@ def measured_traffic(args, reads_per_launch):
     with open(path) as fh:
         t = json.load(fh)
     per_read = t["fetch_bytes_per_read"] + t["write_bytes_per_read_uncalibrated"]
-    return per_read * reads_per_launch, (f"profiles/r02/{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+    return per_read * reads_per_launch, (f"profiles/r03/{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                           "separate passes, per read x reads per launch)")
 
 
 def issue_model(args, kernel_ms, reads_per_launch):
-    """The kernel is instruction-issue bound, not HBM bound.  Instructions per read from
-    the committed PMC pass; issue costs from profiles/r02/ubench_issue_rates.txt (measured on MI355X): a SIMD
-    issues a plain wave64 VALU op every 2 cycles and the CU's scalar unit ~1 op per cycle."""
+    """The kernel is instruction-issue bound, not HBM bound.  Instructions per read and lane
+    occupancy from the committed PMC passes of this round (profiles/r03/pmc_sq.txt); issue costs from the microbenchmark
+    (profiles/r02/ubench_issue_rates.txt, MI355X): a SIMD issues a plain 2-operand wave64 VALU op every 2.0 cycles and a
+    3-operand / DPP / lane-access op every 3.2 cycles (most of this kernel's bit operations), the CU's one scalar unit
+    1.0-1.35 ops per cycle.  Both VALU bounds are given; the truth lies between them, nearer the upper one."""
     path = os.path.join(PROFILE_DIR, PMC_FILE)
     if not default_workload(args) or not os.path.exists(path) or kernel_ms <= 0:
         return None
@@ -120,12 +122,20 @@ def issue_model(args, kernel_ms, reads_per_launch):
     if "SQ_INSTS_VALU" not in c:
         return None
     valu, salu = c["SQ_INSTS_VALU"], c.get("SQ_INSTS_SALU", 0.0)
-    valu_ms = valu * reads_per_launch * 2.0 / (1024 * 2.4e9) * 1e3
-    salu_ms = salu * reads_per_launch * 1.0 / (256 * 2.4e9) * 1e3
-    return {"valu_insts_per_read": valu, "salu_insts_per_read": salu,
-            "valu_issue_ms_at_2_cycles": valu_ms, "salu_issue_ms_at_1_per_cu_cycle": salu_ms,
-            "valu_busy_frac": valu_ms / kernel_ms, "salu_busy_frac": salu_ms / kernel_ms,
-            "source": f"profiles/r02/{PMC_FILE} + profiles/r02/ubench_issue_rates.txt, 256 CUs x 4 SIMDs, 2.4 GHz nominal"}
+    per_simd = reads_per_launch / 1024.0                       # 256 CUs x 4 SIMDs
+    cyc = kernel_ms * 1e-3 * 2.4e9
+    out = {"valu_insts_per_read": valu, "salu_insts_per_read": salu,
+           "valu_busy_frac_at_2p0_cycles": valu * per_simd * 2.0 / cyc,
+           "valu_busy_frac_at_3p2_cycles": valu * per_simd * 3.2 / cyc,
+           "salu_busy_frac_at_1_per_cu_cycle": salu * reads_per_launch / 256.0 / cyc,
+           "source": f"profiles/r03/{PMC_FILE} + profiles/r02/ubench_issue_rates.txt, 256 CUs x 4 SIMDs, 2.4 GHz nominal"}
+    if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_ACTIVE_INST_VALU"):
+        # active lanes per executed VALU instruction (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU), of 64
+        out["valu_active_lanes_per_inst"] = c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"]
+        out["valu_lane_utilisation"] = out["valu_active_lanes_per_inst"] / 64.0
+    if c.get("SQ_WAIT_INST_ANY") and c.get("SQ_WAVE_CYCLES"):
+        out["wave_cycles_waiting_frac"] = c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"]
+    return out
 
 
 def self_spawn(args):

@@ -874,6 +874,22 @@ int pg_create(const pg_params *p, pg_ctx **out)
         delete ctx;
         return PG_E_DEVICE;
     }
+    // The persistent launch spreads its read counters over PG_N_XCD = 8 parts and relies on workgroup b running on XCD
+    // b % 8 for locality (never for correctness: a workgroup that finds its part empty moves on to the next).  The
+    // MI355X reports 256 compute units in 8 XCDs; on anything else the search still works, the note says what was found.
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, p->device) == hipSuccess) {
+            const std::string arch = prop.gcnArchName;
+            if (arch.rfind("gfx950", 0) != 0) {
+                pg_destroy(ctx);
+                return PG_E_DEVICE;                     // the library holds gfx950 code only
+            }
+            if (prop.multiProcessorCount != 256 && getenv("PG_QUIET") == nullptr)
+                fprintf(stderr, "pindel_pg: note: device %d reports %d compute units (an MI355X has 256 in 8 XCDs); the per-XCD "
+                                "work split stays correct but was tuned for that shape\n", p->device, prop.multiProcessorCount);
+        }
+    }
     // the kernel evaluates g_maxMismatch[L] from breakpoints: the table must be monotone (it is for every
     // -e/-E tried).  Whether a batch fits the 16 mismatch levels depends on its longest read and is checked
     // per batch (validate_and_measure).

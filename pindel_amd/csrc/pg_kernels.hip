@@ -1400,9 +1400,6 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     make_planes<NB>(rb, len, opaque(lane), qplanes);
 #endif
 
-#if defined(PG_STOP) && PG_STOP == 1
-    return;                                           // diagnostics: instruction count up to here
-#endif
     PG_T(S, 0);
     const bool do_close = (mode & PG_MODE_CLOSE) != 0, do_far = (mode & PG_MODE_FAR) != 0;
     int flipped = 0, close_max = 0, n_close = 0;
@@ -1469,9 +1466,6 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                                    opaque(lane), att == 1 || att == 2, cr0, cr1, vr);
                 ps = s1;
                 pe = e1;
-#if defined(PG_STOP) && PG_STOP == 2
-                if (A.m1 != 0x54321u) return;         // diagnostics: first attempt up to the end of its scan
-#endif
                 if (S.nsurv != nsurv_eval) {
                     nsurv_eval = S.nsurv;
                     Eval<NB, Id> E;
@@ -1481,10 +1475,6 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
 #endif
                     evaluate<NB, Id>(S, A, mm0, E, opaque(lane));
                     close_max = uni(E.max_len);
-#if defined(PG_STOP) && PG_STOP == 6
-                    if (lane == 0) B.out[rid].alg = (u32)(close_max + E.n_runs);   // diagnostics: first attempt incl. its evaluation
-                    return;
-#endif
                     if (uni(E.n_runs) > 0) {
                         u64 kept[NB];
                         n_close = uni(count_kept<NB, Id>(E, true, kept));
@@ -1499,16 +1489,9 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                         const u64 idl = (u64)E.id_last;
                         const int pl = w1s + (int)(u32)(idl & ((1ull << IdFmt<Id>::RB) - 1ull));
                         close_last = ((idl >> IdFmt<Id>::RB) & 1ull) ? (u32)(pl - close_max + 1) : (u32)(pl + close_max - 1);
-#if defined(PG_STOP) && PG_STOP == 7
-                        if (lane == 0) B.out[rid].alg = (u32)(n_close + close_max + close_last);   // diagnostics: + emission
-                        return;
-#endif
                         break;
                     }
                 }
-#if defined(PG_STOP) && (PG_STOP == 6 || PG_STOP == 7)
-                return;                                   // diagnostics: the first attempt found nothing
-#endif
             }
         }
         if (n_close == 0) { flipped = 0; close_max = 0; }       // back to the original orientation
@@ -1522,10 +1505,6 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
         alg = (u32)uni((int)o1.z) << 3;
     }
 
-#if defined(PG_STOP) && PG_STOP == 3
-    if (lane == 0) B.out[rid].alg = (u32)(n_close + close_max + close_last);   // diagnostics: the whole close end
-    return;
-#endif
     // ------------------------------------------------------------------------------- far end
 #ifdef PG_TIMING
     PG_T(S, S.t_base + 2);
@@ -1720,16 +1699,10 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                     }
                     // an evaluation can only differ from the previous one if candidates were folded since; an
                     // empty state yields no point ("NumberOfHits == 0" leaves UP_Far untouched, farend_searcher.cpp:87)
-#if defined(PG_STOP) && PG_STOP == 4
-                    if (A.m1 != 0x54321u) break;      // diagnostics: + far end up to the end of the first range's scan
-#endif
                     if (S.nsurv != nsurv_eval) {
                         nsurv_eval = S.nsurv;
                         far_update(origin, nullptr, 15);
                     }
-#if defined(PG_STOP) && PG_STOP == 5
-                    break;                            // diagnostics: + first range's evaluation
-#endif
                     if (far_max + close_max >= len) break;       // goodFarEndFound
                 }
                 far_bases += (pe - ps) + 2 * len;

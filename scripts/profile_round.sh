@@ -23,13 +23,21 @@ f=$(find /tmp/rp_stats -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && head -12 "$f" > "$out/kernel_stats.csv"
 
 LIBSO=$root/pindel_amd/libpindel_pg.so
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE \
-    --output-format csv -d /tmp/rp_sq -- python "$root/scripts/run_variant.py" "$LIBSO" "$reads" > /tmp/rp_sq.log 2>&1
-python "$root/scripts/pmc_brief.py" /tmp/rp_sq "$reads" > "$out/pmc_sq.txt"
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT \
-    --output-format csv -d /tmp/rp_sq2 -- python "$root/scripts/run_variant.py" "$LIBSO" "$reads" > /tmp/rp_sq2.log 2>&1
-python "$root/scripts/pmc_brief.py" /tmp/rp_sq2 "$reads" >> "$out/pmc_sq.txt"
+pmc_set() {   # pmc_set <outfile> <env...>: the SQ counter passes of the search kernel (bench workload unless PG_X / PG_LEN say otherwise)
+    local out_file=$1; shift
+    : > "$out_file"
+    for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+               "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT" \
+               "SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_BRANCH SQ_IFETCH SQC_ICACHE_MISSES SQ_INST_LEVEL_VMEM"; do
+        rm -rf /tmp/rp_sq
+        env "$@" rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/rp_sq -- python "$root/scripts/run_variant.py" "$LIBSO" "$reads" > /tmp/rp_sq.log 2>&1
+        python "$root/scripts/pmc_brief.py" /tmp/rp_sq "$reads" >> "$out_file"
+    done
+}
+pmc_set "$out/pmc_sq.txt" PG_NONE=1
 cat "$out/pmc_sq.txt"
+pmc_set "$out/pmc_sq_x5.txt" PG_X=5
+pmc_set "$out/pmc_sq_150bp.txt" PG_LEN=150
 
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/rp_fetch -- python "$root/scripts/run_variant.py" "$LIBSO" "$reads" > /tmp/rp_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/rp_write -- python "$root/scripts/run_variant.py" "$LIBSO" "$reads" > /tmp/rp_write.log 2>&1
@@ -37,22 +45,42 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/rp_calib -
 python "$root/scripts/traffic_summary.py" /tmp/rp_fetch /tmp/rp_write /tmp/rp_calib "$reads" "$out/bench_under_rocprof.json" > "$out/hbm_traffic.json"
 cat "$out/hbm_traffic.json"
 
-# per-phase instruction counts: cumulative SQ_INSTS_* per read of builds that return early (-DPG_STOP=k, built
-# here by scripts/build_variant.sh stop$k -DPG_STOP=$k before the gpurun call)
+# kernel_stats for -x 5 and 150 bp as well
+for v in "x5 --max-range-index 5" "150bp --read-len 150"; do
+    set -- $v
+    tag2=$1; shift
+    rm -rf /tmp/rp_stats2
+    rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stats2 -- \
+        python "$root/bench.py" --reads "$reads" --steps 3 --warmup 1 --no-cpu-baseline --no-host-path "$@" > "$out/bench_under_rocprof_$tag2.json" 2> /tmp/rp_stats2.err
+    f=$(find /tmp/rp_stats2 -name '*kernel_stats.csv' | head -1)
+    [ -n "$f" ] && head -8 "$f" > "$out/kernel_stats_$tag2.csv"
+done
+
+# the host path with a download: the delivery kernels (HBM-bound) next to the search kernel
+rm -rf /tmp/rp_host
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_host -- python "$root/scripts/host_path_rate.py" 4000000 > "$out/host_path_rate.txt" 2> /tmp/rp_host.err
+f=$(find /tmp/rp_host -name '*kernel_stats.csv' | head -1)
+[ -n "$f" ] && head -14 "$f" > "$out/kernel_stats_host_path.csv"
+python "$root/scripts/host_path_rate.py" 50000 | tail -1 >> "$out/host_path_rate.txt"
+
+# wave-cycles per phase of a read (s_memtime at the phase boundaries; -DPG_TIMING build made by scripts/build_variant.sh tim)
 cd "$root" || exit 1
-{
-    echo "# cumulative instructions per read of builds that stop early (bench workload, $reads reads)"
-    echo "# stop1 = record + read planes loaded, window of the first close-end attempt filled; stop2 = + close end, first attempt up to the end of its scan; stop6 = + its evaluation;"
-    echo "# stop7 = + emission of its points; stop3 = whole close end (retries included); stop4 = + far end up to the end of"
-    echo "# the first range's scan; stop5 = + its evaluation; full = the shipped kernel"
-    for k in 1 2 6 7 3 4 5; do
-        [ -f pindel_amd/libpindel_pg_stop$k.so ] || continue
-        echo "stop$k"
-        bash scripts/pmc_pass.sh pindel_amd/libpindel_pg_stop$k.so "$reads" | grep -E "VALU|SALU|INSTS_LDS|VMEM"
-    done
-    echo "full"
-    bash scripts/pmc_pass.sh pindel_amd/libpindel_pg.so "$reads" | grep -E "VALU|SALU|INSTS_LDS|VMEM"
-} > "$out/phase_instruction_counts.txt"
+if [ -f pindel_amd/libpindel_pg_tim.so ]; then
+    {
+        python scripts/phase_timing.py pindel_amd/libpindel_pg_tim.so 1000000
+        echo "== -x 5"
+        PG_X=5 python scripts/phase_timing.py pindel_amd/libpindel_pg_tim.so 500000
+        echo "== 150 bp"
+        PG_LEN=150 python scripts/phase_timing.py pindel_amd/libpindel_pg_tim.so 1000000
+    } 2>/dev/null > "$out/phase_wave_cycles.txt"
+fi
+if [ -f pindel_amd/libpindel_pg_diag.so ]; then
+    {
+        python scripts/diag_counts.py pindel_amd/libpindel_pg_diag.so 1000000
+        echo "== -x 5"
+        PG_X=5 python scripts/diag_counts.py pindel_amd/libpindel_pg_diag.so 500000
+    } 2>/dev/null > "$out/per_read_event_counts.txt"
+fi
 
 # the other workloads and parameter points quoted in DESIGN.md section 8 (one bench line each)
 {
@@ -62,6 +90,7 @@ cd "$root" || exit 1
     python bench.py --steps 3 --warmup 1 --max-range-index 5 --reads 2000000 --no-cpu-baseline --no-host-path 2>/dev/null | tail -1
     python bench.py --steps 3 --warmup 1 --read-len 150 --no-cpu-baseline --no-host-path 2>/dev/null | tail -1
     python bench.py --steps 3 --warmup 1 --read-len 250 --reads 4000000 --no-cpu-baseline --no-host-path 2>/dev/null | tail -1
+    python bench.py --steps 3 --warmup 1 --read-len 400 --reads 2000000 --no-cpu-baseline --no-host-path 2>/dev/null | tail -1
 } > "$out/bench_workloads.jsonl"
 python - "$out/bench_workloads.jsonl" <<'PY'
 import json, sys
@@ -70,3 +99,4 @@ for l in open(sys.argv[1]):
         d = json.loads(l)
         print(d["config"]["workload"][:70], "|", round(d["value"] / 1e6, 1), "M reads/s | cand/read", round(d["config"].get("candidates_per_read", 0), 1))
 PY
+

@@ -32,3 +32,14 @@ def test_bench_workload_properties(engine_factory):
     eng.load_reference(chroms)
     n_close, n_far = check_workload(eng, chroms, batch)
     assert n_close > 0.7 * N_READS and n_far > 0.5 * N_READS
+    # The workload is seeded: the checksum of checksums bench.py prints as config.result_sha256 (one 64-bit digest per
+    # read over its rc flag and run lists, sha256 over the digests) is a constant of the repository.  It has been
+    # ec6c3a18... since the round-1 kernel; a kernel change that alters ANY read's result alters it.
+    from pindel_amd import shard
+    db = eng.upload(batch)
+    eng.search_device(db)
+    res = eng.download(db)
+    eng.free_device_batch(db)
+    assert int(res.close_off[-1]) + int(res.far_off[-1]) == 25663994
+    assert int((res.far_off[1:] > res.far_off[:-1]).sum()) == 6290009
+    assert shard.digest_hex(shard.read_digests(res)) == "ec6c3a18d3adc53802a769355a3129f4668632c3072f87679b6c1b245b94c19f"
