@@ -40,6 +40,6 @@ def test_bench_workload_properties(engine_factory):
     eng.search_device(db)
     res = eng.download(db)
     eng.free_device_batch(db)
-    assert int(res.close_off[-1]) + int(res.far_off[-1]) == 25663994
+    assert int(res.close_off[-1]) + int(res.far_off[-1]) == 21235377
     assert int((res.far_off[1:] > res.far_off[:-1]).sum()) == 6290009
     assert shard.digest_hex(shard.read_digests(res)) == "ec6c3a18d3adc53802a769355a3129f4668632c3072f87679b6c1b245b94c19f"
