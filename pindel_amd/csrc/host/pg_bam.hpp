@@ -60,6 +60,7 @@ public:
         block_len_ = 0;
         pos_ = 0;
         eof_ = false;
+        bad_ = false;
         return f_ != nullptr;
     }
     void close()
@@ -82,7 +83,7 @@ public:
         data_.clear();
         pos_ = 0;
         eof_ = false;
-        if (!load_block()) return (voff & 0xffff) == 0;
+        if (!load_block()) return !bad_ && (voff & 0xffff) == 0;
         pos_ = (size_t)(voff & 0xffff);
         return pos_ <= data_.size();
     }
@@ -106,34 +107,44 @@ public:
         return true;
     }
     bool ok() const { return f_ != nullptr; }
+    // a corrupt or truncated block was met (as opposed to the clean end of the file)
+    bool failed() const { return bad_; }
+    void mark_failed() { bad_ = true; }
 
 private:
+    bool fail()
+    {
+        bad_ = true;
+        return false;
+    }
     bool load_block()
     {
         data_.clear();
         pos_ = 0;
         for (;;) {                                       // skip empty blocks (the end-of-file marker is one)
             uint8_t h[18];
-            if (fread(h, 1, 18, f_) != 18) {
+            const size_t got = fread(h, 1, 18, f_);
+            if (got != 18) {
                 eof_ = true;
+                if (got != 0) bad_ = true;               // a truncated block header is not a clean end of file
                 return false;
             }
-            if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return false;
+            if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return fail();
             const unsigned xlen = h[10] | (h[11] << 8);
             // the BC subfield is the first one in every BGZF writer; search the extra field to be safe
             std::vector<uint8_t> extra(xlen);
             memcpy(extra.data(), h + 12, std::min<size_t>(6, xlen));
-            if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, f_) != xlen - 6) return false;
+            if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, f_) != xlen - 6) return fail();
             unsigned bsize = 0;
             for (size_t i = 0; i + 4 <= xlen;) {
                 const unsigned slen = extra[i + 2] | (extra[i + 3] << 8);
                 if (extra[i] == 'B' && extra[i + 1] == 'C' && slen == 2 && i + 6 <= xlen) bsize = (extra[i + 4] | (extra[i + 5] << 8)) + 1u;
                 i += 4 + slen;
             }
-            if (bsize < 12 + xlen + 8) return false;
+            if (bsize < 12 + xlen + 8) return fail();
             const size_t clen = bsize - 12 - xlen - 8;
             comp_.resize(clen + 8);
-            if (fread(comp_.data(), 1, clen + 8, f_) != clen + 8) return false;
+            if (fread(comp_.data(), 1, clen + 8, f_) != clen + 8) return fail();
             const uint32_t isize = comp_[clen + 4] | (comp_[clen + 5] << 8) | (comp_[clen + 6] << 16) | ((uint32_t)comp_[clen + 7] << 24);
             block_len_ = bsize;
             if (isize == 0) {
@@ -144,14 +155,14 @@ private:
             data_.resize(isize);
             z_stream zs;
             memset(&zs, 0, sizeof zs);
-            if (inflateInit2(&zs, -15) != Z_OK) return false;
+            if (inflateInit2(&zs, -15) != Z_OK) return fail();
             zs.next_in = comp_.data();
             zs.avail_in = (uInt)clen;
             zs.next_out = data_.data();
             zs.avail_out = isize;
             const int zr = inflate(&zs, Z_FINISH);
             inflateEnd(&zs);
-            if (zr != Z_STREAM_END || zs.total_out != isize) return false;
+            if (zr != Z_STREAM_END || zs.total_out != isize) return fail();
             return true;
         }
     }
@@ -159,7 +170,7 @@ private:
     uint64_t block_addr_ = 0, block_len_ = 0;
     std::vector<uint8_t> data_, comp_;
     size_t pos_ = 0;
-    bool eof_ = false;
+    bool eof_ = false, bad_ = false;
 };
 
 // ------------------------------------------------------------------------------------------ BAM records
@@ -301,10 +312,17 @@ public:
     bool next(BamRecord &r)
     {
         int32_t block_size = 0;
-        if (!z_.read(&block_size, 4) || block_size < 32) return false;
+        if (!z_.read(&block_size, 4)) return false;       // the end of the file, or a bad block (z_.failed())
+        if (block_size < 32) {
+            z_.mark_failed();
+            return false;
+        }
         buf_.resize((size_t)block_size);
-        if (!z_.read(buf_.data(), (size_t)block_size)) return false;
-        return decode(buf_.data(), (size_t)block_size, r);
+        if (!z_.read(buf_.data(), (size_t)block_size) || !decode(buf_.data(), (size_t)block_size, r)) {
+            z_.mark_failed();                             // a record cut short or inconsistent: never a clean end
+            return false;
+        }
+        return true;
     }
     // the bytes of the record `next` delivered last (block_size bytes, without the length word)
     const std::vector<uint8_t> &last_raw() const { return buf_; }
@@ -347,7 +365,7 @@ public:
             if (!z_.seek(first_record_)) return false;
             while (next(r))
                 if (r.tid == tid && r.pos < end && r.end_pos() > beg) fn(r);
-            return true;
+            return !z_.failed();                          // a damaged file must not pass for a short one
         }
         const BaiBins &bins_ = idx_->bins;
         const std::vector<std::vector<uint64_t>> &linear_ = idx_->linear;
@@ -384,6 +402,7 @@ public:
             if (!z_.seek(c.first)) return false;
             while (z_.tell() < c.second && next(r))
                 if (r.tid == tid && r.pos < end && r.end_pos() > beg) fn(r);
+            if (z_.failed()) return false;
         }
         return true;
     }

@@ -203,12 +203,21 @@ static thread_local std::vector<EvMark> *tl_box_marks = nullptr;
 
 std::ostream &operator<<(std::ostream &out, Caller::EvNo e)
 {
+    // An event number is only known when the boxes are written out in order: inside for_boxes the place is recorded and
+    // the number put in later.  Anywhere else there is nothing to put it in later -- a report written that way would
+    // silently lack its event numbers, so that is a programming error, loudly.
+    bool marked = false;
     if (tl_box_out)
         for (int k = 0; k < 4; k++)
             if (&out == static_cast<std::ostream *>(&tl_box_out[k])) {
                 tl_box_marks[k].push_back(EvMark{ (size_t)out.tellp(), (int)e.kind });
+                marked = true;
                 break;
             }
+    if (!marked) {
+        fprintf(stderr, "pgh: event number written outside Caller::for_boxes (reporter called on the wrong stream)\n");
+        abort();
+    }
     return out;
 }
 

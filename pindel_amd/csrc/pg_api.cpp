@@ -35,7 +35,8 @@ struct PinnedCache {
     std::mutex mu;
     std::vector<std::pair<void *, size_t>> free_blocks;
     size_t cached_bytes = 0;
-    static const size_t kMaxCached = (size_t)6 << 30;
+    // page-locked memory kept for reuse: 6 GiB unless PG_PINNED_CACHE_MB says otherwise (0 = no caching)
+    const size_t kMaxCached = getenv("PG_PINNED_CACHE_MB") ? (size_t)std::max(0L, atol(getenv("PG_PINNED_CACHE_MB"))) << 20 : (size_t)6 << 30;
     void *get(size_t bytes, size_t *got)
     {
         {
@@ -55,7 +56,8 @@ struct PinnedCache {
         }
         void *p = nullptr;
         const size_t want = (bytes + 4095) & ~(size_t)4095;
-        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+        // portable: a cached block may be reused by a context on another GPU
+        if (hipHostMalloc(&p, want, hipHostMallocPortable) != hipSuccess) return nullptr;
         *got = want;
         return p;
     }
@@ -71,8 +73,21 @@ struct PinnedCache {
         }
         (void)hipHostFree(p);
     }
+    // releases every cached block (when the last context of the process goes away)
+    void trim()
+    {
+        std::vector<std::pair<void *, size_t>> gone;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            gone.swap(free_blocks);
+            cached_bytes = 0;
+        }
+        for (auto &b : gone) (void)hipHostFree(b.first);
+    }
 };
 PinnedCache g_pinned;
+std::mutex g_ctx_mu;
+int g_live_ctx = 0;
 
 template <typename T>
 struct HostBuf {
@@ -185,6 +200,7 @@ struct pg_ctx {
     double last_ms = 0.0;
     uint64_t last_runs = 0;
     std::string err;
+    bool counted = false;              // in g_live_ctx (the pinned-memory cache is trimmed with the last context)
 };
 
 struct pg_device_batch {
@@ -902,6 +918,11 @@ int pg_create(const pg_params *p, pg_ctx **out)
         pg_destroy(ctx);
         return PG_E_DEVICE;
     }
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        g_live_ctx++;
+        ctx->counted = true;
+    }
     *out = ctx;
     return PG_OK;
 }
@@ -910,6 +931,14 @@ void pg_destroy(pg_ctx *ctx)
 {
     use_device(ctx);
     if (!ctx) return;
+    if (ctx->counted) {
+        bool last;
+        {
+            std::lock_guard<std::mutex> lk(g_ctx_mu);
+            last = --g_live_ctx == 0;
+        }
+        if (last) g_pinned.trim();                   // the page-locked result buffers cached for reuse
+    }
     free_reference(ctx);
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
     if (ctx->d_thr) (void)hipFree(ctx->d_thr);

@@ -690,3 +690,38 @@ def test_command_line_read_pair_hints_find_large_deletions(tmp_path):
     run("sharded", "-G", "0,0")
     for sfx in ("_D", "_SI", "_TD", "_INV", "_RP"):
         assert filecmp.cmp(tmp_path / ("hinted" + sfx), tmp_path / ("sharded" + sfx), shallow=False), sfx
+
+
+def test_damaged_bam_is_an_error_not_a_short_file(tmp_path):
+    """A corrupt or truncated BGZF block must fail the window ("BAM read failed"), not end it quietly with a partial
+    read set (the clean end-of-file marker is the only way a file may end)."""
+    rng = np.random.default_rng(3)
+    recs = _messy_records(rng, 3000, 1_000_000)
+    bam = tmp_path / "ok.bam"
+    bw.write_bam(str(bam), [("chrZ", 1_000_000)], recs, with_index=True, block_bytes=0x4000)
+    good = ingest(bam, "chrZ", 0, 1_200_000, 0, 1_000_000, 450)
+    assert len(good) > 500
+    data = bytearray(open(bam, "rb").read())
+    L = _lib()
+    n, nb = C.c_uint64(), C.c_uint64()
+
+    def try_ingest(path, use_index):
+        return L.pgh_bam_ingest(str(path).encode(), b"chrZ", 0, 1_200_000, 0, 1_000_000, 450, b"S", 0, 100000, 1 if use_index else 0,
+                                C.byref(n), C.byref(nb))
+    # flipped bytes in the middle of the compressed stream
+    bad = bytearray(data)
+    mid = len(bad) // 2
+    for k in range(64):
+        bad[mid + k] ^= 0x5a
+    p1 = tmp_path / "flipped.bam"
+    open(p1, "wb").write(bad)
+    shutil_copy = __import__("shutil").copy
+    shutil_copy(str(bam) + ".bai", str(p1) + ".bai")
+    for use_index in (True, False):
+        assert not try_ingest(p1, use_index), "a corrupt block was read as the end of the file"
+        assert b"BAM read failed" in L.pgh_last_error()
+    # cut in the middle of a block (no end-of-file marker)
+    p2 = tmp_path / "cut.bam"
+    open(p2, "wb").write(data[:len(data) * 2 // 3])
+    assert not try_ingest(p2, False)
+    assert b"BAM read failed" in L.pgh_last_error()
