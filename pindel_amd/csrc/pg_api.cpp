@@ -474,7 +474,7 @@ int validate_and_measure(pg_ctx *ctx, const pg_read_batch *reads, uint32_t *max_
 
 // Runs per list the chunked delivery of search_host has room for (1.04 per read on average; a batch that needs more
 // falls back to the whole-batch download).
-static size_t deliver_cap(size_t n) { return 3 * n + 1024; }
+static size_t deliver_cap(size_t n) { return getenv("PG_TEST_TINY_DELIVERY") ? n / 2 + 8 : 3 * n + 1024; }   // (tests: force the fallback)
 
 // Validates the batch and allocates its device buffers.  copy = true also copies the inputs
 // (synchronously); otherwise the caller streams them in (search_host).  off = read offsets rebased to 0.

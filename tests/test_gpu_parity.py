@@ -221,6 +221,18 @@ def test_pool_overflow_is_retried_on_the_gpu(engine_factory, small_ref, monkeypa
     compare_result(gpu, orc, batch.n)
 
 
+def test_delivery_overflow_falls_back_to_the_whole_batch_download(engine_factory, small_ref, monkeypatch):
+    """The chunk-by-chunk delivery of pg_search_batch has room for three runs per read and list; a batch that needs more
+    is downloaded the whole-batch way instead (forced here with room for half a run per read)."""
+    eng = engine_factory()
+    eng.load_reference(small_ref)
+    batch = synth.make_reads(small_ref[0][1], 5000, seed=15)
+    orc = run_oracle({}, small_ref, batch)
+    monkeypatch.setenv("PG_TEST_TINY_DELIVERY", "1")
+    compare_result(eng.search_batch(batch), orc, batch.n)
+    compare_result(eng.close_end_batch(batch), orc, batch.n, check_far=False)
+
+
 def test_wide_cells_and_split_launches(engine_factory, small_ref, monkeypatch):
     """The 64-bit candidate ids and the two-launch form (close kernel, then far kernel) on a default
     workload give the same result as the default (32-bit ids, one fused launch)."""
@@ -564,3 +576,31 @@ def test_more_than_16_mismatch_levels(engine_factory, small_ref):
     orc = run_oracle(kw, small_ref, batch)
     assert (orc["close_cnt"] > 0).sum() > 400 and (orc["far_cnt"] > 0).sum() > 200
     compare_result(gpu, orc, batch.n)
+
+
+def test_host_pipeline_chunk_boundaries_equal_the_device_resident_path(engine_factory, small_ref):
+    """pg_search_batch streams a batch through the GPU in 2^18-read chunks (copy / search on two kernel streams / deliver /
+    download); whatever the batch size relative to the chunk -- one read, a chunk minus / plus one, several chunks with a
+    ragged tail -- the result is the one of the device-resident entry points on the same reads, and so is the close-end
+    only form (pg_close_end_batch).  One size is also checked against the oracle."""
+    from pindel_amd import shard
+    eng = engine_factory()
+    eng.load_reference(small_ref)
+    chunk = 1 << 18
+    big = synth.make_reads(small_ref[0][1], 2 * chunk + 4097, seed=91, read_lens=[100, 76, 120])
+    for n in (1, 255, chunk - 1, chunk, chunk + 1, big.n):
+        b = big.slice(0, n)
+        host = shard.result_arrays(eng.search_batch(b))
+        db = eng.upload(b)
+        eng.search_device(db)
+        dev = shard.result_arrays(eng.download(db))
+        eng.free_device_batch(db)
+        for k in ("close_off", "far_off", "rc_flag"):
+            assert np.array_equal(host[k], dev[k]), (n, k)
+        for k in ("close_runs", "far_runs"):
+            assert host[k].tobytes() == dev[k].tobytes(), (n, k)
+        close = eng.close_end_batch(b)
+        assert np.array_equal(close.close_off, dev["close_off"]) and close.close_runs.tobytes() == dev["close_runs"].tobytes()
+        assert np.array_equal(close.rc_flag, dev["rc_flag"]) and int(close.far_off[-1]) == 0
+    small = big.slice(chunk - 3000, chunk + 3000)              # (reads on both sides of a chunk boundary of the full batch)
+    compare_result(eng.search_batch(small), run_oracle({}, small_ref, small), small.n)
