@@ -1323,6 +1323,8 @@ static int search_host(pg_ctx *ctx, const pg_read_batch *reads, int mode, pg_res
     double t_alloc = now_ms();
     pg_result *r = nullptr;
     auto bail = [&](int code) {
+        // on an error nothing queued on the four streams may outlive the buffers it points at
+        if (code) (void)hipDeviceSynchronize();
         free_batch_buffers(b);
         delete b;
         if (code && r) delete r;
