@@ -560,6 +560,16 @@ struct IngestedReads {
     }
 };
 
+// PGH_TIMING diagnostics: seconds spent in the three parts of the indexed ingest, summed over the windows of a run
+struct IngestTiming {
+    double inflate_decode = 0, select = 0, layout = 0;
+};
+inline IngestTiming &ingest_timing()
+{
+    static IngestTiming t;
+    return t;
+}
+
 class BamIngest {
 public:
     explicit BamIngest(const BamIngestSettings &s) : S(s) {}
@@ -610,6 +620,8 @@ public:
                 std::vector<uint32_t> hash;        // hash of each record's read name
             };
             std::vector<Part> parts(nt);
+            auto clock_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+            double t_mark = clock_s();
             if (!bam.query_split(tid, win_start, win_end, nt, [&](unsigned t, const BamRecord &rec, const BamFile &reader) {
                     const std::vector<uint8_t> &raw = reader.last_raw();
                     parts[t].bytes.insert(parts[t].bytes.end(), raw.begin(), raw.end());
@@ -641,6 +653,8 @@ public:
                 }
             }
             const size_t N = recs.size();
+            ingest_timing().inflate_decode += clock_s() - t_mark;
+            t_mark = clock_s();
             const unsigned T2 = (unsigned)std::max<size_t>(1, std::min<size_t>(BamFile::worker_threads(), N / 20000 + 1));
             struct Emit {
                 IngestedReads out;
@@ -695,6 +709,8 @@ public:
                     error = e.error;
                     return false;
                 }
+            ingest_timing().select += clock_s() - t_mark;
+            t_mark = clock_s();
             // layout in trigger order: reads (and reference reads) per trigger, prefix sums, every thread moves its own
             std::vector<uint32_t> rstart(N + 1, 0), fstart(N + 1, 0);
             for (const Emit &e : em) {
@@ -766,6 +782,7 @@ public:
             for (size_t g = 0; g < M; g++) out.batch.off[base + g + 1] = out.batch.off[base + g] + lens[g];
             out.batch.seq.resize((size_t)out.batch.off[base + M]);
             on_threads(true);
+            ingest_timing().layout += clock_s() - t_mark;
             return true;
         }
         const bool q = bam.query(tid, win_start, win_end, take);

@@ -260,6 +260,7 @@ int run_bam_pipeline(const std::vector<Chromosome> &genome, const std::vector<un
         return d;
     };
     std::future<std::unique_ptr<WinData>> ahead;
+    std::future<void> trash;
     if (!wins.empty()) ahead = std::async(std::launch::async, read_win, (size_t)0);
     int status = 0;
     for (size_t w = 0; w < wins.size(); w++) {
@@ -352,16 +353,27 @@ int run_bam_pipeline(const std::vector<Chromosome> &genome, const std::vector<un
         t_cov += now() - t0; t0 = now();
         if (!kept.empty()) caller.process_window(chrom, kept, win.ws, win.we, bed_start, bed_end);
         t_call += now() - t0; t0 = now();
-        release_reads(kept);
-        d.reset();
+        // the window's reads are freed behind the next window's work (one disposal in flight)
+        if (trash.valid()) trash.wait();
+        {
+            std::shared_ptr<std::vector<SplitRead>> dead_reads(new std::vector<SplitRead>(std::move(kept)));
+            std::shared_ptr<WinData> dead_win(d.release());
+            trash = std::async(std::launch::async, [dead_reads, dead_win]() mutable {
+                release_reads(*dead_reads);
+                dead_reads.reset();
+                dead_win.reset();
+            });
+        }
         t_free += now() - t0;
     }
     if (ahead.valid()) ahead.wait();                      // (an early exit must not leave the reader running on dead objects)
+    if (trash.valid()) trash.wait();
     if (timing)
         fprintf(stderr, "pgh timing: BAM pipeline %.3f s wall: waiting for the reader %.3f s, close end %.3f s, keep + SplitReads %.3f s, "
                         "far end %.3f s, reference coverage %.3f s, classify + report %.3f s, free %.3f s | reader thread: read-pair "
-                        "discovery %.3f s, ingest %.3f s\n",
-                now() - t_begin, t_wait, t_close, t_keep, t_far, t_cov, t_call, t_free, t_rp, t_ingest);
+                        "discovery %.3f s, ingest %.3f s (inflate + decode on threads %.3f, selection rules on threads %.3f, layout %.3f)\n",
+                now() - t_begin, t_wait, t_close, t_keep, t_far, t_cov, t_call, t_free, t_rp, t_ingest,
+                ingest_timing().inflate_decode, ingest_timing().select, ingest_timing().layout);
     return status;
 }
 
