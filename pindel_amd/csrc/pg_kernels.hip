@@ -631,18 +631,66 @@ __device__ __forceinline__ int seed_depth(int len, int T, bool wide)
     return J > jt ? jt : J;
 }
 
-// positions whose bit-sliced mismatch count (c[NS-1] .. c0, ov = overflowed) is <= thr (wave-uniform)
-template <int NS>
-__device__ __forceinline__ u32 count_le(const u32 *c, u32 ov, int thr)
+// positions whose bit-sliced mismatch count (c[NS-1] .. c0, ov = overflowed) is <= thr (wave-uniform, >= 0).
+// "count <= constant" is a fixed boolean function of the slices: the low three slices against thr & 7 are ONE v_bitop3
+// whose truth table is picked by a scalar switch, the upper slice(s) a second one, the overflow bit a third --
+// v_bitop3 on VGPR operands issues at the fast VALU rate (scripts/ubench_issue.hip), the compare-free generic form
+// (selects on scalar conditions, v_or3) at the slow one.
+__host__ __device__ constexpr u32 le3_table(int t)          // truth table of [4 c + 2 b + a <= t] for v_bitop3(a, b, c)
 {
-    u32 eq = ~ov, lt = 0u;
-#pragma unroll
-    for (int i = NS - 1; i >= 0; i--) {
-        const u32 ti = ((thr >> i) & 1) ? ~0u : 0u;
-        lt |= eq & ~c[i] & ti;
-        eq &= ~(c[i] ^ ti);
+    u32 tt = 0u;
+    for (int i = 0; i < 8; i++) {
+        const int v = 4 * (i & 1) + 2 * ((i >> 1) & 1) + ((i >> 2) & 1);
+        if (v <= t) tt |= 1u << i;
     }
-    return thr >= (1 << NS) - 1 ? ~ov : (lt | eq);
+    return tt;
+}
+#define PG_BO3(a, b, c, tt) __builtin_amdgcn_bitop3_b32((a), (b), (c), (tt))
+// (two counters against the same threshold share the scalar switch: TWO = the far end's second kind)
+template <int NS, bool TWO>
+__device__ __forceinline__ void count_le(const u32 *c, u32 ov, const u32 *d, u32 ovd, int thr, u32 &rc, u32 &rd)
+{
+    thr = uni(thr);
+    rd = 0u;
+    if (thr < 0) { rc = 0u; return; }
+    if (thr >= (1 << NS) - 1) { rc = ~ov; if (TWO) rd = ~ovd; return; }
+    u32 g, h = 0u;
+#define PG_LE3(t) g = PG_BO3(c[0], c[1], c[2], le3_table(t)); if (TWO) h = PG_BO3(d[0], d[1], d[2], le3_table(t)); break;
+    switch (thr & 7) {
+    case 0: PG_LE3(0)
+    case 1: PG_LE3(1)
+    case 2: PG_LE3(2)
+    case 3: PG_LE3(3)
+    case 4: PG_LE3(4)
+    case 5: PG_LE3(5)
+    case 6: PG_LE3(6)
+    default: g = h = ~0u; break;
+    }
+#undef PG_LE3
+    if (NS == 3) {                                                 // g & ~ov
+        rc = PG_BO3(g, ov, ov, 0x30);
+        if (TWO) rd = PG_BO3(h, ovd, ovd, 0x30);
+    } else if (NS == 4) {
+        if (thr >> 3) {                                            // (g | ~c3) & ~ov
+            rc = PG_BO3(g, c[3], ov, 0x51);
+            if (TWO) rd = PG_BO3(h, d[3], ovd, 0x51);
+        } else {                                                   // g & ~c3 & ~ov
+            rc = PG_BO3(g, c[3], ov, 0x10);
+            if (TWO) rd = PG_BO3(h, d[3], ovd, 0x10);
+        }
+    } else {
+        u32 u, v = 0u;
+#define PG_LE5(tt) u = PG_BO3(g, c[3], c[4], tt); if (TWO) v = PG_BO3(h, d[3], d[4], tt); break;
+        switch (thr >> 3) {                                        // (c4 c3) against thr >> 3, g breaks the tie
+        case 0: PG_LE5(0x10)                                       // ~c4 & ~c3 & g
+        case 1: PG_LE5(0x51)                                       // ~c4 & (~c3 | g)
+        case 2: PG_LE5(0x75)                                       // ~c4 | (~c3 & g)
+        default: PG_LE5(0xf7)                                      // ~c4 | ~c3 | g
+        }
+#undef PG_LE5
+        rc = PG_BO3(u, ov, ov, 0x30);
+        if (TWO) rd = PG_BO3(v, ovd, ovd, 0x30);
+    }
 }
 
 // Bit-sliced mismatch counter of the seed filter: NS slices (3: up to 8 levels, 4: up to 16, 5: up to 32) + a sticky
@@ -656,7 +704,7 @@ __device__ __forceinline__ u32 count_le(const u32 *c, u32 ov, int thr)
 #define PG_SHIFT(m, j) "v_alignbit_b32 %[" m "], %[hi], %[lo], %[" j "]\n\t"
 #define PG_MIRROR(t, j) "s_sub_i32 %[" t "], 32, %[" j "]\n\t"      // (writes SCC: the statements using it clobber "scc")
 // one base: k0 = ~ma & c0, c0 ^= ~ma, k1 = c1 & k0, c1 ^= k0
-#define PG_ADD1 "v_bfi_b32 %[k0], %[ma], 0, %[c0]\n\tv_xnor_b32 %[c0], %[c0], %[ma]\n\t" \
+#define PG_ADD1 "v_bitop3_b32 %[k0], %[ma], %[c0], %[c0] bitop3:0x0c\n\tv_bitop3_b32 %[c0], %[c0], %[ma], %[ma] bitop3:0xc3\n\t" \
                 "v_and_b32 %[k1], %[c1], %[k0]\n\tv_xor_b32 %[c1], %[c1], %[k0]\n\t"
 // two bases: sum of the two mismatch bits = low bit ma ^ mb, high bit ~(ma | mb); the high bit and the carry out
 // of slice 0 exclude each other, so slice 1 adds t = high | carry
@@ -668,20 +716,22 @@ __device__ __forceinline__ u32 count_le(const u32 *c, u32 ov, int thr)
                 "v_and_b32 %[k0], %[c0], %[s0]\n\tv_xor_b32 %[c0], %[c0], %[s0]\n\t" \
                 "v_bitop3_b32 %[k1], %[c1], %[s1], %[k0] bitop3:0xe8\n\tv_bitop3_b32 %[c1], %[c1], %[s1], %[k0] bitop3:0x96\n\t"
 // the carry out of slice 1 (k1) through the upper slice(s)
-#define PG_UP3 "v_and_or_b32 %[ov], %[c2], %[k1], %[ov]\n\tv_xor_b32 %[c2], %[c2], %[k1]"
+#define PG_UP3 "v_bitop3_b32 %[ov], %[c2], %[k1], %[ov] bitop3:0xea\n\tv_xor_b32 %[c2], %[c2], %[k1]"
 #define PG_UP4 "v_and_b32 %[k0], %[c2], %[k1]\n\tv_xor_b32 %[c2], %[c2], %[k1]\n\t" \
-               "v_and_or_b32 %[ov], %[c3], %[k0], %[ov]\n\tv_xor_b32 %[c3], %[c3], %[k0]"
+               "v_bitop3_b32 %[ov], %[c3], %[k0], %[ov] bitop3:0xea\n\tv_xor_b32 %[c3], %[c3], %[k0]"
 #define PG_UP5 "v_and_b32 %[k0], %[c2], %[k1]\n\tv_xor_b32 %[c2], %[c2], %[k1]\n\t" \
                "v_and_b32 %[k1], %[c3], %[k0]\n\tv_xor_b32 %[c3], %[c3], %[k0]\n\t" \
-               "v_and_or_b32 %[ov], %[c4], %[k1], %[ov]\n\tv_xor_b32 %[c4], %[c4], %[k1]"
+               "v_bitop3_b32 %[ov], %[c4], %[k1], %[ov] bitop3:0xea\n\tv_xor_b32 %[c4], %[c4], %[k1]"
 template <int NS>
 struct Counter {
     u32 c0, c1, c2, c3, c4, ov;
     __device__ __forceinline__ void reset() { c0 = c1 = c2 = c3 = c4 = ov = 0u; }
-    __device__ __forceinline__ u32 le(int thr) const
+    // positions with count <= thr in this counter (and, TWO, in `o`)
+    template <bool TWO>
+    __device__ __forceinline__ void le(const Counter &o, int thr, u32 &mine, u32 &others) const
     {
-        const u32 c[5] = { c0, c1, c2, c3, c4 };
-        return thr < 0 ? 0u : count_le<NS>(c, ov, thr);
+        const u32 c[5] = { c0, c1, c2, c3, c4 }, d[5] = { o.c0, o.c1, o.c2, o.c3, o.c4 };
+        count_le<NS, TWO>(c, ov, d, o.ov, thr, mine, others);
     }
 #define PG_CTR3 [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2), [ov] "+v"(ov)
 #define PG_CTR4 [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2), [c3] "+v"(c3), [ov] "+v"(ov)
@@ -872,17 +922,16 @@ __device__ __forceinline__ void seed_filter_run(const Search &S, const Query<NB>
     for (int it = 0; it < 10; it++) {
         const int X = it >= 5 ? it - 5 : it;
         const int X2 = X < 4 ? 3 - X : X;                              // the complementary symbol
-        if (it == 5) {
-            snap = C.le(cap0 - o_pre);
-            if (DUAL) snap2 = C2.le(cap0 - o_pre);
-        }
+        if (it == 5) C.template le<DUAL>(C2, cap0 - o_pre, snap, snap2);
         u32 pm = sym[X] & (it >= 5 ? (jmask & ~g0mask) : g0mask);
         if (DUAL) add_bases<NS, true>(X < 4, pm, C, w0[X], w1[X], C2, wm[X2], w0[X2]);
         else if (kindB) add_bases<NS, false>(X < 4, __brev(pm) << 1, C, wm[X], w0[X], C2, 0u, 0u);
         else add_bases<NS, false>(X < 4, pm, C, w0[X], w1[X], C2, 0u, 0u);
     }
-    mF = seed & (snap | C.le(S.T - 1 - o_all));
-    if (DUAL) mB = seed2 & (snap2 | C2.le(S.T - 1 - o_all));
+    u32 fin, fin2;
+    C.template le<DUAL>(C2, S.T - 1 - o_all, fin, fin2);
+    mF = seed & (snap | fin);
+    if (DUAL) mB = seed2 & (snap2 | fin2);
 }
 
 template <int NB, bool DUAL>
@@ -891,6 +940,28 @@ __device__ __forceinline__ void seed_filter(const Search &S, const Query<NB> &Q,
 {
     const int T = S.T;
     PG_DG(const_cast<Search &>(S), 8);
+#if defined(PG_PAD_S) || defined(PG_PAD_VF) || defined(PG_PAD_VS)
+    {   // diagnostics: what do 128 more scalar / fast-rate vector / slow-rate vector instructions per filter run cost?
+        u32 pa = (u32)lane;
+#define PG_R16(x) x x x x x x x x x x x x x x x x
+#if defined(PG_PAD_S)
+        asm volatile("s_mov_b32 s100, 1\n\t"
+                     PG_R16("s_add_u32 s100, s100, 3\n\ts_xor_b32 s100, s100, 5\n\ts_add_u32 s100, s100, 7\n\ts_xor_b32 s100, s100, 9\n\t"
+                            "s_add_u32 s100, s100, 3\n\ts_xor_b32 s100, s100, 5\n\ts_add_u32 s100, s100, 7\n\ts_xor_b32 s100, s100, 9\n\t")
+                     "v_xor_b32 %0, s100, %0"
+                     : "+v"(pa) : : "scc", "s100");
+#elif defined(PG_PAD_VF)
+        asm volatile(PG_R16("v_xor_b32 %0, 3, %0\n\tv_add_u32 %0, 5, %0\n\tv_xor_b32 %0, 7, %0\n\tv_add_u32 %0, 9, %0\n\t"
+                            "v_xor_b32 %0, 3, %0\n\tv_add_u32 %0, 5, %0\n\tv_xor_b32 %0, 7, %0\n\tv_add_u32 %0, 9, %0\n\t")
+                     : "+v"(pa));
+#else
+        asm volatile(PG_R16("v_alignbit_b32 %0, %0, %0, 3\n\tv_alignbit_b32 %0, %0, %0, 5\n\tv_alignbit_b32 %0, %0, %0, 7\n\tv_alignbit_b32 %0, %0, %0, 9\n\t"
+                            "v_alignbit_b32 %0, %0, %0, 3\n\tv_alignbit_b32 %0, %0, %0, 5\n\tv_alignbit_b32 %0, %0, %0, 7\n\tv_alignbit_b32 %0, %0, %0, 9\n\t")
+                     : "+v"(pa));
+#endif
+        asm volatile("" : : "v"(pa));
+    }
+#endif
     // bases inspected: two more in the chunks of wide far-end windows, where survivors cost a whole pass of
     // fold_candidates for a handful of candidates (measured: -4 % time at -x 5, +2 % if used everywhere)
     const int J = seed_depth(S.len, T, wide);
@@ -966,7 +1037,6 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
                 if (end >= WAVE) n = WAVE;
                 else if (h < nh) {                            // every survivor so far is queued: the next half
                     const int word = 64 * h + lane;
-                    const int pbase = cs + 32 * word;
                     seed_filter<NB, true>(S, Q, false, true, word, mF, mB);
 #if defined(PG_DUP) && PG_DUP == 3
                     u32 dF, dB;
@@ -974,6 +1044,7 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
                     mF &= dF | (u32)opaque(0);
                     mB &= dB | (u32)opaque(0);
 #endif
+                    const int pbase = cs + 32 * word;
                     const u32 rmask = bits32(ns - pbase, ne - pbase) & ~bits32(xs - pbase, xe - pbase);
                     mF &= rmask;
                     mB &= rmask;
