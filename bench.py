@@ -107,9 +107,12 @@ def measured_traffic(args, reads_per_launch):
 def issue_model(args, kernel_ms, reads_per_launch):
     """The kernel is instruction-issue bound, not HBM bound.  Instructions per read and lane
     occupancy from the committed PMC passes of this round (profiles/r03/pmc_sq.txt); issue costs from the microbenchmark
-    (profiles/r02/ubench_issue_rates.txt, MI355X): a SIMD issues a plain 2-operand wave64 VALU op every 2.0 cycles and a
-    3-operand / DPP / lane-access op every 3.2 cycles (most of this kernel's bit operations), the CU's one scalar unit
-    1.0-1.35 ops per cycle.  Both VALU bounds are given; the truth lies between them, nearer the upper one."""
+    (profiles/r03/ubench_issue_rates.txt, MI355X): a SIMD issues a fast-rate wave64 VALU op (plain logic / add / v_bitop3
+    on VGPR or constant operands) every 2.0 cycles and a slow-rate one (an SGPR operand, funnel shifts, compares, selects,
+    DPP, lane reads: 44 % of this kernel's VALU instructions statically) every 3.2 cycles, the CU's one scalar unit
+    1.0-1.35 ops per cycle.  Both VALU bounds are given; the truth lies between them.  `ns_per_instruction` = SIMD time
+    per read / (VALU + SALU instructions per read); `in_situ_ns_per_extra_instruction` = what 128 more instructions
+    per seed-filter run were measured to cost inside this kernel (profiles/r03/issue_calibration.txt)."""
     path = os.path.join(PROFILE_DIR, PMC_FILE)
     if not default_workload(args) or not os.path.exists(path) or kernel_ms <= 0:
         return None
@@ -128,7 +131,10 @@ def issue_model(args, kernel_ms, reads_per_launch):
            "valu_busy_frac_at_2p0_cycles": valu * per_simd * 2.0 / cyc,
            "valu_busy_frac_at_3p2_cycles": valu * per_simd * 3.2 / cyc,
            "salu_busy_frac_at_1_per_cu_cycle": salu * reads_per_launch / 256.0 / cyc,
-           "source": f"profiles/r03/{PMC_FILE} + profiles/r02/ubench_issue_rates.txt, 256 CUs x 4 SIMDs, 2.4 GHz nominal"}
+           "ns_per_instruction": kernel_ms * 1e6 / per_simd / (valu + salu),
+           "in_situ_ns_per_extra_instruction": {"salu": 1.24, "valu_fast_rate": 0.98, "valu_slow_rate": 1.24},
+           "source": f"profiles/r03/{PMC_FILE} + profiles/r03/ubench_issue_rates.txt + profiles/r03/issue_calibration.txt, "
+                     "256 CUs x 4 SIMDs, 2.4 GHz nominal"}
     if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_ACTIVE_INST_VALU"):
         # active lanes per executed VALU instruction (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU), of 64
         out["valu_active_lanes_per_inst"] = c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"]
