@@ -223,6 +223,7 @@ struct pg_device_batch {
     uint32_t *close_off = nullptr, *close_cnt = nullptr, *far_off = nullptr, *far_cnt = nullptr;
     uint32_t *alg = nullptr;
     PgInRec *in_rec = nullptr;         // packed per-read records the kernel reads / writes (pg_device.h)
+    uint64_t *planes = nullptr;        // the reads as bit planes (PgDevBatch::planes)
     PgOutRec *out_rec = nullptr;
     bool unpacked = true;              // the SoA output arrays reflect out_rec
     bool in_arena = false;             // buffers belong to the ctx arena (not freed one by one)
@@ -384,7 +385,7 @@ void free_batch_buffers(pg_device_batch *b)
         b->bd = nullptr;
         return;
     }
-    void *ptrs[] = { b->seq, b->seq_off, b->strand, b->pos, b->isz, b->chr, b->rc_flag,
+    void *ptrs[] = { b->planes, b->seq, b->seq_off, b->strand, b->pos, b->isz, b->chr, b->rc_flag,
                      b->close_last, b->close_max, b->bd_off, b->bd, b->close_off, b->close_cnt,
                      b->far_off, b->far_cnt, b->alg, b->pool, b->pool_used, b->in_rec, b->out_rec };
     for (void *p : ptrs)
@@ -511,6 +512,7 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, PodVec<uint6
         { (void **)&b->seq, std::max<size_t>((size_t)nseq, 1) }, { (void **)&b->seq_off, (n + 1) * 8 },
         { (void **)&b->strand, n1 }, { (void **)&b->pos, n1 * 4 }, { (void **)&b->isz, n1 * 2 }, { (void **)&b->chr, n1 * 4 },
         { (void **)&b->in_rec, n1 * sizeof(PgInRec) },
+        { (void **)&b->planes, n1 * 64 * pg_plane_blocks(max_len) },
         { (void **)&b->pool, (size_t)b->pool_shard_cap * PG_POOL_SHARDS * sizeof(pg_run) },
         // ---- zero-initialised from here
         { (void **)&b->rc_flag, n1 }, { (void **)&b->close_last, n1 * 4 }, { (void **)&b->close_max, n1 * 2 },
@@ -519,7 +521,7 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, PodVec<uint6
         { (void **)&b->out_rec, n1 * sizeof(PgOutRec) },
         { (void **)&b->pool_used, (PG_POOL_SHARDS * 16 + 2 * PG_WORK_CTRS * 16 + PG_DIAG_WORDS * 2) * 4 },   // + a second set of read counters  // run-pool cursors + the launch's read counters
     };
-    const size_t n_items = sizeof items / sizeof items[0], first_zero = 8;
+    const size_t n_items = sizeof items / sizeof items[0], first_zero = 9;
     auto drop = [&](int code) {
         free_batch_buffers(b);
         delete b;
@@ -580,6 +582,9 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, PodVec<uint6
 PgSoaIn soa_in(const pg_ctx *ctx, const pg_device_batch *b)
 {
     PgSoaIn a;
+    a.seq = b->seq;
+    a.planes = b->planes;
+    a.plane_blocks = pg_plane_blocks(b->max_len);
     a.seq_off = b->seq_off;
     a.strand = b->strand;
     a.pos = b->pos;
@@ -649,6 +654,8 @@ PgDevBatch dev_batch(const pg_device_batch *b)
     d.in = b->in_rec;
     d.out = b->out_rec;
     d.seq = b->seq;
+    d.planes = b->planes;
+    d.plane_blocks = pg_plane_blocks(b->max_len);
     d.bd = b->bd_off ? b->bd : nullptr;
     d.pool = b->pool;
     d.pool_shard_cap = b->pool_shard_cap;

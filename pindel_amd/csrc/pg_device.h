@@ -66,6 +66,12 @@ struct PgDevBatch {
     const PgInRec *in;
     PgOutRec *out;                 // close-end fields: written in CLOSE/BOTH mode, read in FAR mode
     const uint8_t *seq;
+    // The reads as bit planes, built once by pg_pack_reads (every lane busy) instead of per read in the search kernel
+    // (ten byte compares and eight ballots of a single wave): per read u64[2 orientations][4 planes][plane_blocks],
+    // orientation 0 = left to right, 1 = reversed; planes = code bit 0, code bit 1, is-N, is-other; bit j of block b =
+    // base 64 b + j.
+    const uint64_t *planes;
+    uint32_t plane_blocks;         // 64-base blocks per read in `planes` (pg_plane_blocks of the batch's longest read)
     const pg_window *bd;           // BreakDancer windows (nullable)
     // Run pool, split into PG_POOL_SHARDS equal regions with one bump cursor each (a single
     // device-wide cursor saturates at ~88 M atomics/s, MI355X_MICROARCH.md "dequeue").  Workgroup b
@@ -77,7 +83,14 @@ struct PgDevBatch {
 };
 
 // SoA views for the pack / unpack kernels
+static inline uint32_t pg_plane_blocks(uint32_t max_len)
+{
+    return max_len <= 64u ? 1u : (max_len <= 128u ? 2u : (max_len <= 192u ? 3u : (max_len <= 256u ? 4u : 8u)));
+}
 struct PgSoaIn {
+    const uint8_t *seq;            // the reads' bases ...
+    uint64_t *planes;              // ... and where their bit planes go (PgDevBatch::planes)
+    uint32_t plane_blocks;
     const uint64_t *seq_off;
     const uint8_t *strand;
     const int32_t *pos;

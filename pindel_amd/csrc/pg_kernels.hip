@@ -1346,44 +1346,21 @@ __device__ __forceinline__ void emit_runs(const Search &S, bool antiF, bool anti
 }
 
 // ---------------------------------------------------------------------------------
-// The read's bases -> bit planes (code bit 0 / 1, N, other; forward and reversed) in LDS.  In two steps, so that the
-// caller can put other loads between the request and the first use of the bases.
+// The read's bit planes (PgDevBatch::planes, built by pg_pack_reads) into LDS.  In two steps, so that the caller can put
+// other loads between the request and the first use.  Lane l < 8 plane_blocks holds one u64; blocks the batch's layout
+// does not have (plane_blocks < NB) stay zero in LDS from the start of the kernel.
 template <int NB>
-struct ReadBases {
-    uint8_t cf[NB], cr[NB];
-};
-template <int NB>
-__device__ __forceinline__ void request_bases(const uint8_t *seq, int len, int lane, ReadBases<NB> &rb)
+__device__ __forceinline__ u64 request_planes(const PgDevBatch &B, uint32_t rid, int lane)
 {
-#pragma unroll
-    for (int b = 0; b < NB; b++) {
-        const int idx = 64 * b + lane;
-        const bool in = idx < len;
-        rb.cf[b] = in ? seq[idx] : 0;
-        rb.cr[b] = in ? seq[len - 1 - idx] : 0;
-    }
+    const u32 pb = B.plane_blocks;
+    return (u32)lane < 8u * pb ? B.planes[(size_t)rid * 8u * pb + (u32)lane] : 0ull;
 }
 template <int NB>
-__device__ __forceinline__ void make_planes(const ReadBases<NB> &rb, int len, int lane, u64 *qp)
+__device__ __forceinline__ void store_planes(const PgDevBatch &B, u64 v, int lane, u64 *qp)
 {
+    const u32 pb = B.plane_blocks;
     __syncthreads();
-#pragma unroll
-    for (int b = 0; b < NB; b++) {
-        const bool in = 64 * b + lane < len;
-        const uint8_t cf = rb.cf[b], cr = rb.cr[b];
-        // code: A=0 C=1 G=2 T=3
-        bool fA = cf == 'A', fC = cf == 'C', fG = cf == 'G', fT = cf == 'T', fN = cf == 'N';
-        bool rA = cr == 'A', rC = cr == 'C', rG = cr == 'G', rT = cr == 'T', rN = cr == 'N';
-        const u64 flo = ballot64(fC || fT), fhi = ballot64(fG || fT), fnn = ballot64(fN);
-        const u64 foo = ballot64(in && !(fA || fC || fG || fT || fN));
-        const u64 rlo = ballot64(rC || rT), rhi = ballot64(rG || rT), rnn = ballot64(rN);
-        const u64 roo = ballot64(in && !(rA || rC || rG || rT || rN));
-        if (lane == 0) {
-            qp[QP_LO * NB + b] = flo; qp[QP_HI * NB + b] = fhi; qp[QP_NN * NB + b] = fnn; qp[QP_OO * NB + b] = foo;
-            u64 *qr = qp + 4 * NB;
-            qr[QP_LO * NB + b] = rlo; qr[QP_HI * NB + b] = rhi; qr[QP_NN * NB + b] = rnn; qr[QP_OO * NB + b] = roo;
-        }
-    }
+    if ((u32)lane < 8u * pb) qp[pb == (u32)NB ? (u32)lane : ((u32)lane / pb) * NB + (u32)lane % pb] = v;
     __syncthreads();
 }
 
@@ -1452,8 +1429,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     }
     // The record is the read's first memory round trip; its bases and the window of the first close-end attempt are
     // the second: both are requested before either is used (the scan below finds the window resident).
-    ReadBases<NB> rb;
-    request_bases<NB>(B.seq + ((u64)r0.x | ((u64)r0.y << 32)), len, lane, rb);
+    const u64 planes_of_read = request_planes<NB>(B, rid, lane);
     if (mode & PG_MODE_CLOSE) {
         const int strand0 = uni((int)((r1.y >> 16) & 0xffu));
         if (len - 1 >= prm.min_close && (strand0 == '+' || strand0 == '-')) {
@@ -1465,11 +1441,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
             }
         }
     }
-    make_planes<NB>(rb, len, lane, qplanes);
-#if defined(PG_DUP) && PG_DUP == 1
-    request_bases<NB>(B.seq + ((u64)r0.x | ((u64)r0.y << 32)), len, opaque(lane), rb);
-    make_planes<NB>(rb, len, opaque(lane), qplanes);
-#endif
+    store_planes<NB>(B, planes_of_read, lane, qplanes);
 
     PG_T(S, 0);
     const bool do_close = (mode & PG_MODE_CLOSE) != 0, do_far = (mode & PG_MODE_FAR) != 0;
@@ -1841,6 +1813,7 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
     S.add_mm = prm.add_mm;
     S.min_perfect = prm.min_perfect;
     u64 *qplanes = lds.qp;                        // [0]: forward, [1]: reversed consumption order
+    if (lane < 8 * NB) qplanes[lane] = 0ull;      // (blocks beyond the batch's plane layout are never written)
 #ifdef PG_TIMING
     S.t_acc = lds.t_acc;
     S.t_last = &lds.t_last;
@@ -1962,6 +1935,38 @@ __global__ void pg_pack_reads_kernel(PgSoaIn a, PgInRec *in, uint32_t lo, uint32
     in[i] = r;
 }
 
+// The reads' bit planes (PgDevBatch::planes): one wave per (read, 64-base block); code A=0 C=1 G=2 T=3, N and "other"
+// (matches nothing) as planes of their own; orientation 1 = the read from its last base.
+__global__ __launch_bounds__(256) void pg_pack_planes_kernel(PgSoaIn a, uint32_t lo, uint32_t cnt)
+{
+    const uint32_t pb = a.plane_blocks;
+    const uint64_t w = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (w >= (uint64_t)cnt * pb) return;                      // (whole waves)
+    const uint32_t i = lo + (uint32_t)(w / pb), b = (uint32_t)(w % pb), lane = threadIdx.x & 63u;
+    const uint8_t *seq = a.seq + a.seq_off[i];
+    const uint32_t len = (uint32_t)(a.seq_off[i + 1] - a.seq_off[i]);
+    const uint32_t idx = 64u * b + lane;
+    const bool in = idx < len;
+    const uint8_t cf = in ? seq[idx] : 0, cr = in ? seq[len - 1u - idx] : 0;
+    const bool fA = cf == 'A', fC = cf == 'C', fG = cf == 'G', fT = cf == 'T', fN = cf == 'N';
+    const bool rA = cr == 'A', rC = cr == 'C', rG = cr == 'G', rT = cr == 'T', rN = cr == 'N';
+    u64 v[8];
+    v[QP_LO] = ballot64(fC || fT);
+    v[QP_HI] = ballot64(fG || fT);
+    v[QP_NN] = ballot64(fN);
+    v[QP_OO] = ballot64(in && !(fA || fC || fG || fT || fN));
+    v[4 + QP_LO] = ballot64(rC || rT);
+    v[4 + QP_HI] = ballot64(rG || rT);
+    v[4 + QP_NN] = ballot64(rN);
+    v[4 + QP_OO] = ballot64(in && !(rA || rC || rG || rT || rN));
+    if (lane < 8u) {
+        u64 mine = v[0];
+#pragma unroll
+        for (int k = 1; k < 8; k++) mine = lane == (uint32_t)k ? v[k] : mine;
+        a.planes[((size_t)i * 8u + lane) * pb + b] = mine;     // [orientation][plane][block]
+    }
+}
+
 __global__ void pg_pack_close_kernel(PgSoaOut a, PgOutRec *out, uint32_t n)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1995,7 +2000,11 @@ __global__ void pg_unpack_kernel(const PgOutRec *out, PgSoaOut a, uint32_t n)
 
 extern "C" int pg_pack_reads(const PgSoaIn *soa, PgInRec *in, uint32_t lo, uint32_t cnt, void *stream)
 {
-    if (cnt) pg_pack_reads_kernel<<<(cnt + 255u) / 256u, 256, 0, (hipStream_t)stream>>>(*soa, in, lo, cnt);
+    if (cnt) {
+        pg_pack_reads_kernel<<<(cnt + 255u) / 256u, 256, 0, (hipStream_t)stream>>>(*soa, in, lo, cnt);
+        const uint64_t waves = (uint64_t)cnt * soa->plane_blocks;
+        pg_pack_planes_kernel<<<(uint32_t)((waves + 3u) / 4u), 256, 0, (hipStream_t)stream>>>(*soa, lo, cnt);
+    }
     return (int)hipGetLastError();
 }
 
