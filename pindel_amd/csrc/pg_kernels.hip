@@ -1935,35 +1935,41 @@ __global__ void pg_pack_reads_kernel(PgSoaIn a, PgInRec *in, uint32_t lo, uint32
     in[i] = r;
 }
 
-// The reads' bit planes (PgDevBatch::planes): one wave per (read, 64-base block); code A=0 C=1 G=2 T=3, N and "other"
-// (matches nothing) as planes of their own; orientation 1 = the read from its last base.
+// The reads' bit planes (PgDevBatch::planes): a wave takes PG_PLANES_PER_WAVE (read, 64-base block) pairs, one after
+// the other (lanes = bases); code A=0 C=1 G=2 T=3, N and "other" (matches nothing) as planes of their own; orientation 1
+// = the read from its last base.
+#define PG_PLANES_PER_WAVE 16u
 __global__ __launch_bounds__(256) void pg_pack_planes_kernel(PgSoaIn a, uint32_t lo, uint32_t cnt)
 {
-    const uint32_t pb = a.plane_blocks;
-    const uint64_t w = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (w >= (uint64_t)cnt * pb) return;                      // (whole waves)
-    const uint32_t i = lo + (uint32_t)(w / pb), b = (uint32_t)(w % pb), lane = threadIdx.x & 63u;
-    const uint8_t *seq = a.seq + a.seq_off[i];
-    const uint32_t len = (uint32_t)(a.seq_off[i + 1] - a.seq_off[i]);
-    const uint32_t idx = 64u * b + lane;
-    const bool in = idx < len;
-    const uint8_t cf = in ? seq[idx] : 0, cr = in ? seq[len - 1u - idx] : 0;
-    const bool fA = cf == 'A', fC = cf == 'C', fG = cf == 'G', fT = cf == 'T', fN = cf == 'N';
-    const bool rA = cr == 'A', rC = cr == 'C', rG = cr == 'G', rT = cr == 'T', rN = cr == 'N';
-    u64 v[8];
-    v[QP_LO] = ballot64(fC || fT);
-    v[QP_HI] = ballot64(fG || fT);
-    v[QP_NN] = ballot64(fN);
-    v[QP_OO] = ballot64(in && !(fA || fC || fG || fT || fN));
-    v[4 + QP_LO] = ballot64(rC || rT);
-    v[4 + QP_HI] = ballot64(rG || rT);
-    v[4 + QP_NN] = ballot64(rN);
-    v[4 + QP_OO] = ballot64(in && !(rA || rC || rG || rT || rN));
-    if (lane < 8u) {
-        u64 mine = v[0];
+    const uint32_t pb = a.plane_blocks, lane = threadIdx.x & 63u;
+    const uint64_t total = (uint64_t)cnt * pb;
+    const uint64_t w0 = ((uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6)) * PG_PLANES_PER_WAVE;
+    for (uint32_t t = 0; t < PG_PLANES_PER_WAVE; t++) {
+        const uint64_t w = w0 + t;
+        if (w >= total) break;                                // (whole waves)
+        const uint32_t i = lo + (uint32_t)(w / pb), b = (uint32_t)(w % pb);
+        const uint8_t *seq = a.seq + a.seq_off[i];
+        const uint32_t len = (uint32_t)(a.seq_off[i + 1] - a.seq_off[i]);
+        const uint32_t idx = 64u * b + lane;
+        const bool in = idx < len;
+        const uint8_t cf = in ? seq[idx] : 0, cr = in ? seq[len - 1u - idx] : 0;
+        const bool fA = cf == 'A', fC = cf == 'C', fG = cf == 'G', fT = cf == 'T', fN = cf == 'N';
+        const bool rA = cr == 'A', rC = cr == 'C', rG = cr == 'G', rT = cr == 'T', rN = cr == 'N';
+        u64 v[8];
+        v[QP_LO] = ballot64(fC || fT);
+        v[QP_HI] = ballot64(fG || fT);
+        v[QP_NN] = ballot64(fN);
+        v[QP_OO] = ballot64(in && !(fA || fC || fG || fT || fN));
+        v[4 + QP_LO] = ballot64(rC || rT);
+        v[4 + QP_HI] = ballot64(rG || rT);
+        v[4 + QP_NN] = ballot64(rN);
+        v[4 + QP_OO] = ballot64(in && !(rA || rC || rG || rT || rN));
+        if (lane < 8u) {
+            u64 mine = v[0];
 #pragma unroll
-        for (int k = 1; k < 8; k++) mine = lane == (uint32_t)k ? v[k] : mine;
-        a.planes[((size_t)i * 8u + lane) * pb + b] = mine;     // [orientation][plane][block]
+            for (int k = 1; k < 8; k++) mine = lane == (uint32_t)k ? v[k] : mine;
+            a.planes[((size_t)i * 8u + lane) * pb + b] = mine;     // [orientation][plane][block]
+        }
     }
 }
 
@@ -2002,8 +2008,8 @@ extern "C" int pg_pack_reads(const PgSoaIn *soa, PgInRec *in, uint32_t lo, uint3
 {
     if (cnt) {
         pg_pack_reads_kernel<<<(cnt + 255u) / 256u, 256, 0, (hipStream_t)stream>>>(*soa, in, lo, cnt);
-        const uint64_t waves = (uint64_t)cnt * soa->plane_blocks;
-        pg_pack_planes_kernel<<<(uint32_t)((waves + 3u) / 4u), 256, 0, (hipStream_t)stream>>>(*soa, lo, cnt);
+        const uint64_t per_wg = 4u * PG_PLANES_PER_WAVE, items = (uint64_t)cnt * soa->plane_blocks;
+        pg_pack_planes_kernel<<<(uint32_t)((items + per_wg - 1u) / per_wg), 256, 0, (hipStream_t)stream>>>(*soa, lo, cnt);
     }
     return (int)hipGetLastError();
 }
