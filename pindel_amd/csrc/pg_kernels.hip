@@ -11,11 +11,12 @@
 // the same function differently (DESIGN.md "kernel formulation"):
 //
 //   * The chromosome lives in HBM as three bit planes (2-bit code planar + N plane).  A window chunk
-//     (2048 positions + overhang) is staged into LDS with coalesced dword loads, as code planes and as
-//     one-hot planes (is-A/C/G/T/not-N).
+//     (2048 positions + overhang) is staged into LDS with coalesced dword loads as code planes; the seed filter derives
+//     the one-hot planes (is-A/C/G/T/not-N) of its words from them.  The reads arrive as bit planes too (built by
+//     pg_pack_planes_kernel, a wave per 64-base block), one 8-byte load per lane and read.
 //   * SEED FILTER, bit sliced: each lane owns the 32 window positions of one LDS word.  The match mask of
 //     consumed base j for all 32 positions is one v_alignbit of the one-hot plane of that read symbol;
-//     mismatch counts live in a 4-bit ripple counter of 32-bit slices.  It keeps exactly the seeds that
+//     mismatch counts live in a bit-sliced carry-save counter (3 to 5 slices of 32 bits).  It keeps exactly the seeds that
 //     can matter (DESIGN.md "relevance"); survivors (~2 % of positions) get queue slots from a wave prefix
 //     sum of the per-lane popcounts.
 //   * CANDIDATES, one per lane, 64 at a time: the mismatch pattern of the read placed at p comes 64 bases
@@ -39,8 +40,9 @@
 //     counters (every XCD works through a contiguous eighth of the batch: neighbouring reads share cache
 //     lines and reference windows in ONE L2).
 //
-// The kernel is bound by instruction issue (vector + scalar), not by HBM (DESIGN.md section 4,
-// profiles/r02/ubench_issue_rates.txt).  No MFMA: this is bit/byte comparison work, not a contraction.
+// The kernel is bound by instruction issue (vector + scalar together: an instruction of either kind costs about 1 ns
+// of SIMD time in situ), not by HBM (profiles/r03/ubench_issue_rates.txt,
+// profiles/r03/issue_calibration.txt).  No MFMA: this is bit/byte comparison work, not a contraction.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -117,6 +119,17 @@ __device__ __forceinline__ u64 low_bits(int n)            // clamped to [0,64]
 __device__ __forceinline__ u32 low32(int n)               // clamped to [0,32]
 {
     return n >= 32 ? 0xffffffffu : (n <= 0 ? 0u : ((1u << n) - 1u));
+}
+// the same for a per-lane n, without the two compare / select pairs (v_cmp + s_nop + v_cndmask each): v_med3 + v_bfm
+// (width n & 31: 0 for n = 32) + the n = 32 case.  (Measured: -1 % where the masks are per read, +0.5 % in the wide
+// far-end windows' loop, which keeps low32.)
+__device__ __forceinline__ u32 low32_lane(int n)
+{
+    int t;
+    asm("v_med3_i32 %0, %1, 0, 32" : "=v"(t) : "v"(n));
+    u32 m;
+    asm("v_bfm_b32 %0, %1, 0" : "=v"(m) : "v"(t));
+    return m | (0u - ((u32)t >> 5));
 }
 __device__ __forceinline__ u64 bit_range(int lo, int hi)  // bits [lo,hi), clamped to [0,64]
 {
@@ -568,8 +581,8 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
     if (nA > 0) {
         const int lA = opaque(lane);
         const int L = S.bps + (lA & 15);
-        const u32 mk = low32(L);
-        const u32 bpm = mk & ~low32(L - S.min_perfect);               // bits [L - m, L)
+        const u32 mk = low32_lane(L);
+        const u32 bpm = mk & ~low32_lane(L - S.min_perfect);               // bits [L - m, L)
         int idx = qb;
         for (int it = 0; it < n_iter; it++, idx += qs) {
             const uint4 e = S.bufA[idx < 67 ? idx : 67];                // (an index past the quarter's list is not used)
@@ -1084,7 +1097,7 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
 #endif
         }
         const int pbase = cs + 32 * lane;
-        const u32 rmask = bits32(ns - pbase, ne - pbase) & ~bits32(xs - pbase, xe - pbase);
+        const u32 rmask = (low32_lane(ne - pbase) & ~low32_lane(ns - pbase)) & ~(low32_lane(xe - pbase) & ~low32_lane(xs - pbase));
         const bool cached = use_cache && k == 0 && cache_valid;
         u32 mF = 0u, mB = 0u;
         if (cached) {
@@ -1434,7 +1447,13 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
         const int strand0 = uni((int)((r1.y >> 16) & 0xffu));
         if (len - 1 >= prm.min_close && (strand0 == '+' || strand0 == '-')) {
             const int apos0 = uni((int)r0.z), isz0 = uni((int)(short)(r1.x >> 16));
-            const int s1 = strand0 == '+' ? apos0 : apos0 - isz0, e1 = s1 + isz0;     // attempt 0: R = 0
+            int s1 = strand0 == '+' ? apos0 : apos0 - isz0, e1 = s1 + isz0;           // attempt 0: R = 0
+#ifndef PG_NO_SHARED_CLOSE_GRID
+            if (isz0 > 0 && 3 * isz0 <= (int)PG_CHUNK) {                              // ... on the grid of the R = 1 window (below)
+                s1 -= isz0;
+                e1 += isz0;
+            }
+#endif
             if (s1 < e1) {
                 const int se = e1 < s1 + (int)PG_CHUNK ? e1 : s1 + (int)PG_CHUNK;
                 stage_window<NB>(ref, S, chr_wo, s1 - 64 * NB, se + 64 * NB, lane);
@@ -1469,8 +1488,19 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
             // use the same orientation of the read, so the seed-filter masks of the first chunk are computed
             // once for both and attempt 2 only adds the flanks to attempt 1's state (the reduction is additive).
             const int w1s = strand == '+' ? apos - isz : apos - 2 * isz, w1e = w1s + 3 * isz;
-            u32 cr0 = 0u, cr1 = 0u;                       // cached masks of the reverse-complemented read
+            // When the R = 1 window fits one chunk (3 InsertSize <= 2048, the usual case), attempt 0 runs on that grid too:
+            // the stage above already brought the whole R = 1 window (one pass of the fill loop either way), and
+            // attempts 0 and 3 -- same orientation, nested windows -- share their seed-filter masks the way attempts 1
+            // and 2 do: a read without a close end costs two filter runs and one fill instead of three and two.
+#ifndef PG_NO_SHARED_CLOSE_GRID
+            const bool shared_grid = isz > 0 && 3 * isz <= (int)PG_CHUNK;
+#else
+            const bool shared_grid = false;
+#endif
+            u32 cr0 = 0u, cr1 = 0u;                       // cached masks of the orientation in hand ...
             bool vr = false;
+            u32 co0 = 0u, co1 = 0u;                       // ... and of the other one (swapped at attempts 1 and 3)
+            bool vo = false;
             int ps = 0, pe = 0, nsurv_eval = 0;
             for (int att = 0; att < 4; att++) {
                 const int Rg = att >> 1;
@@ -1504,9 +1534,17 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                     nsurv_eval = 0;
                     ps = pe = 0;
                 }
-                // one call site: attempt 0 on its own grid, the retries on the grid of the R = 1 window
-                scan_range<NB, Id>(ref, S, Q, A, chr_wo, att == 0 ? s1 : w1s, s1, e1, att == 0 ? e1 : w1e, ps, pe, w1s, 0u,
-                                   opaque(lane), att == 1 || att == 2, cr0, cr1, vr);
+                if (att == 1 || att == 3) {               // the read turns round: the other orientation's masks
+                    const u32 t0 = cr0, t1 = cr1;
+                    const bool tv = vr;
+                    cr0 = co0; cr1 = co1; vr = vo;
+                    co0 = t0; co1 = t1; vo = tv;
+                }
+                // one call site: attempt 0 on its own grid unless the R = 1 window fits a chunk, the retries on the grid
+                // of the R = 1 window
+                const bool own_grid = att == 0 && !shared_grid;
+                scan_range<NB, Id>(ref, S, Q, A, chr_wo, own_grid ? s1 : w1s, s1, e1, own_grid ? e1 : w1e, ps, pe, w1s, 0u,
+                                   opaque(lane), att == 1 || att == 2 || shared_grid, cr0, cr1, vr);
                 ps = s1;
                 pe = e1;
                 if (S.nsurv != nsurv_eval) {
@@ -1672,7 +1710,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                         cacheB = mB;
                         cache_valid = true;
                         const int pbase = g0 + 32 * lane;
-                        const u32 rmask = bits32(rs[R] - pbase, re[R] - pbase);
+                        const u32 rmask = low32_lane(re[R] - pbase) & ~low32_lane(rs[R] - pbase);
                         mF &= rmask;
                         mB &= rmask;
                         const u32 cnt = (u32)(__popc(mF) + __popc(mB));
