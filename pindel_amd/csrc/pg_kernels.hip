@@ -102,6 +102,20 @@ __device__ __forceinline__ u64 read_lane(u64 v, int l)
     return (u64)read_lane((u32)v, l) | ((u64)read_lane((u32)(v >> 32), l) << 32);
 }
 
+// LDS hand-over between the lanes of the workgroup's ONE wave: the LDS unit executes a wave's instructions in order, so all
+// this has to do is keep the compiler from moving LDS reads above LDS writes of other lanes.  (__syncthreads() costs
+// nothing as a barrier here -- the compiler drops s_barrier for a 64-thread workgroup -- but its workgroup-scope fences
+// also wait for every outstanding global load and STORE.)
+#ifdef PG_SYNCTHREADS
+#define PG_SYNC() __syncthreads()
+#else
+#define PG_SYNC()                                              \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+#endif
 // tells the compiler a value is wave-uniform (keeps it in SGPRs)
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // An opaque copy of a per-lane value: expressions built on it cannot be hoisted out of the enclosing
@@ -576,7 +590,7 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
         }
     }
     if (lng) S.hdrB[lane] = make_uint2((u32)id, meta);
-    __syncthreads();
+    PG_SYNC();
     // ---- tier A
     if (nA > 0) {
         const int lA = opaque(lane);
@@ -595,7 +609,7 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
     }
     // ---- tier B (with rings: left to the caller, ring by ring)
     if (!(MIXED && R.on)) fold_tier_b<NB, Id>(S, Q, A, longm, lane);
-    __syncthreads();
+    PG_SYNC();
 }
 
 // Stages bases [lo, hi) (hi - lo <= PG_CHUNK + 128 NB) of a chromosome into LDS: word i of the window
@@ -607,7 +621,7 @@ __device__ __forceinline__ void stage_window(const PgDevRef &ref, Search &S, lon
     const int nw = ((hi - lo + 31) >> 5) + 2;
     const u32 sh = (u32)(lo & 31);
     PG_DG(S, 0);
-    __syncthreads();
+    PG_SYNC();
     {
         const long long g0 = wo + (long long)(lo >> 5);     // arithmetic shift = floor
         const u32 *glo = ref.lo + g0, *ghi = ref.hi + g0, *gnn = ref.nn + g0;
@@ -618,7 +632,7 @@ __device__ __forceinline__ void stage_window(const PgDevRef &ref, Search &S, lon
             *(uint3 *)__builtin_assume_aligned(&S.win[i], 16) = make_uint3(x, y, z);        // (the fourth dword holds the table above)
         }
     }
-    __syncthreads();
+    PG_SYNC();
     S.win_wo = wo;
     S.wbase = lo;
     S.win_lo = lo;
@@ -1073,7 +1087,7 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
                 else break;
                 S.nsurv += n;
                 S.nsurv_total += n;
-                __syncthreads();
+                PG_SYNC();
                 PG_T(S, S.t_base);
                 fold_candidates<NB, Id, MIXED>(S, Q, A, wb, origin, region, n, lane, Rings{ false, 0, 0, 0, 0 }, nullptr);
                 PG_T(S, S.t_base + 1);
@@ -1128,7 +1142,7 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
         const int total = (int)read_lane(incl, 63);
         int slot = (int)(incl - cnt);
         for (int base = 0; base < total; base += WAVE) {
-            __syncthreads();
+            PG_SYNC();
             const int top = base + WAVE;
             while (mF != 0u && slot < top) {
                 const int bit = __ffs((int)mF) - 1;
@@ -1145,7 +1159,7 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
             const int n = total - base < WAVE ? total - base : WAVE;
             S.nsurv += n;
             S.nsurv_total += n;
-            __syncthreads();
+            PG_SYNC();
 #if defined(PG_DUP) && PG_DUP == 4
             {   // diagnostics: the same pass into a throw-away copy of the state
                 Acc<NB, Id> A2 = A;
@@ -1227,7 +1241,7 @@ __device__ __forceinline__ void evaluate(Search &S, const Acc<NB, Id> &A, u32 mm
         if (lane < 16) { a1 = A.a1; a2 = A.a2; aok = A.aok; aid = A.aid; }
         if (qmask != 1) {                                     // uniform (quarter 0 alone: nothing to fetch)
             S.bufA[lane] = make_uint4(A.a1, A.a2 | (A.aok << 16), (u32)A.aid, (u32)((u64)A.aid >> 32));
-            __syncthreads();
+            PG_SYNC();
             if (lane < 16) {
 #pragma unroll
                 for (int q = 1; q < 4; q++) {
@@ -1237,7 +1251,7 @@ __device__ __forceinline__ void evaluate(Search &S, const Acc<NB, Id> &A, u32 mm
                     merge<Id>(a1, a2, aid, aok, o.x, o.y & 0xffffu, oid, o.y >> 16);
                 }
             }
-            __syncthreads();
+            PG_SYNC();
         }
         merge<Id>(t1, t2, tid, tok, a1, a2, aid, aok);
     }
@@ -1372,9 +1386,9 @@ template <int NB>
 __device__ __forceinline__ void store_planes(const PgDevBatch &B, u64 v, int lane, u64 *qp)
 {
     const u32 pb = B.plane_blocks;
-    __syncthreads();
+    PG_SYNC();
     if ((u32)lane < 8u * pb) qp[pb == (u32)NB ? (u32)lane : ((u32)lane / pb) * NB + (u32)lane % pb] = v;
-    __syncthreads();
+    PG_SYNC();
 }
 
 // Bump-allocates n runs in this workgroup's pool shard (one atomic per wave); returns the pool
@@ -1722,7 +1736,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                             pe = re[R];
                             if (total > 0) {
                                 int slot = (int)(incl - cnt);
-                                __syncthreads();
+                                PG_SYNC();
                                 while (mF != 0u) {
                                     const int bit = __ffs((int)mF) - 1;
                                     mF &= mF - 1u;
@@ -1737,7 +1751,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                                 }
                                 S.nsurv += total;
                                 S.nsurv_total += total;
-                                __syncthreads();
+                                PG_SYNC();
                                 int ring_n[3];
                                 PG_T(S, 7);
                                 fold_candidates<NB, Id, true>(S, Q, A, wb, origin, 0u, total, lane,
@@ -1836,7 +1850,7 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
         lds.chr_tab[3 * lane + 1] = (u32)(wo >> 32);
         lds.chr_tab[3 * lane + 2] = ref.chr_size[lane];
     }
-    __syncthreads();
+    PG_SYNC();
     Search S;
     S.queue = lds.queue;
     S.win = lds.win;
@@ -1881,10 +1895,10 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
         }
         const uint32_t first = lo + got, end = hi - first < claim ? hi : first + claim;
         if (PG_REC_LDS(NB)) {
-            __syncthreads();
+            PG_SYNC();
             if ((uint32_t)lane < 8u * (end - first))
                 ((u32 *)lds.rec)[lane] = ((const u32 *)(B.in + B.first_read + first))[lane];
-            __syncthreads();
+            PG_SYNC();
         }
         PG_T(S, 11);
         // run-pool slots of the claim's reads: one atomic per claim (its round trip overlaps the record load above)
