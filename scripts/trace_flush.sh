@@ -13,7 +13,7 @@ for f in glob.glob('/tmp/tr50/**/*.csv', recursive=True):
         rows.append((s,e,kind,name[:60], r.get('Size','') ))
 rows.sort()
 # last pg_search_batch call: find the last hipMemsetAsync burst... just print the last 90 events
-t0=rows[-90][0]
-for s,e,k,n,sz in rows[-90:]:
+t0=rows[-int(__import__("os").environ.get("TR_N","90"))][0]
+for s,e,k,n,sz in rows[-int(__import__("os").environ.get("TR_N","90")):]:
     print(f"{(s-t0)/1000:9.1f} us  +{(e-s)/1000:8.1f} us  {k:7s} {n} {sz}")
 PY
