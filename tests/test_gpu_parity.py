@@ -543,6 +543,33 @@ def test_more_than_127_windows_in_a_cluster(engine_factory):
     assert len(far) > 1000
 
 
+@pytest.mark.parametrize("read_len", [50, 150])
+def test_plane_layout_narrower_than_the_kernel_blocks(engine_factory, read_len):
+    """The pack kernel lays the reads' bit planes out in pg_plane_blocks(longest read) 64-base blocks (1 for 50-base reads,
+    3 for 150-base ones); the search kernel with 64-bit candidate ids (forced here by clusters of more than 127 windows)
+    is compiled for 2 and 4 blocks: the missing blocks must read as zero.  == the oracle."""
+    from pindel_amd import binding
+    ref = [("chrA", synth.make_reference(400_000, seed=61))]
+    eng = engine_factory()
+    eng.load_reference(ref)
+    batch = synth.make_reads(ref[0][1], 300, seed=62 + read_len, read_len=read_len)
+    rng = np.random.default_rng(63)
+    per = 140
+    bd = np.zeros(batch.n * per, dtype=binding.WINDOW_DTYPE)
+    st = rng.integers(100_000, 400_000 - 100_400, len(bd))
+    bd["start"] = st
+    bd["end"] = st + rng.integers(50, 400, len(bd))
+    ap = batch.anchor_pos.astype(np.int64) + 100_000
+    bd["start"][::per] = np.clip(ap - 3000, 100_000, 290_000)
+    bd["end"][::per] = bd["start"][::per] + 6000
+    bd_off = (np.arange(batch.n + 1) * per).astype(np.uint64)
+    orc = run_oracle({}, ref, batch, bd=bd, bd_off=bd_off)
+    close = eng.close_end_batch(batch)
+    both = eng.far_end_batch(batch, close, bd, bd_off)
+    compare_result(both, orc, batch.n)
+    assert (orc["close_cnt"] > 0).sum() > 100 and (orc["far_cnt"] > 0).sum() > 50
+
+
 def test_window_of_more_than_2_26_positions(engine_factory):
     """A search window wider than the 26-bit position field of a candidate id is searched as consecutive pieces (the
     reduction is additive over disjoint position sets): same points as the oracle on the whole window."""
