@@ -9,12 +9,17 @@
 //                                          needs nothing but the reads themselves -- UnmatchedSeq as the
 //                                          close end left it and UP_Close.back()
 //
-// Both are templates over the read type so that they compile unchanged against the
-// reference's SPLIT_READ (fields Name/UnmatchedSeq/MatchedD/MatchedRelPos/InsertSize/FragName/
-// UP_Close/UP_Far, src/pindel.h:265-383) and against pgh::SplitRead used by this repository's
-// own command line.  They restore exactly the post-state the reference leaves behind:
-// UnmatchedSeq reverse-complemented when GetCloseEnd did so, UP_Close after CleanUniquePoints,
-// UP_Far untouched by any pruning.
+// Both are templates over the read type.  What they use of it is the public interface of the reference's SPLIT_READ /
+// SortedUniquePoints / UniquePoint and nothing more (src/pindel.h:137-197, 265-383): the fields UnmatchedSeq /
+// MatchedD / MatchedRelPos / InsertSize / UP_Close / UP_Far, setUnmatchedSeq() when the read type has one
+// (src/pindel.cpp:142-169, what GetCloseEnd calls at :2545), and of the point lists only push_back / size / empty /
+// operator[] / clear -- `reserve` is used where a container offers it (std::vector-backed lists such as
+// pgh::SplitRead's) and skipped where it does not (the reference's SortedUniquePoints).
+// tests/test_cpu_suite.py::test_adapter_compiles_against_reference_shapes instantiates all three entry points against
+// tests/ref_shapes.hpp (those declarations restated), tests/test_gpu_parity.py::test_adapter_on_reference_shapes runs
+// them on the GPU against the oracle; pindel_pg_main.cpp instantiates them with pgh::SplitRead.
+// They restore the post-state the reference leaves behind: UnmatchedSeq reverse-complemented when GetCloseEnd did so,
+// UP_Close after CleanUniquePoints, UP_Far untouched by any pruning.
 //
 // The per-read work either side of the GPU call (gathering the bases into one buffer, expanding the
 // run-length-encoded lists into UniquePoints) is spread over host threads in contiguous read ranges: it
@@ -26,6 +31,8 @@
 #include <cstdint>
 #include <string>
 #include <thread>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "pindel_pg.h"
@@ -125,14 +132,28 @@ Batch make_batch(const std::vector<Read> &reads, ChrOf chr_of, const uint8_t *un
     return b;
 }
 
+// optional members of the caller's types (detection idiom): Points::reserve, Read::setUnmatchedSeq
+template <class T, class = void> struct has_reserve : std::false_type {};
+template <class T> struct has_reserve<T, decltype((void)std::declval<T &>().reserve((size_t)1))> : std::true_type {};
+template <class T> inline void reserve_if_possible(T &c, size_t n, std::true_type) { c.reserve(n); }
+template <class T> inline void reserve_if_possible(T &, size_t, std::false_type) {}
+template <class T, class = void> struct has_set_seq : std::false_type {};
+template <class T>
+struct has_set_seq<T, decltype((void)std::declval<T &>().setUnmatchedSeq(std::declval<const std::string &>()))> : std::true_type {};
+// "read.setUnmatchedSeq(ReverseComplement(read.getUnmatchedSeq()))" (src/pindel.cpp:2545)
+template <class Read> inline void flip_read(Read &r, std::true_type) { r.setUnmatchedSeq(rc(r.UnmatchedSeq)); }
+template <class Read> inline void flip_read(Read &r, std::false_type) { rc_in_place(r.UnmatchedSeq); }
+
 // make_point(pg_point) -> the read type's UniquePoint; the runs [lo, hi) are expanded in place
 template <class Points, class MakePoint>
 void fill_points(Points &dst, const pg_run *runs, uint64_t lo, uint64_t hi, MakePoint make_point)
 {
     dst.clear();
-    size_t total = 0;
-    for (uint64_t k = lo; k < hi; k++) total += (size_t)(runs[k].len_last - runs[k].len_first) + 1;
-    dst.reserve(total);
+    if (has_reserve<Points>::value) {
+        size_t total = 0;
+        for (uint64_t k = lo; k < hi; k++) total += (size_t)(runs[k].len_last - runs[k].len_first) + 1;
+        reserve_if_possible(dst, total, has_reserve<Points>());
+    }
     for (uint64_t k = lo; k < hi; k++) {
         const pg_run &r = runs[k];
         const bool back = (r.flags & PG_RUN_BACKWARD) != 0;
@@ -164,7 +185,7 @@ int CloseEndBatch(pg_ctx *ctx, std::vector<Read> &reads, ChrOf chr_of, MakePoint
     pg_result_view_get(*result, &rv);
     parallel_ranges(reads.size(), [&](size_t lo, size_t hi) {
         for (size_t i = lo; i < hi; i++) {
-            if (rv.rc_flag[i]) rc_in_place(reads[i].UnmatchedSeq);     // setUnmatchedSeq(RC), pindel.cpp:2545
+            if (rv.rc_flag[i]) flip_read(reads[i], has_set_seq<Read>());
             fill_points(reads[i].UP_Close, rv.close_runs, rv.close_off[i], rv.close_off[i + 1], make_point);
         }
     });

@@ -267,3 +267,25 @@ def test_pindel_text_loader_framing_and_errors(tmp_path):
     text = b"".join(rec(k, strand=b"x") if k in (300, 19000) else rec(k) for k in range(20000))
     with pytest.raises(RuntimeError, match="expected in read @r300/1"):
         run(text, 20000)
+
+
+def test_adapter_compiles_against_reference_shapes(tmp_path):
+    """The reference-side binding of INTEGRATION.md (pg_adapter.hpp: CloseEndBatch and both SearchFarEnds overloads)
+    instantiated against the public interface of the reference's SPLIT_READ / SortedUniquePoints / UniquePoint
+    (tests/ref_shapes.hpp restates src/pindel.h:137-197, 265-383: no reserve, no iterators, private storage)."""
+    import subprocess
+    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+           "-I" + os.path.join(ROOT, "pindel_amd", "csrc", "host"), "-I" + os.path.join(ROOT, "tests"),
+           os.path.join(ROOT, "tests", "adapter_ref_shapes.cpp")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    # the mock is not more generous than the reference: a vector-only member must fail to compile against it
+    probe = tmp_path / "probe.cpp"
+    probe.write_text('#include "ref_shapes.hpp"\nvoid f(SortedUniquePoints &p) { p.reserve(4); }\n')
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I" + os.path.join(ROOT, "tests"), str(probe)],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "reserve" in r.stderr
+    # ... and the same adapters still serve this repository's own read type (std::vector point lists)
+    cmd[-1] = os.path.join(ROOT, "pindel_amd", "csrc", "host", "pindel_pg_main.cpp")
+    r = subprocess.run([c for c in cmd if c != "-Werror"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

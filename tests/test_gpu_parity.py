@@ -631,3 +631,66 @@ def test_host_pipeline_chunk_boundaries_equal_the_device_resident_path(engine_fa
         assert np.array_equal(close.rc_flag, dev["rc_flag"]) and int(close.far_off[-1]) == 0
     small = big.slice(chunk - 3000, chunk + 3000)              # (reads on both sides of a chunk boundary of the full batch)
     compare_result(eng.search_batch(small), run_oracle({}, small_ref, small), small.n)
+
+
+def test_adapter_on_reference_shapes(engine_factory, tmp_path):
+    """INTEGRATION.md's binding run against reference-shaped types (tests/ref_shapes.hpp = the public interface of
+    src/pindel.h's SPLIT_READ / SortedUniquePoints / UniquePoint): seam 1 in 700-read flushes, the reads with a close end
+    kept, seam 2 on their union (both overloads); every UniquePoint and the sequence left behind equal the oracle's."""
+    import os
+    import subprocess
+    from pindel_amd import binding
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "adapter_ref_shapes"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(root, "include"),
+                    "-I" + os.path.join(root, "pindel_amd", "csrc", "host"), "-I" + os.path.join(root, "tests"),
+                    os.path.join(root, "tests", "adapter_ref_shapes.cpp"), "-L" + os.path.join(root, "pindel_amd"),
+                    "-lpindel_pg", "-pthread", "-Wl,-rpath," + os.path.join(root, "pindel_amd"), "-o", str(exe)], check=True)
+    spacer = 100_000
+    chroms = [("chrA", synth.make_reference(400_000, seed=21)), ("chrB", synth.make_reference(300_000, seed=22))]
+    fa = tmp_path / "ref.fa"
+    with open(fa, "w") as f:
+        for name, padded in chroms:
+            body = bytes(padded[spacer:-spacer]).decode()
+            # Genome::loadChromosome repeats the final base of the last record (pindel.cpp:288-299): end it with a
+            # throw-away record so that the real ones load as they are
+            f.write(f">{name}\n{body}\n")
+        f.write(">tail\nA\n")
+    chroms_loaded = chroms + [("tail", b"N" * spacer + b"AA" + b"N" * spacer)]
+    batch = synth.make_reads_genome(chroms, 2500, seed=23)
+    tab = tmp_path / "reads.txt"
+    with open(tab, "w") as f:
+        for i in range(batch.n):
+            s = bytes(batch.seq[batch.seq_off[i]:batch.seq_off[i + 1]]).decode()
+            f.write(f"r{i} {chroms[batch.chr_id[i]][0]} {chr(batch.anchor_strand[i])} {batch.anchor_pos[i]} "
+                    f"{batch.insert_size[i]} {s}\n")
+    out = tmp_path / "out.txt"
+    subprocess.run([str(exe), str(fa), str(tab), "700", str(out), "both"], check=True)
+    orc = run_oracle({}, chroms_loaded, batch)
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    lines = open(out).read().splitlines()
+    n_first = 0
+    for ln in lines:
+        tok = ln.split()
+        first = tok[0] == "first"
+        if first:
+            tok = tok[1:]
+            n_first += 1
+        i = int(tok[0][1:])
+        k = 1
+        if not first:
+            s = bytes(batch.seq[batch.seq_off[i]:batch.seq_off[i + 1]])
+            want = s.translate(comp)[::-1] if orc["rc_flag"][i] else s
+            assert tok[1].encode() == want, f"read {i}: UnmatchedSeq"
+            k = 2
+        while k < len(tok):
+            which = {"C": "close", "F": "far"}[tok[k]]
+            cnt = int(tok[k + 1])
+            got = [tuple(t.split(",")) for t in tok[k + 2:k + 2 + cnt]]
+            k += 2 + cnt
+            o = orc[which + "_pts"][i][:orc[which + "_cnt"][i]]
+            exp = [(str(int(p["length"])), str(int(p["abs_loc"])), p["direction"].decode(), p["strand"].decode(),
+                    str(int(p["mismatches"])), str(int(p["chr_id"]))) for p in o]
+            assert got == exp, f"read {i} {which}{' (one-flush overload)' if first else ''}"
+    assert len(lines) - n_first == batch.n and n_first == 700
+    assert (orc["far_cnt"] > 0).sum() > 800
