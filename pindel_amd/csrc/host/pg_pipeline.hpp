@@ -55,10 +55,12 @@ inline void release_reads(std::vector<SplitRead> &v)
 //   search(chrom, chr_id, reads, index_in_all)   on ALL reads of the window: must fill UP_Close (empty when there is no
 //                                                close end) and leave UnmatchedSeq as GetCloseEnd would
 //                                                (ReadBuffer::flush, src/read_buffer.cpp:36-101); may fill UP_Far too
-//   far_search(chrom, chr_id, kept)              on the reads that kept a close end (state.Reads_SR): fills UP_Far
-//                                                (SearchFarEnds, src/pindel.cpp:1115-1138, called at :1888)
+//   far_search(chrom, chr_id, kept, ws, we)      on the reads that kept a close end (state.Reads_SR): fills UP_Far
+//                                                (SearchFarEnds, src/pindel.cpp:1115-1138, called at :1888); [ws, we) =
+//                                                the window being processed, biological coordinates (currentWindow,
+//                                                src/pindel.cpp:1828: what g_bdData.loadRegion is given at :1853)
 struct NoFarSearch {
-    int operator()(const Chromosome &, int, std::vector<SplitRead> &) const { return 0; }
+    int operator()(const Chromosome &, int, std::vector<SplitRead> &, unsigned, unsigned) const { return 0; }
 };
 
 template <class Search, class FarSearch>
@@ -137,7 +139,7 @@ int run_pipeline(const std::vector<Chromosome> &genome, const std::vector<unsign
             for (SplitRead &r : reads)
                 if (!r.UP_Close.empty()) kept.push_back(std::move(r));      // `reads` is not used after this loop
             t_keep += now() - t0; t0 = now();
-            if (!kept.empty() && (rc = far_search(chrom, (int)c, kept))) {
+            if (!kept.empty() && (rc = far_search(chrom, (int)c, kept, ws, we))) {
                 err = "far-end search step failed";
                 return rc;
             }
@@ -185,7 +187,7 @@ struct CloseView {
 //   close_soa(chrom, chr_id, batch, view)   ReadBuffer::flush on the window's candidates as ingested (SoA): the close
 //                                           ends as run lists + rc flags; only the reads that have one become SplitReads
 //                                           (UnmatchedSeq reverse-complemented where GetCloseEnd did, UP_Close filled)
-//   far_search(chrom, chr_id, kept)         SearchFarEnds on those reads
+//   far_search(chrom, chr_id, kept, ws, we) SearchFarEnds on those reads; [ws, we) = the window (for the hints' loadRegion)
 //
 // The windows are a three-stage pipeline on the host: while window k is searched and classified, a second thread
 // already reads window k + 1 from the BAMs (read-pair discovery + ingest, the stage that dominates a BAM-fed run).
@@ -335,7 +337,7 @@ int run_bam_pipeline(const std::vector<Chromosome> &genome, const std::vector<un
         if (view.release) view.release();
         caller.note_close_mapped_all(kept);
         t_keep += now() - t0; t0 = now();
-        if (!kept.empty() && (rc = far_search(chrom, (int)c, kept))) {
+        if (!kept.empty() && (rc = far_search(chrom, (int)c, kept, win.ws, win.we))) {
             err = "far-end search step failed";
             status = rc;
             break;

@@ -320,16 +320,15 @@ int main(int argc, char **argv)
     };
     // Seam 2 (SearchFarEnds, src/pindel.cpp:1115-1138, called at :1888 on state.Reads_SR): the far end of the reads that
     // kept a close end -- the filtered union of the flushes -- through pg_far_end_batch_from_close.
-    auto far_search = [&](const Chromosome &, int, std::vector<SplitRead> &kept) {
+    auto far_search = [&](const Chromosome &, int chr_id, std::vector<SplitRead> &kept, unsigned ws, unsigned we) {
         const double t0 = now_s();
         if (use_bd && bd.n_events() && !kept.empty()) {
-            // the bin of these reads, as main() hands it to g_bdData.loadRegion (pindel.cpp:1828, 1853)
-            unsigned lo = kept[0].MatchedRelPos;
-            for (const SplitRead &x : kept) lo = std::min(lo, x.MatchedRelPos);
-            const unsigned W = (unsigned)(S.window_mbp * 1000000);
-            const unsigned ws = lo / W * W, we = ws + W;
+            // the window main() is working on, as it hands it to g_bdData.loadRegion (currentWindow_cs, pindel.cpp:1828, 1853):
+            // [ws, we) + spacer, we clipped to the end of the scanned region (LoopingSearchWindow::updateEndPositions).  NOT
+            // derived from the reads: a BAM window also holds reads whose anchor lies before ws (reader.cpp has no position
+            // filter on that path), and the bin of min(MatchedRelPos) would then be the previous window.
             std::string berr;
-            if (!bd.load_region(chr_names, kept[0].chr_id, ws + prm.spacer, we + prm.spacer, berr)) {
+            if (!bd.load_region(chr_names, chr_id, ws + prm.spacer, we + prm.spacer, berr)) {
                 fprintf(stderr, "pindel_pg: %s\n", berr.c_str());
                 return (int)PG_E_INVALID;
             }

@@ -692,6 +692,76 @@ def test_command_line_read_pair_hints_find_large_deletions(tmp_path):
         assert filecmp.cmp(tmp_path / ("hinted" + sfx), tmp_path / ("sharded" + sfx), shallow=False), sfx
 
 
+@pytest.mark.gpu
+def test_command_line_hints_use_the_window_not_the_reads_bin(tmp_path):
+    """Several windows (-w 0.1) over one BAM with a BreakDancer file: g_bdData.loadRegion gets the window main() is
+    working on (src/pindel.cpp:1828, 1853), not a bin derived from the reads.  Every window from the second on holds a
+    split read whose '+' anchor starts 50 bases BEFORE the window (the BAM query returns records reaching into it,
+    reader.cpp has no position filter on this path); a bin taken from the smallest anchor position would be the previous
+    window and every read further than 3 kb into the real one would lose its hints -- the 8-30 kb deletions in the middle
+    of the windows, out of reach of the ranges at -x 2, would go uncalled."""
+    import subprocess
+    from pindel_amd import binding, synth
+    rng = np.random.default_rng(11)
+    ref = synth.make_reference(600_000, seed=93)
+    biol = np.frombuffer(ref, dtype=np.uint8)[100000:-100000]
+    fa = tmp_path / "ref.fa"
+    with open(fa, "wb") as fh:
+        fh.write(b">chrD\n")
+        for i in range(0, len(biol), 60):
+            fh.write(biol[i:i + 60].tobytes() + b"\n")
+    (tmp_path / "ref.fa.fai").write_text(f"chrD\t{len(biol)}\t6\t60\t61\n")
+    comp = np.zeros(256, np.uint8)
+    for x, y in zip(b"ACGTN", b"TGCAN"):
+        comp[x] = y
+    L, isz, recs, dels, k = 100, 400, [], [], 0
+
+    def split_pair(apos, a, b, sp):
+        nonlocal k
+        read = np.concatenate([biol[a - sp:a], biol[b:b + L - sp]])
+        recs.append(dict(qname=f"s{k}", flag=F["PAIRED"] | F["READ1"] | F["MUNMAP"], tid=0, mtid=0, pos=apos, mpos=apos, mapq=60,
+                         cigar=[(0, L)], seq=biol[apos:apos + L].tobytes().decode(), tlen=0))
+        recs.append(dict(qname=f"s{k}", flag=F["PAIRED"] | F["READ2"] | F["UNMAP"], tid=0, mtid=0, pos=apos, mpos=apos, mapq=0,
+                         cigar=[], seq=comp[read[::-1]].tobytes().decode(), tlen=0))
+        k += 1
+
+    W = 100_000
+    for w in range(1, 5):
+        # the straddler: anchor [w W - 50, w W + 50), its mate across a 60-base deletion 200 bases into the window
+        split_pair(w * W - 50, w * W + 200, w * W + 260, 50)
+        a = w * W + 40_000 + int(rng.integers(0, 3000))
+        b = a + int(rng.integers(8_000, 30_000))
+        dels.append((a, b))
+        for j in range(10):
+            sp = int(rng.integers(30, 70))
+            split_pair(a - sp - 120 - 13 * j, a, b, sp)
+    recs.sort(key=lambda r: r["pos"])
+    bw.write_bam(str(tmp_path / "w.bam"), [("chrD", len(biol))], recs, with_index=True)
+    (tmp_path / "cfg.txt").write_text(f"w.bam\t{isz}\tTUMOR\n")
+    bd_lines = ["#Chr1\tPos1\tOri1\tChr2\tPos2\tOri2\tType\tSize\tScore\tReads"]
+    bd_lines += [f"chrD\t{a}\t5+0-\tchrD\t{b}\t0+5-\tDEL\t{b - a}\t99\t5" for a, b in dels]
+    (tmp_path / "bd.txt").write_text("\n".join(bd_lines) + "\n")
+    exe = os.path.join(os.path.dirname(binding.LIB_PATH), "pindel_pg")
+
+    def called(prefix, *extra):
+        out = subprocess.run([exe, "-f", str(fa), "-i", str(tmp_path / "cfg.txt"), "-o", str(tmp_path / prefix),
+                              "-b", str(tmp_path / "bd.txt"), *extra], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        sizes = set()
+        for line in open(tmp_path / (prefix + "_D")):
+            f = line.split("\t")
+            if len(f) > 5 and f[1].startswith("D "):
+                sizes.add(int(f[1].split()[1]))
+        return sizes
+
+    want = {b - a for a, b in dels}
+    one = called("one_window")                               # the default 5-Mbp window: one bin, nothing to get wrong
+    assert want <= one
+    many = called("many_windows", "-w", "0.1")
+    assert want <= many, sorted(want - many)
+    assert {s for s in many if s >= 8000} == want
+
+
 def test_damaged_bam_is_an_error_not_a_short_file(tmp_path):
     """A corrupt or truncated BGZF block must fail the window ("BAM read failed"), not end it quietly with a partial
     read set (the clean end-of-file marker is the only way a file may end)."""
