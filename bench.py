@@ -144,6 +144,17 @@ def issue_model(args, kernel_ms, reads_per_launch):
     return out
 
 
+def pack_roofline(batch, pack_ms):
+    """Second roofline entry: the pack kernel (a streaming transpose, HBM-bound by nature)."""
+    lens = batch.lengths()
+    ml = int(lens.max()) if batch.n else 1
+    blocks = 1 if ml <= 64 else 2 if ml <= 128 else 3 if ml <= 192 else 4 if ml <= 256 else 8
+    nbytes = float(lens.sum()) + batch.n * (8 + 11 + 64 * blocks + 32)
+    achieved = nbytes / (pack_ms * 1e-3) / 1e9 if pack_ms > 0 else 0.0
+    return {"bound": "hbm", "kernel": "pg_pack_kernel", "kernel_ms": pack_ms, "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes, "traffic": None}
+
+
 def self_spawn(args):
     """`python bench.py --gpus N` without a launcher: run N ranks under torch.distributed.run."""
     s = socket.socket()
@@ -348,7 +359,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- outside the timed region: accounting, result digests, the host-buffer seam, the CPU baseline
+    # ---- outside the timed region: accounting, result digests, the pack stage, the host-buffer seam, the CPU baseline
+    # The pack stage (pg_pack_kernel: ASCII bases as src/reader.cpp:852-856 hands them over -> the bit planes + packed
+    # records the search kernel reads) runs once at upload, before the timed region; its own duration on this batch, HIP
+    # events on the ctx's stream, goes on the record beside `value` (config.pack_ms_per_step, config.value_incl_pack,
+    # roofline.pack).  Bytes per read: len + 8 (offset) + 11 (strand, position, insert size, chromosome) in, 64 x blocks
+    # (planes) + 32 (record) out.
+    pack_ms = min(eng.repack(dbatch) for _ in range(5))
     if bins is not None:
         eng.search_device(dbatch)                 # the whole batch once, for the accounting below (same reads)
     alg_bytes = eng.algorithmic_bytes(dbatch)     # per launch
@@ -410,6 +427,8 @@ def main():
                 "candidates_per_read": n_cand / max(batch.n, 1),    # seed-filter survivors that went through the full comparison
                 "result_sha256": shard.digest_hex(digests),
                 "host_path_reads_per_s": host_path,
+                "pack_ms_per_step": pack_ms,
+                "value_incl_pack": units * args.steps / (elapsed + args.steps * pack_ms * 1e-3),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -418,6 +437,7 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "actual_bound": "instruction issue (VALU + scalar), see DESIGN.md section 4",
                 "issue": issue_model(args, avg_ms, batch.n),
+                "pack": pack_roofline(batch, pack_ms),
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -205,6 +205,10 @@ int  pg_device_batch_set_windows(pg_ctx *ctx, pg_device_batch *b, const pg_windo
  * Synchronous: returns when the kernels have finished. */
 int  pg_device_batch_search(pg_ctx *ctx, pg_device_batch *b);
 int  pg_device_batch_download(pg_ctx *ctx, pg_device_batch *b, pg_result **out);
+/* Measurement: runs the pack stage of pg_device_batch_upload again on the resident batch -- ASCII bases (what
+ * src/reader.cpp:852-856 hands over) -> the bit planes and packed records the search kernel reads; idempotent -- and
+ * returns its HIP-event duration in ms (events on the ctx's own stream). */
+int  pg_device_batch_repack(pg_ctx *ctx, pg_device_batch *b, double *pack_ms);
 void pg_device_batch_free(pg_ctx *ctx, pg_device_batch *b);
 /* HIP-event duration (ms) of the kernel of the last search on this ctx (events recorded on
  * the ctx's own stream around the launch) and the run-pool slots it took (reserved per read + allocated; the number

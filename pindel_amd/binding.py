@@ -68,7 +68,7 @@ EXPORTS = [
     "pg_search_batch", "pg_search_batch_multi", "pg_result_view_get", "pg_result_free", "pg_expand_runs",
     "pg_device_batch_upload", "pg_device_batch_set_windows", "pg_device_batch_search", "pg_device_batch_download",
     "pg_device_batch_free", "pg_last_search_stats", "pg_device_batch_algorithmic_bytes",
-    "pg_device_batch_candidates"]
+    "pg_device_batch_candidates", "pg_device_batch_repack"]
 
 
 def build(force: bool = False) -> str:
@@ -142,6 +142,7 @@ def lib():
     L.pg_last_search_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64)]
     L.pg_device_batch_algorithmic_bytes.argtypes = [vp, vp, C.POINTER(C.c_double)]
     L.pg_device_batch_candidates.argtypes = [vp, vp, C.POINTER(C.c_double)]
+    L.pg_device_batch_repack.argtypes = [vp, vp, C.POINTER(C.c_double)]
     _lib = L
     return L
 
@@ -357,6 +358,12 @@ class Engine:
 
     def search_device(self, dbatch):
         self._check(self._L.pg_device_batch_search(self._h, dbatch))
+
+    def repack(self, dbatch) -> float:
+        """The pack stage (ASCII bases -> bit planes + packed records) again on the resident batch; HIP-event ms."""
+        ms = C.c_double()
+        self._check(self._L.pg_device_batch_repack(self._h, dbatch, C.byref(ms)))
+        return ms.value
 
     def download(self, dbatch) -> Result:
         h = C.c_void_p()

@@ -509,7 +509,7 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, PodVec<uint6
     // (pointer, bytes) of every buffer; the zeroed block (outputs) is contiguous in the arena case
     struct Item { void **p; size_t bytes; };
     const Item items[] = {
-        { (void **)&b->seq, std::max<size_t>((size_t)nseq, 1) }, { (void **)&b->seq_off, (n + 1) * 8 },
+        { (void **)&b->seq, (size_t)nseq + 16 }, { (void **)&b->seq_off, (n + 1) * 8 },
         { (void **)&b->strand, n1 }, { (void **)&b->pos, n1 * 4 }, { (void **)&b->isz, n1 * 2 }, { (void **)&b->chr, n1 * 4 },
         { (void **)&b->in_rec, n1 * sizeof(PgInRec) },
         { (void **)&b->planes, n1 * 64 * pg_plane_blocks(max_len) },
@@ -1211,6 +1211,21 @@ int pg_device_batch_search(pg_ctx *ctx, pg_device_batch *b)
     if (!ctx || !b) return PG_E_INVALID;
     b->modes_done = 0;
     return run_search(ctx, b, PG_MODE_BOTH);
+}
+
+int pg_device_batch_repack(pg_ctx *ctx, pg_device_batch *b, double *pack_ms)
+{
+    use_device(ctx);
+    if (!ctx || !b) return PG_E_INVALID;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    int rc = b->n ? pack_reads(ctx, b, 0, b->n) : PG_OK;
+    if (rc) return rc;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    if (pack_ms) *pack_ms = ms;
+    return PG_OK;
 }
 
 int pg_device_batch_download(pg_ctx *ctx, pg_device_batch *b, pg_result **out)

@@ -13,7 +13,7 @@
 //   * The chromosome lives in HBM as three bit planes (2-bit code planar + N plane).  A window chunk
 //     (2048 positions + overhang) is staged into LDS with coalesced dword loads as code planes; the seed filter derives
 //     the one-hot planes (is-A/C/G/T/not-N) of its words from them.  The reads arrive as bit planes too (built by
-//     pg_pack_planes_kernel, a wave per 64-base block), one 8-byte load per lane and read.
+//     pg_pack_kernel), one 8-byte load per lane and read.
 //   * SEED FILTER, bit sliced: each lane owns the 32 window positions of one LDS word.  The match mask of
 //     consumed base j for all 32 positions is one v_alignbit of the one-hot plane of that read symbol;
 //     mismatch counts live in a bit-sliced carry-save counter (3 to 5 slices of 32 bits).  It keeps exactly the seeds that
@@ -1963,64 +1963,149 @@ static void launch(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch
 
 // ---------------------------------------------------------------------------------
 // Packed per-read records <-> the SoA arrays of the C ABI (pg_device.h).
-__global__ void pg_pack_reads_kernel(PgSoaIn a, PgInRec *in, uint32_t lo, uint32_t cnt)
+//
+// pg_pack_kernel: ASCII reads -> the 32-byte input record + the bit planes the search kernel reads (PgDevBatch::planes:
+// u64[2 orientations][4 planes][PB blocks] per read; code A=0 C=1 G=2 T=3, N and "other" (matches nothing) as planes of
+// their own; orientation 1 = the read from its last base).  A streaming transpose, HBM-bound by nature
+// (len + 27 bytes in, 64 PB + 32 out per read), so it is laid out for bandwidth, not for a wave per block:
+//   * 8 PB consecutive lanes own one read, lane L its bases [8 L, 8 L + 8): the wave's loads walk the concatenated
+//     sequence buffer in 8-byte steps (three aligned dword loads + v_alignbyte per lane; any read alignment), the
+//     bases are classified four at a time with exact SWAR byte compares, no ballots;
+//   * a 4 x 4 byte transpose inside every lane quad (two quad shuffles) turns "8 bases x 4 planes" per lane into
+//     "32 bases of ONE plane" per lane: lane (D, p) = dword D of plane p, so the read's 8 PB lanes write its forward
+//     planes as 8 PB dwords that tile 32 PB contiguous bytes;
+//   * the reversed orientation is the same bit string mirrored: dword D of it is a 32-bit window of the forward plane
+//     at bit len - 32 - 32 D, bit-reversed -- two lane shuffles + v_alignbit + v_bfrev, no second pass over the bases.
+__device__ __forceinline__ u32 swar_eq(u32 w, u32 k)         // 0x80 in every byte of w that equals the byte of k
 {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= cnt) return;
-    const uint32_t i = lo + k;
-    PgInRec r;
-    r.seq_off = a.seq_off[i];
-    const uint32_t len = (uint32_t)(a.seq_off[i + 1] - a.seq_off[i]);
-    r.apos = a.pos[i] + (int32_t)a.spacer;
-    r.chr = a.chr[i];
-    r.len = (uint16_t)len;
-    r.isz = a.isz[i];
-    r.thr = a.thr[len < 512u ? len : 511u];
-    r.strand = a.strand[i];
-    r.M = (uint8_t)a.mm[len < 512u ? len : 511u];
-    r.bd_cnt = 0;
-    r.bd_off = 0;
-    if (a.bd_off) {
-        r.bd_off = (uint32_t)a.bd_off[i];
-        r.bd_cnt = (uint32_t)(a.bd_off[i + 1] - a.bd_off[i]);
-    }
-    in[i] = r;
+    const u32 x = w ^ k;
+    const u32 t = (x & 0x7f7f7f7fu) + 0x7f7f7f7fu;
+    return ~(t | x) & 0x80808080u;
 }
-
-// The reads' bit planes (PgDevBatch::planes): a wave takes PG_PLANES_PER_WAVE (read, 64-base block) pairs, one after
-// the other (lanes = bases); code A=0 C=1 G=2 T=3, N and "other" (matches nothing) as planes of their own; orientation 1
-// = the read from its last base.
-#define PG_PLANES_PER_WAVE 16u
-__global__ __launch_bounds__(256) void pg_pack_planes_kernel(PgSoaIn a, uint32_t lo, uint32_t cnt)
+__device__ __forceinline__ u32 swar_bits(u32 m)               // the four 0x80 flags of m as bits 0..3
 {
-    const uint32_t pb = a.plane_blocks, lane = threadIdx.x & 63u;
-    const uint64_t total = (uint64_t)cnt * pb;
-    const uint64_t w0 = ((uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6)) * PG_PLANES_PER_WAVE;
-    for (uint32_t t = 0; t < PG_PLANES_PER_WAVE; t++) {
-        const uint64_t w = w0 + t;
-        if (w >= total) break;                                // (whole waves)
-        const uint32_t i = lo + (uint32_t)(w / pb), b = (uint32_t)(w % pb);
-        const uint8_t *seq = a.seq + a.seq_off[i];
-        const uint32_t len = (uint32_t)(a.seq_off[i + 1] - a.seq_off[i]);
-        const uint32_t idx = 64u * b + lane;
-        const bool in = idx < len;
-        const uint8_t cf = in ? seq[idx] : 0, cr = in ? seq[len - 1u - idx] : 0;
-        const bool fA = cf == 'A', fC = cf == 'C', fG = cf == 'G', fT = cf == 'T', fN = cf == 'N';
-        const bool rA = cr == 'A', rC = cr == 'C', rG = cr == 'G', rT = cr == 'T', rN = cr == 'N';
-        u64 v[8];
-        v[QP_LO] = ballot64(fC || fT);
-        v[QP_HI] = ballot64(fG || fT);
-        v[QP_NN] = ballot64(fN);
-        v[QP_OO] = ballot64(in && !(fA || fC || fG || fT || fN));
-        v[4 + QP_LO] = ballot64(rC || rT);
-        v[4 + QP_HI] = ballot64(rG || rT);
-        v[4 + QP_NN] = ballot64(rN);
-        v[4 + QP_OO] = ballot64(in && !(rA || rC || rG || rT || rN));
-        if (lane < 8u) {
-            u64 mine = v[0];
+    return (((m >> 7) * 0x01020408u) >> 24) & 0xfu;
+}
+// PG_PACK_UNROLL reads per 8 PB-lane group, their loads issued together: the kernel is a chain of two dependent HBM round
+// trips (offsets -> bases) and moves only ~280 bytes per read, so what bounds it is bytes in flight per CU, not
+// instructions (one read per group: 2.5 TB/s; measured in profiles/r04).
+#ifndef PG_PACK_UNROLL
+#define PG_PACK_UNROLL 4
+#endif
+template <int PB>
+__global__ __launch_bounds__(256) void pg_pack_kernel(PgSoaIn a, PgInRec *in, uint32_t lo, uint32_t cnt)
+{
+    constexpr u32 LPR = 8u * PB;                       // lanes per read
+    constexpr u32 RPW = 64u / LPR;                     // reads per wave and step (PB = 3: two reads on 48 lanes)
+    constexpr int U = PG_PACK_UNROLL;
+    const u32 lane = threadIdx.x & 63u;
+    const u32 slot = lane / LPR, L = lane % LPR;
+    const u32 k0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * (RPW * U) + slot;
+    const u32 D = L >> 2, pl = L & 3u, idx0 = 8u * L;
+    bool active[U];
+    u32 i[U], len[U], d0[U], d1[U], d2[U];
+    u64 so[U];
+    // ---- round trip 1: the reads' offsets (every lane of a read asks for the same two words)
 #pragma unroll
-            for (int k = 1; k < 8; k++) mine = lane == (uint32_t)k ? v[k] : mine;
-            a.planes[((size_t)i * 8u + lane) * pb + b] = mine;     // [orientation][plane][block]
+    for (int u = 0; u < U; u++) {
+        const u32 k = k0 + (u32)u * RPW;
+        active[u] = slot < RPW && k < cnt;
+        i[u] = lo + (active[u] ? k : 0u);
+        so[u] = 0;
+        len[u] = 0;
+        if (active[u]) {
+            so[u] = a.seq_off[i[u]];
+            len[u] = (u32)(a.seq_off[i[u] + 1] - so[u]);
+        }
+    }
+    // ---- round trip 2: the lane's eight bases of each read (three aligned dwords around them); the record's fields
+    // ride along in lane 0
+    int32_t r_pos[U], r_chr[U];
+    int16_t r_isz[U];
+    uint8_t r_strand[U];
+    uint16_t r_thr[U];
+    u32 r_mm[U], r_bd0[U], r_bd1[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        d0[u] = d1[u] = d2[u] = 0u;
+        if (idx0 < len[u]) {
+            const u32 *p = (const u32 *)a.seq + ((so[u] + idx0) >> 2);   // (the buffer is padded: up to 11 bytes past the read are touched)
+            d0[u] = p[0];
+            d1[u] = p[1];
+            d2[u] = p[2];
+        }
+        r_pos[u] = r_chr[u] = 0;
+        r_isz[u] = 0;
+        r_strand[u] = 0;
+        r_thr[u] = 0;
+        r_mm[u] = r_bd0[u] = r_bd1[u] = 0u;
+        if (active[u] && L == 0u) {
+            const u32 ii = i[u], lc = len[u] < 512u ? len[u] : 511u;
+            r_pos[u] = a.pos[ii];
+            r_chr[u] = a.chr[ii];
+            r_isz[u] = a.isz[ii];
+            r_strand[u] = a.strand[ii];
+            r_thr[u] = a.thr[lc];
+            r_mm[u] = a.mm[lc];
+            if (a.bd_off) {
+                r_bd0[u] = (u32)a.bd_off[ii];
+                r_bd1[u] = (u32)a.bd_off[ii + 1];
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const u32 sh = (u32)(so[u] + idx0) & 3u;
+        const u32 w0 = __builtin_amdgcn_alignbyte(d1[u], d0[u], sh), w1 = __builtin_amdgcn_alignbyte(d2[u], d1[u], sh);
+        const u32 ln = len[u];
+        const u32 nv = ln > idx0 ? (ln - idx0 < 8u ? ln - idx0 : 8u) : 0u;
+        const u32 vm0 = nv >= 4u ? 0x80808080u : (0x80808080u & ((1u << (8u * nv)) - 1u));
+        const u32 vm1 = nv >= 8u ? 0x80808080u : (nv > 4u ? (0x80808080u & ((1u << (8u * (nv - 4u))) - 1u)) : 0u);
+        u32 P;
+        {
+            const u32 a0 = swar_eq(w0, 0x41414141u), c0 = swar_eq(w0, 0x43434343u), g0 = swar_eq(w0, 0x47474747u),
+                      t0 = swar_eq(w0, 0x54545454u), n0 = swar_eq(w0, 0x4e4e4e4eu);
+            const u32 a1 = swar_eq(w1, 0x41414141u), c1 = swar_eq(w1, 0x43434343u), g1 = swar_eq(w1, 0x47474747u),
+                      t1 = swar_eq(w1, 0x54545454u), n1 = swar_eq(w1, 0x4e4e4e4eu);
+            const u32 lo8 = swar_bits((c0 | t0) & vm0) | (swar_bits((c1 | t1) & vm1) << 4);
+            const u32 hi8 = swar_bits((g0 | t0) & vm0) | (swar_bits((g1 | t1) & vm1) << 4);
+            const u32 nn8 = swar_bits(n0 & vm0) | (swar_bits(n1 & vm1) << 4);
+            const u32 oo8 = swar_bits(vm0 & ~(a0 | c0 | g0 | t0 | n0)) | (swar_bits(vm1 & ~(a1 | c1 | g1 | t1 | n1)) << 4);
+            P = lo8 | (hi8 << 8) | (nn8 << 16) | (oo8 << 24);     // byte j = plane j of bases [8 L, 8 L + 8)
+        }
+        // ---- 4 x 4 byte transpose in the quad: lane (D = L >> 2, p = L & 3) <- dword D of plane p
+        const u32 t = (u32)__shfl_xor((int)P, 2);
+        const u32 y = (L & 2u) ? ((t >> 16) | (P & 0xffff0000u)) : ((P & 0xffffu) | (t << 16));
+        const u32 x = (u32)__shfl_xor((int)y, 1);
+        const u32 Fd = (L & 1u) ? (((x >> 8) & 0x00ff00ffu) | (y & 0xff00ff00u)) : ((y & 0x00ff00ffu) | ((x & 0x00ff00ffu) << 8));
+        // ---- the mirrored orientation: dword D = bits [q, q + 32) of the forward plane, reversed; q = len - 32 - 32 D
+        const int q = (int)ln - 32 - 32 * (int)D;
+        const int dF = q >> 5;                                        // (arithmetic: floor)
+        const u32 sb = (u32)q & 31u;
+        const int j0 = dF < 0 ? 0 : (dF >= 2 * PB ? 2 * PB - 1 : dF), j1 = dF + 1 < 0 ? 0 : (dF + 1 >= 2 * PB ? 2 * PB - 1 : dF + 1);
+        u32 fl = (u32)__shfl((int)Fd, (int)((slot * LPR + 4u * (u32)j0 + pl) & 63u));
+        u32 fh = (u32)__shfl((int)Fd, (int)((slot * LPR + 4u * (u32)j1 + pl) & 63u));
+        if (dF < 0 || dF >= 2 * PB) fl = 0u;
+        if (dF + 1 < 0 || dF + 1 >= 2 * PB) fh = 0u;
+        const u32 Rd = __brev(__builtin_amdgcn_alignbit(fh, fl, sb));
+        if (active[u]) {
+            u32 *dst = (u32 *)a.planes + (size_t)i[u] * (16u * PB);
+            dst[2u * PB * pl + D] = Fd;
+            dst[2u * PB * (4u + pl) + D] = Rd;
+            if (L == 0u) {
+                PgInRec r;
+                r.seq_off = so[u];
+                r.apos = r_pos[u] + (int32_t)a.spacer;
+                r.chr = r_chr[u];
+                r.len = (uint16_t)ln;
+                r.isz = r_isz[u];
+                r.thr = r_thr[u];
+                r.strand = r_strand[u];
+                r.M = (uint8_t)r_mm[u];
+                r.bd_off = r_bd0[u];
+                r.bd_cnt = r_bd1[u] - r_bd0[u];
+                in[i[u]] = r;
+            }
         }
     }
 }
@@ -2056,12 +2141,24 @@ __global__ void pg_unpack_kernel(const PgOutRec *out, PgSoaOut a, uint32_t n)
     if (a.cand) a.cand[i] = r.reserved;
 }
 
+template <int PB>
+static void launch_pack(const PgSoaIn *soa, PgInRec *in, uint32_t lo, uint32_t cnt, hipStream_t st)
+{
+    constexpr uint32_t per_wg = 4u * (64u / (8u * PB)) * PG_PACK_UNROLL;    // reads per 256-thread workgroup
+    pg_pack_kernel<PB><<<(cnt + per_wg - 1u) / per_wg, 256, 0, st>>>(*soa, in, lo, cnt);
+}
 extern "C" int pg_pack_reads(const PgSoaIn *soa, PgInRec *in, uint32_t lo, uint32_t cnt, void *stream)
 {
     if (cnt) {
-        pg_pack_reads_kernel<<<(cnt + 255u) / 256u, 256, 0, (hipStream_t)stream>>>(*soa, in, lo, cnt);
-        const uint64_t per_wg = 4u * PG_PLANES_PER_WAVE, items = (uint64_t)cnt * soa->plane_blocks;
-        pg_pack_planes_kernel<<<(uint32_t)((items + per_wg - 1u) / per_wg), 256, 0, (hipStream_t)stream>>>(*soa, lo, cnt);
+        hipStream_t st = (hipStream_t)stream;
+        switch (soa->plane_blocks) {
+        case 1: launch_pack<1>(soa, in, lo, cnt, st); break;
+        case 2: launch_pack<2>(soa, in, lo, cnt, st); break;
+        case 3: launch_pack<3>(soa, in, lo, cnt, st); break;
+        case 4: launch_pack<4>(soa, in, lo, cnt, st); break;
+        case 8: launch_pack<8>(soa, in, lo, cnt, st); break;
+        default: return (int)hipErrorInvalidValue;
+        }
     }
     return (int)hipGetLastError();
 }
