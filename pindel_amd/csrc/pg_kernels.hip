@@ -1986,125 +1986,130 @@ __device__ __forceinline__ u32 swar_bits(u32 m)               // the four 0x80 f
 {
     return (((m >> 7) * 0x01020408u) >> 24) & 0xfu;
 }
-// PG_PACK_UNROLL reads per 8 PB-lane group, their loads issued together: the kernel is a chain of two dependent HBM round
-// trips (offsets -> bases) and moves only ~280 bytes per read, so what bounds it is bytes in flight per CU, not
-// instructions (one read per group: 2.5 TB/s; measured in profiles/r04).
+// A wave takes 64 CONSECUTIVE reads at a time.  What bounds this kernel is neither ALU (-8 % with the classification removed)
+// nor bytes in flight per wave (unrolling does nothing) nor the number of memory instructions, but the number of memory
+// REQUESTS (cache lines touched) per byte moved -- measured on 10 M x 100 bp, profiles/r04/pack_kernel.txt: four reads
+// per wave with every lane fetching its own read's fields touched ~20 lines for 476 useful bytes and stopped at 2.6 TB/s.
+//   phase A  lane j = read j of the 64: its two offsets (one 16-byte load), position / chromosome / insert size / strand
+//            (four full-width coalesced loads), the two table entries of its length -> the whole 32-byte record from one
+//            lane (the wave writes 2 KB contiguous)
+//   phase B  RPW reads per step (8 PB lanes each, lane L = bases [8 L, 8 L + 8)): offset and length of the step's reads come
+//            from phase A's lanes by ds_bpermute, the bases as one 12-byte load per lane (the wave walks the concatenated
+//            sequence buffer), PG_PACK_UNROLL steps' loads in flight together.
 #ifndef PG_PACK_UNROLL
-#define PG_PACK_UNROLL 4
+#define PG_PACK_UNROLL 2
 #endif
+#ifndef PG_PACK_GRID
+#define PG_PACK_GRID 65536u
+#endif
+static_assert(sizeof(PgInRec) == 32 && offsetof(PgInRec, apos) == 8 && offsetof(PgInRec, chr) == 12 && offsetof(PgInRec, len) == 16 &&
+              offsetof(PgInRec, isz) == 18 && offsetof(PgInRec, thr) == 20 && offsetof(PgInRec, strand) == 22 && offsetof(PgInRec, M) == 23 &&
+              offsetof(PgInRec, bd_cnt) == 24 && offsetof(PgInRec, bd_off) == 28, "pg_pack_kernel writes PgInRec as two uint4");
+struct PgDw3 { u32 x, y, z; };
 template <int PB>
 __global__ __launch_bounds__(256) void pg_pack_kernel(PgSoaIn a, PgInRec *in, uint32_t lo, uint32_t cnt)
 {
-    constexpr u32 LPR = 8u * PB;                       // lanes per read
-    constexpr u32 RPW = 64u / LPR;                     // reads per wave and step (PB = 3: two reads on 48 lanes)
-    constexpr int U = PG_PACK_UNROLL;
+    constexpr u32 LPR = 8u * PB;                       // lanes per read in phase B
+    constexpr u32 RPW = 64u / LPR;                     // reads per step (PB = 3: two reads on 48 lanes)
+    constexpr u32 STEPS = (64u + RPW - 1u) / RPW;
+    constexpr u32 U = PG_PACK_UNROLL < STEPS ? PG_PACK_UNROLL : STEPS;
+    static_assert(STEPS % U == 0, "unroll must divide the steps");
     const u32 lane = threadIdx.x & 63u;
     const u32 slot = lane / LPR, L = lane % LPR;
-    const u32 k0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * (RPW * U) + slot;
     const u32 D = L >> 2, pl = L & 3u, idx0 = 8u * L;
-    bool active[U];
-    u32 i[U], len[U], d0[U], d1[U], d2[U];
-    u64 so[U];
-    // ---- round trip 1: the reads' offsets (every lane of a read asks for the same two words)
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-        const u32 k = k0 + (u32)u * RPW;
-        active[u] = slot < RPW && k < cnt;
-        i[u] = lo + (active[u] ? k : 0u);
-        so[u] = 0;
-        len[u] = 0;
-        if (active[u]) {
-            so[u] = a.seq_off[i[u]];
-            len[u] = (u32)(a.seq_off[i[u] + 1] - so[u]);
-        }
-    }
-    // ---- round trip 2: the lane's eight bases of each read (three aligned dwords around them); the record's fields
-    // ride along in lane 0
-    int32_t r_pos[U], r_chr[U];
-    int16_t r_isz[U];
-    uint8_t r_strand[U];
-    uint16_t r_thr[U];
-    u32 r_mm[U], r_bd0[U], r_bd1[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-        d0[u] = d1[u] = d2[u] = 0u;
-        if (idx0 < len[u]) {
-            const u32 *p = (const u32 *)a.seq + ((so[u] + idx0) >> 2);   // (the buffer is padded: up to 11 bytes past the read are touched)
-            d0[u] = p[0];
-            d1[u] = p[1];
-            d2[u] = p[2];
-        }
-        r_pos[u] = r_chr[u] = 0;
-        r_isz[u] = 0;
-        r_strand[u] = 0;
-        r_thr[u] = 0;
-        r_mm[u] = r_bd0[u] = r_bd1[u] = 0u;
-        if (active[u] && L == 0u) {
-            const u32 ii = i[u], lc = len[u] < 512u ? len[u] : 511u;
-            r_pos[u] = a.pos[ii];
-            r_chr[u] = a.chr[ii];
-            r_isz[u] = a.isz[ii];
-            r_strand[u] = a.strand[ii];
-            r_thr[u] = a.thr[lc];
-            r_mm[u] = a.mm[lc];
+    const u32 n_blocks = (cnt + 63u) >> 6, n_waves = gridDim.x * 4u;
+    for (u32 g = blockIdx.x * 4u + (threadIdx.x >> 6); g < n_blocks; g += n_waves) {
+        const u32 r0 = g << 6;
+        const u32 nb = cnt - r0 < 64u ? cnt - r0 : 64u;
+        // ---- phase A: lane = read
+        u32 so_lo = 0u, so_hi = 0u, len = 0u;
+        if (lane < nb) {
+            const u32 ii = lo + r0 + lane;
+            uint4 o;
+            __builtin_memcpy(&o, __builtin_assume_aligned(a.seq_off + ii, 8), 16);
+            so_lo = o.x;
+            so_hi = o.y;
+            len = o.z - o.x;                           // (a read is shorter than 2^32 bases: the low words suffice)
+            const u32 lc = len < 512u ? len : 511u;
+            uint4 r_lo, r_hi;
+            r_lo.x = so_lo;
+            r_lo.y = so_hi;
+            r_lo.z = (u32)(a.pos[ii] + (int32_t)a.spacer);
+            r_lo.w = (u32)a.chr[ii];
+            r_hi.x = (len & 0xffffu) | ((u32)(uint16_t)a.isz[ii] << 16);
+            r_hi.y = (u32)a.thr[lc] | ((u32)a.strand[ii] << 16) | ((a.mm[lc] & 0xffu) << 24);
+            r_hi.z = r_hi.w = 0u;
             if (a.bd_off) {
-                r_bd0[u] = (u32)a.bd_off[ii];
-                r_bd1[u] = (u32)a.bd_off[ii + 1];
+                uint4 w;
+                __builtin_memcpy(&w, __builtin_assume_aligned(a.bd_off + ii, 8), 16);
+                r_hi.w = w.x;
+                r_hi.z = w.z - w.x;
             }
+            uint4 *dst = (uint4 *)(in + ii);
+            dst[0] = r_lo;
+            dst[1] = r_hi;
         }
-    }
+        // ---- phase B: 8 PB lanes = one read
+        for (u32 s = 0; s < STEPS; s += U) {
+            u32 d0[U], d1[U], d2[U], ln[U], sh[U];
+            bool act[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-        const u32 sh = (u32)(so[u] + idx0) & 3u;
-        const u32 w0 = __builtin_amdgcn_alignbyte(d1[u], d0[u], sh), w1 = __builtin_amdgcn_alignbyte(d2[u], d1[u], sh);
-        const u32 ln = len[u];
-        const u32 nv = ln > idx0 ? (ln - idx0 < 8u ? ln - idx0 : 8u) : 0u;
-        const u32 vm0 = nv >= 4u ? 0x80808080u : (0x80808080u & ((1u << (8u * nv)) - 1u));
-        const u32 vm1 = nv >= 8u ? 0x80808080u : (nv > 4u ? (0x80808080u & ((1u << (8u * (nv - 4u))) - 1u)) : 0u);
-        u32 P;
-        {
-            const u32 a0 = swar_eq(w0, 0x41414141u), c0 = swar_eq(w0, 0x43434343u), g0 = swar_eq(w0, 0x47474747u),
-                      t0 = swar_eq(w0, 0x54545454u), n0 = swar_eq(w0, 0x4e4e4e4eu);
-            const u32 a1 = swar_eq(w1, 0x41414141u), c1 = swar_eq(w1, 0x43434343u), g1 = swar_eq(w1, 0x47474747u),
-                      t1 = swar_eq(w1, 0x54545454u), n1 = swar_eq(w1, 0x4e4e4e4eu);
-            const u32 lo8 = swar_bits((c0 | t0) & vm0) | (swar_bits((c1 | t1) & vm1) << 4);
-            const u32 hi8 = swar_bits((g0 | t0) & vm0) | (swar_bits((g1 | t1) & vm1) << 4);
-            const u32 nn8 = swar_bits(n0 & vm0) | (swar_bits(n1 & vm1) << 4);
-            const u32 oo8 = swar_bits(vm0 & ~(a0 | c0 | g0 | t0 | n0)) | (swar_bits(vm1 & ~(a1 | c1 | g1 | t1 | n1)) << 4);
-            P = lo8 | (hi8 << 8) | (nn8 << 16) | (oo8 << 24);     // byte j = plane j of bases [8 L, 8 L + 8)
-        }
-        // ---- 4 x 4 byte transpose in the quad: lane (D = L >> 2, p = L & 3) <- dword D of plane p
-        const u32 t = (u32)__shfl_xor((int)P, 2);
-        const u32 y = (L & 2u) ? ((t >> 16) | (P & 0xffff0000u)) : ((P & 0xffffu) | (t << 16));
-        const u32 x = (u32)__shfl_xor((int)y, 1);
-        const u32 Fd = (L & 1u) ? (((x >> 8) & 0x00ff00ffu) | (y & 0xff00ff00u)) : ((y & 0x00ff00ffu) | ((x & 0x00ff00ffu) << 8));
-        // ---- the mirrored orientation: dword D = bits [q, q + 32) of the forward plane, reversed; q = len - 32 - 32 D
-        const int q = (int)ln - 32 - 32 * (int)D;
-        const int dF = q >> 5;                                        // (arithmetic: floor)
-        const u32 sb = (u32)q & 31u;
-        const int j0 = dF < 0 ? 0 : (dF >= 2 * PB ? 2 * PB - 1 : dF), j1 = dF + 1 < 0 ? 0 : (dF + 1 >= 2 * PB ? 2 * PB - 1 : dF + 1);
-        u32 fl = (u32)__shfl((int)Fd, (int)((slot * LPR + 4u * (u32)j0 + pl) & 63u));
-        u32 fh = (u32)__shfl((int)Fd, (int)((slot * LPR + 4u * (u32)j1 + pl) & 63u));
-        if (dF < 0 || dF >= 2 * PB) fl = 0u;
-        if (dF + 1 < 0 || dF + 1 >= 2 * PB) fh = 0u;
-        const u32 Rd = __brev(__builtin_amdgcn_alignbit(fh, fl, sb));
-        if (active[u]) {
-            u32 *dst = (u32 *)a.planes + (size_t)i[u] * (16u * PB);
-            dst[2u * PB * pl + D] = Fd;
-            dst[2u * PB * (4u + pl) + D] = Rd;
-            if (L == 0u) {
-                PgInRec r;
-                r.seq_off = so[u];
-                r.apos = r_pos[u] + (int32_t)a.spacer;
-                r.chr = r_chr[u];
-                r.len = (uint16_t)ln;
-                r.isz = r_isz[u];
-                r.thr = r_thr[u];
-                r.strand = r_strand[u];
-                r.M = (uint8_t)r_mm[u];
-                r.bd_off = r_bd0[u];
-                r.bd_cnt = r_bd1[u] - r_bd0[u];
-                in[i[u]] = r;
+            for (u32 u = 0; u < U; u++) {
+                const u32 src = (s + u) * RPW + slot;
+                act[u] = slot < RPW && src < nb;
+                const u32 olo = (u32)__shfl((int)so_lo, (int)(src & 63u)), ohi = (u32)__shfl((int)so_hi, (int)(src & 63u));
+                ln[u] = (u32)__shfl((int)len, (int)(src & 63u));
+                if (!act[u]) ln[u] = 0u;
+                const u64 A = ((u64)olo | ((u64)ohi << 32)) + idx0;
+                sh[u] = (u32)A & 3u;
+                d0[u] = d1[u] = d2[u] = 0u;
+                if (idx0 < ln[u]) {
+                    // (the buffer is padded: up to 11 bytes past the read are touched; a multi-dword load only needs dword alignment)
+                    PgDw3 t;
+                    __builtin_memcpy(&t, __builtin_assume_aligned((const u32 *)a.seq + (A >> 2), 4), 12);
+                    d0[u] = t.x;
+                    d1[u] = t.y;
+                    d2[u] = t.z;
+                }
+            }
+#pragma unroll
+            for (u32 u = 0; u < U; u++) {
+                const u32 w0 = __builtin_amdgcn_alignbyte(d1[u], d0[u], sh[u]), w1 = __builtin_amdgcn_alignbyte(d2[u], d1[u], sh[u]);
+                const u32 nv = ln[u] > idx0 ? (ln[u] - idx0 < 8u ? ln[u] - idx0 : 8u) : 0u;
+                const u32 vm0 = nv >= 4u ? 0x80808080u : (0x80808080u & ((1u << (8u * nv)) - 1u));
+                const u32 vm1 = nv >= 8u ? 0x80808080u : (nv > 4u ? (0x80808080u & ((1u << (8u * (nv - 4u))) - 1u)) : 0u);
+                u32 P;
+                {
+                    const u32 a0 = swar_eq(w0, 0x41414141u), c0 = swar_eq(w0, 0x43434343u), g0 = swar_eq(w0, 0x47474747u),
+                              t0 = swar_eq(w0, 0x54545454u), n0 = swar_eq(w0, 0x4e4e4e4eu);
+                    const u32 a1 = swar_eq(w1, 0x41414141u), c1 = swar_eq(w1, 0x43434343u), g1 = swar_eq(w1, 0x47474747u),
+                              t1 = swar_eq(w1, 0x54545454u), n1 = swar_eq(w1, 0x4e4e4e4eu);
+                    const u32 lo8 = swar_bits((c0 | t0) & vm0) | (swar_bits((c1 | t1) & vm1) << 4);
+                    const u32 hi8 = swar_bits((g0 | t0) & vm0) | (swar_bits((g1 | t1) & vm1) << 4);
+                    const u32 nn8 = swar_bits(n0 & vm0) | (swar_bits(n1 & vm1) << 4);
+                    const u32 oo8 = swar_bits(vm0 & ~(a0 | c0 | g0 | t0 | n0)) | (swar_bits(vm1 & ~(a1 | c1 | g1 | t1 | n1)) << 4);
+                    P = lo8 | (hi8 << 8) | (nn8 << 16) | (oo8 << 24);     // byte j = plane j of bases [8 L, 8 L + 8)
+                }
+                // ---- 4 x 4 byte transpose in the quad: lane (D = L >> 2, p = L & 3) <- dword D of plane p
+                const u32 t = (u32)__shfl_xor((int)P, 2);
+                const u32 y = (L & 2u) ? ((t >> 16) | (P & 0xffff0000u)) : ((P & 0xffffu) | (t << 16));
+                const u32 x = (u32)__shfl_xor((int)y, 1);
+                const u32 Fd = (L & 1u) ? (((x >> 8) & 0x00ff00ffu) | (y & 0xff00ff00u)) : ((y & 0x00ff00ffu) | ((x & 0x00ff00ffu) << 8));
+                // ---- the mirrored orientation: dword D = bits [q, q + 32) of the forward plane, reversed; q = len - 32 - 32 D
+                const int q = (int)ln[u] - 32 - 32 * (int)D;
+                const int dF = q >> 5;                                        // (arithmetic: floor)
+                const u32 sb = (u32)q & 31u;
+                const int j0 = dF < 0 ? 0 : (dF >= 2 * PB ? 2 * PB - 1 : dF), j1 = dF + 1 < 0 ? 0 : (dF + 1 >= 2 * PB ? 2 * PB - 1 : dF + 1);
+                u32 fl = (u32)__shfl((int)Fd, (int)((slot * LPR + 4u * (u32)j0 + pl) & 63u));
+                u32 fh = (u32)__shfl((int)Fd, (int)((slot * LPR + 4u * (u32)j1 + pl) & 63u));
+                if (dF < 0 || dF >= 2 * PB) fl = 0u;
+                if (dF + 1 < 0 || dF + 1 >= 2 * PB) fh = 0u;
+                const u32 Rd = __brev(__builtin_amdgcn_alignbit(fh, fl, sb));
+                if (act[u]) {
+                    u32 *dst = (u32 *)a.planes + (size_t)(lo + r0 + (s + u) * RPW + slot) * (16u * PB);
+                    dst[2u * PB * pl + D] = Fd;
+                    dst[2u * PB * (4u + pl) + D] = Rd;
+                }
             }
         }
     }
@@ -2144,8 +2149,8 @@ __global__ void pg_unpack_kernel(const PgOutRec *out, PgSoaOut a, uint32_t n)
 template <int PB>
 static void launch_pack(const PgSoaIn *soa, PgInRec *in, uint32_t lo, uint32_t cnt, hipStream_t st)
 {
-    constexpr uint32_t per_wg = 4u * (64u / (8u * PB)) * PG_PACK_UNROLL;    // reads per 256-thread workgroup
-    pg_pack_kernel<PB><<<(cnt + per_wg - 1u) / per_wg, 256, 0, st>>>(*soa, in, lo, cnt);
+    const uint32_t want = (cnt + 255u) / 256u, cap = PG_PACK_GRID;       // 64 reads per wave and loop iteration, 4 waves per workgroup
+    pg_pack_kernel<PB><<<want < cap ? want : cap, 256, 0, st>>>(*soa, in, lo, cnt);
 }
 extern "C" int pg_pack_reads(const PgSoaIn *soa, PgInRec *in, uint32_t lo, uint32_t cnt, void *stream)
 {
