@@ -83,19 +83,24 @@ public:
         data_.clear();
         pos_ = 0;
         eof_ = false;
+        bad_ = false;                                     // (a reader may be reused after a failed read)
         if (!load_block()) return !bad_ && (voff & 0xffff) == 0;
         pos_ = (size_t)(voff & 0xffff);
         return pos_ <= data_.size();
     }
-    // reads exactly n bytes; false at end of file (or on a corrupt block)
-    bool read(void *dst, size_t n)
+    // reads exactly n bytes; false at end of file (or on a corrupt block).  got (nullable): the bytes delivered before the end
+    bool read(void *dst, size_t n, size_t *got = nullptr)
     {
         uint8_t *d = (uint8_t *)dst;
+        if (got) *got = 0;
         while (n) {
             if (pos_ == data_.size()) {
                 block_addr_ += block_len_;
                 block_len_ = 0;
-                if (!load_block()) return false;
+                if (!load_block()) {
+                    if (got) *got = (size_t)(d - (uint8_t *)dst);
+                    return false;
+                }
                 continue;
             }
             const size_t k = std::min(n, data_.size() - pos_);
@@ -312,7 +317,11 @@ public:
     bool next(BamRecord &r)
     {
         int32_t block_size = 0;
-        if (!z_.read(&block_size, 4)) return false;       // the end of the file, or a bad block (z_.failed())
+        size_t got = 0;
+        if (!z_.read(&block_size, 4, &got)) {             // the end of the file, or a bad block (z_.failed())
+            if (got != 0) z_.mark_failed();               // ... or a file cut inside a record's length word: not a clean end
+            return false;
+        }
         if (block_size < 32) {
             z_.mark_failed();
             return false;

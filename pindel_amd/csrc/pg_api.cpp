@@ -20,6 +20,8 @@
 #include "pindel_pg.h"
 
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 namespace {
 
 double now_ms()
@@ -93,15 +95,26 @@ template <typename T>
 struct HostBuf {
     T *p = nullptr;
     size_t n = 0, cap_bytes = 0;
+    bool view = false;                // p points into another HostBuf's block (pg_result::block): nothing to give back
     HostBuf() {}
     HostBuf(const HostBuf &) = delete;
     HostBuf &operator=(const HostBuf &) = delete;
     ~HostBuf() { release(); }
     void release()
     {
-        if (p) g_pinned.put(p, cap_bytes);
+        if (p && !view) g_pinned.put(p, cap_bytes);
         p = nullptr;
         n = cap_bytes = 0;
+        view = false;
+    }
+    // count elements at `at` inside somebody else's pinned block (room for `room` elements: resize may shrink and regrow within it)
+    void set_view(void *at, size_t count, size_t room)
+    {
+        release();
+        p = (T *)at;
+        n = count;
+        cap_bytes = room * sizeof(T);
+        view = true;
     }
     // contents are NOT initialised (they are about to be overwritten by a device-to-host copy)
     bool resize(size_t count)
@@ -130,6 +143,7 @@ struct HostBuf {
         std::swap(p, o.p);
         std::swap(n, o.n);
         std::swap(cap_bytes, o.cap_bytes);
+        std::swap(view, o.view);
     }
 };
 
@@ -231,6 +245,7 @@ struct pg_device_batch {
     pg_run *pool = nullptr;
     uint32_t pool_shard_cap = 0;       // runs per shard (PG_POOL_SHARDS shards)
     uint32_t *pool_used = nullptr;     // [PG_POOL_SHARDS * 16]
+    unsigned long long *run_tot = nullptr;   // running totals of the chunked delivery (zeroed with the outputs)
     uint64_t runs_used = 0;            // total runs of the last search
     int modes_done = 0;
 };
@@ -243,6 +258,9 @@ struct pg_result {
     HostBuf<uint32_t> close_last;
     HostBuf<uint16_t> close_max;
     HostBuf<uint32_t> csr32[2];        // staging of the device-built 32-bit offsets
+    // one-chunk results of the host path arrive in ONE device-to-host copy: this block, the arrays above are views into it
+    // (declared last: destroyed first would be wrong -- members are destroyed in reverse order, so the views go first)
+    HostBuf<uint8_t> block;
 };
 
 namespace {
@@ -387,12 +405,81 @@ void free_batch_buffers(pg_device_batch *b)
     }
     void *ptrs[] = { b->planes, b->seq, b->seq_off, b->strand, b->pos, b->isz, b->chr, b->rc_flag,
                      b->close_last, b->close_max, b->bd_off, b->bd, b->close_off, b->close_cnt,
-                     b->far_off, b->far_cnt, b->alg, b->pool, b->pool_used, b->in_rec, b->out_rec };
+                     b->far_off, b->far_cnt, b->alg, b->pool, b->pool_used, b->in_rec, b->out_rec, b->run_tot };
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
 
-// fn(lo, hi) over [0, n) in contiguous ranges on a few host threads (one for small n)
+// fn(lo, hi) over [0, n) in contiguous ranges on a few host threads (one for small n).  The threads are a process-wide
+// pool that sleeps between calls: spawning sixteen std::threads per pass cost more than the pass (0.25 ms of the 1.5 ms a
+// 4 M-read pg_search_batch spent before its first copy).  One job at a time; a second caller (another context's host
+// thread in pg_search_batch_multi) that finds the pool busy runs its ranges on threads of its own as before.
+class HostPool {
+public:
+    ~HostPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (std::thread &t : th_) t.join();
+    }
+    bool try_run(size_t n, unsigned nt, const std::function<void(size_t, size_t)> &fn)
+    {
+        std::unique_lock<std::mutex> job(job_mu_, std::try_to_lock);
+        if (!job.owns_lock()) return false;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            while (th_.size() + 1 < nt) {
+                const unsigned id = (unsigned)th_.size() + 1;
+                th_.emplace_back([this, id] { worker(id); });
+            }
+            fn_ = &fn;
+            n_ = n;
+            nt_ = nt;
+            remaining_ = nt - 1;
+            gen_++;
+        }
+        cv_.notify_all();
+        fn((size_t)0, n / nt);                                  // the caller takes the first range
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [this] { return remaining_ == 0; });
+        fn_ = nullptr;
+        return true;
+    }
+private:
+    void worker(unsigned id)
+    {
+        unsigned seen = 0;
+        for (;;) {
+            const std::function<void(size_t, size_t)> *fn;
+            size_t n;
+            unsigned nt;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || (gen_ != seen && id < nt_); });
+                if (stop_) return;
+                seen = gen_;
+                fn = fn_;
+                n = n_;
+                nt = nt_;
+            }
+            (*fn)(n * id / nt, n * (id + 1) / nt);
+            std::lock_guard<std::mutex> lk(mu_);
+            if (--remaining_ == 0) done_.notify_one();
+        }
+    }
+    std::mutex job_mu_, mu_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> th_;
+    const std::function<void(size_t, size_t)> *fn_ = nullptr;
+    size_t n_ = 0;
+    unsigned nt_ = 0, remaining_ = 0, gen_ = 0;
+    bool stop_ = false;
+};
+HostPool g_host_pool;
+
 template <class Fn>
 void host_ranges(size_t n, Fn fn)
 {
@@ -402,13 +489,16 @@ void host_ranges(size_t n, Fn fn)
         fn((size_t)0, n);
         return;
     }
+    if (g_host_pool.try_run(n, nt, std::function<void(size_t, size_t)>(fn))) return;
     std::vector<std::thread> th;
     for (unsigned t = 0; t < nt; t++) th.emplace_back(fn, n * t / nt, n * (t + 1) / nt);
     for (std::thread &x : th) x.join();
 }
 
 // max_isz (nullable): largest insert size of the batch
-int validate_and_measure(pg_ctx *ctx, const pg_read_batch *reads, uint32_t *max_len, uint32_t *levels, int32_t *max_isz = nullptr)
+// off_out (nullable, n + 1 entries): the read offsets rebased to 0, written in the same pass
+int validate_and_measure(pg_ctx *ctx, const pg_read_batch *reads, uint32_t *max_len, uint32_t *levels, int32_t *max_isz = nullptr,
+                         uint64_t *off_out = nullptr)
 {
     if (!reads || (reads->n_reads && (!reads->seq_off || !reads->anchor_strand || !reads->anchor_pos ||
                                       !reads->insert_size || !reads->chr_id)))
@@ -422,11 +512,14 @@ int validate_and_measure(pg_ctx *ctx, const pg_read_batch *reads, uint32_t *max_
     std::mutex mu;
     Part all;
     size_t first_bad = (size_t)-1;
+    const uint64_t base0 = reads->n_reads ? reads->seq_off[0] : 0;
+    if (off_out) off_out[reads->n_reads] = reads->n_reads ? reads->seq_off[reads->n_reads] - base0 : 0;
     host_ranges(reads->n_reads, [&](size_t lo, size_t hi) {
         Part p;
         size_t bad = (size_t)-1;
         for (size_t i = lo; i < hi; i++) {
             int code = 0;
+            if (off_out) off_out[i] = reads->seq_off[i] - base0;
             if (reads->seq_off[i + 1] < reads->seq_off[i]) code = 1;
             const uint64_t len = reads->seq_off[i + 1] - reads->seq_off[i];
             if (!code && len > PG_MAX_READ_LEN) code = 2;
@@ -475,7 +568,7 @@ int validate_and_measure(pg_ctx *ctx, const pg_read_batch *reads, uint32_t *max_
 
 // Runs per list the chunked delivery of search_host has room for (1.04 per read on average; a batch that needs more
 // falls back to the whole-batch download).
-static size_t deliver_cap(size_t n) { return getenv("PG_TEST_TINY_DELIVERY") ? n / 2 + 8 : 3 * n + 1024; }   // (tests: force the fallback)
+static size_t deliver_cap(size_t n) { return getenv("PG_TEST_TINY_DELIVERY") ? n / 2 + 8 : 2 * n + 4096; }   // (tests: force the fallback)
 
 // Validates the batch and allocates its device buffers.  copy = true also copies the inputs
 // (synchronously); otherwise the caller streams them in (search_host).  off = read offsets rebased to 0.
@@ -485,7 +578,9 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, PodVec<uint6
 {
     uint32_t max_len = 0, levels = 0;
     int32_t max_isz = 0;
-    int rc = validate_and_measure(ctx, reads, &max_len, &levels, &max_isz);
+    off.resize((size_t)(reads ? reads->n_reads : 0) + 1);
+    if (!off.data()) return fail(ctx, PG_E_NOMEM, "host memory for the read offsets");
+    int rc = validate_and_measure(ctx, reads, &max_len, &levels, &max_isz, off.data());
     if (rc) return rc;
     pg_device_batch *b = new pg_device_batch();
     b->n = reads->n_reads;
@@ -495,13 +590,6 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, PodVec<uint6
     const size_t n = b->n;
     const uint64_t base0 = n ? reads->seq_off[0] : 0;
     const uint64_t nseq = n ? reads->seq_off[n] - base0 : 0;
-    off.resize(n + 1);
-    if (!off.data()) {
-        delete b;
-        return fail(ctx, PG_E_NOMEM, "host memory for the read offsets");
-    }
-    if (n) host_ranges(n + 1, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) off[i] = reads->seq_off[i] - base0; });
-    else off[0] = 0;
     // every read reserves PG_RESERVE slots (one atomic per claim of reads); lists longer than their share allocate more
     b->pool_shard_cap = (uint32_t)std::min<uint64_t>(((PG_RESERVE + 2ull) * n) / PG_POOL_SHARDS + 512ull, 0x7fffffffull / PG_POOL_SHARDS);
     if (getenv("PG_TEST_TINY_POOL")) b->pool_shard_cap = 1;      // tests: force the overflow/regrow path
@@ -519,7 +607,10 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, PodVec<uint6
         { (void **)&b->close_off, n1 * 4 }, { (void **)&b->close_cnt, (n + 1) * 4 },   // + 1: the CSR scan runs over n + 1 counts
         { (void **)&b->far_off, n1 * 4 }, { (void **)&b->far_cnt, (n + 1) * 4 }, { (void **)&b->alg, n1 * 4 },
         { (void **)&b->out_rec, n1 * sizeof(PgOutRec) },
-        { (void **)&b->pool_used, (PG_POOL_SHARDS * 16 + 2 * PG_WORK_CTRS * 16 + PG_DIAG_WORDS * 2) * 4 },   // + a second set of read counters  // run-pool cursors + the launch's read counters
+        // run-pool cursors, then per set of read counters (two: launches on the two kernel streams overlap) the counters and the
+        // cycle accumulators of a -DPG_TIMING diagnostics build, which the kernel finds right behind its counters
+        { (void **)&b->pool_used, (PG_POOL_SHARDS * 16 + 2 * (PG_WORK_CTRS * 16 + PG_DIAG_WORDS * 2)) * 4 },   // + a second set of read counters  // run-pool cursors + the launch's read counters
+        { (void **)&b->run_tot, 64 },
     };
     const size_t n_items = sizeof items / sizeof items[0], first_zero = 9;
     auto drop = [&](int code) {
@@ -535,7 +626,7 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, PodVec<uint6
                 pg_scan_tmp_bytes((uint32_t)n) + 4096;
         // ... and for the chunk-by-chunk delivery of search_host: gathered runs (2 lists), 64-bit offsets (2 lists), scratch
         need += 2 * (deliver_cap(n) * sizeof(pg_run) + 512) + 2 * ((n + 1) * 8 + 512) + PG_DELIVER_CHUNK * 8 + 1024 * 8 +
-                (n / PG_DELIVER_CHUNK + 2) * 64 + 8192;
+                (n / PG_DELIVER_CHUNK + 2) * 64 + 8192 + 8 * n + 4096;      // (+ the summaries of a one-block delivery)
         if (need > ctx->arena.cap) {
             if (ctx->arena.base) (void)hipFree(ctx->arena.base);
             ctx->arena.base = nullptr;
@@ -674,7 +765,9 @@ bool small_ids(const pg_ctx *ctx, const pg_device_batch *b)
 
 // Launches the search for reads [lo, lo + cnt) of the batch on the ctx stream.
 // st / set: the stream to launch on and the set of read counters to use (launches that may overlap need their own)
-int launch_range(pg_ctx *ctx, pg_device_batch *b, int mode, uint32_t lo, uint32_t cnt, hipStream_t st = nullptr, int set = 0)
+// fresh: the set's counters are still zero from the batch's allocation (the first launch on each set)
+int launch_range(pg_ctx *ctx, pg_device_batch *b, int mode, uint32_t lo, uint32_t cnt, hipStream_t st = nullptr, int set = 0,
+                 bool fresh = false)
 {
     PgDevRef ref = dev_ref(ctx);
     PgDevParams prm = dev_params(ctx);
@@ -688,7 +781,7 @@ int launch_range(pg_ctx *ctx, pg_device_batch *b, int mode, uint32_t lo, uint32_
         d.work_ctr += PG_WORK_CTRS * 16 + PG_DIAG_WORDS * 2;
         bytes = PG_WORK_CTRS * 16 * sizeof(uint32_t);
     }
-    HIP_TRY(ctx, hipMemsetAsync(d.work_ctr, 0, bytes, st));
+    if (!fresh) HIP_TRY(ctx, hipMemsetAsync(d.work_ctr, 0, bytes, st));
     int lrc = pg_launch_search(&ref, &prm, &d, mode, b->max_len, b->levels, small_ids(ctx, b) ? 1 : 0, st);
     if (lrc != 0) return fail(ctx, PG_E_DEVICE, std::string("kernel launch: ") + hipGetErrorString((hipError_t)lrc));
     return PG_OK;
@@ -1362,9 +1455,42 @@ static int search_host(pg_ctx *ctx, const pg_read_batch *reads, int mode, pg_res
     const uint32_t n = b->n;
     r = new pg_result();
     r->n = n;
-    const size_t cap = deliver_cap(n);
-    if (!r->close_off.resize((size_t)n + 1) || !r->far_off.resize((size_t)n + 1) || !r->rc_flag.resize(n) ||
-        !r->close_last.resize(n) || !r->close_max.resize(n) || !r->close_runs.resize(n ? cap : 0) || !r->far_runs.resize(n ? cap : 0))
+    const char *chunk_env = getenv("PG_HOST_CHUNK");             // (tests: several chunks on a small batch)
+    const uint32_t chunk = chunk_env ? (uint32_t)std::min<long>(std::max(1, atoi(chunk_env)), PG_DELIVER_CHUNK) : PG_DELIVER_CHUNK;
+    // chunk boundaries: a batch of several chunks starts with two smaller ones (a quarter and a half chunk), so that the
+    // first kernel launches after 0.15 ms of input copies instead of 0.6 ms
+    std::vector<uint32_t> bounds(1, 0u);
+    if (n > chunk && !chunk_env) {
+        bounds.push_back(chunk / 4);
+        bounds.push_back(chunk / 4 + chunk / 2);
+    }
+    while (bounds.back() < n) bounds.push_back((uint32_t)std::min<uint64_t>((uint64_t)bounds.back() + chunk, n));
+    const uint32_t n_chunks = (uint32_t)bounds.size() - 1;
+    // A batch that is ONE chunk (Pindel's own 50 000-read flushes) gets its whole result in ONE device-to-host copy: offsets,
+    // summaries and both run lists are laid out in one device block and one pinned host block (pg_result::block), the
+    // result's arrays are views into it -- five copies and their ~10 us of runtime call each otherwise.
+    const bool single = n_chunks == 1 && !getenv("PG_NO_SINGLE_BLOCK");
+    const size_t cap = single ? 2 * deliver_cap(n) : deliver_cap(n);       // (single: both lists share one buffer)
+    size_t o_coff = 0, o_foff = 0, o_rc = 0, o_last = 0, o_max = 0, o_runs = 0, blk_bytes = 0;
+    if (single) {
+        auto put = [&](size_t bytes) { const size_t at = blk_bytes; blk_bytes += (bytes + 15) & ~(size_t)15; return at; };
+        o_coff = put(((size_t)n + 1) * 8);
+        o_foff = put(((size_t)n + 1) * 8);
+        o_rc = put(n);
+        o_last = put((size_t)n * 4);
+        o_max = put((size_t)n * 2);
+        o_runs = put(cap * sizeof(pg_run));
+        if (!r->block.resize(blk_bytes)) return bail(fail(ctx, PG_E_NOMEM, "pinned host memory for the result"));
+        uint8_t *h = r->block.data();
+        r->close_off.set_view(h + o_coff, (size_t)n + 1, (size_t)n + 1);
+        r->far_off.set_view(h + o_foff, (size_t)n + 1, (size_t)n + 1);
+        r->rc_flag.set_view(h + o_rc, n, n);
+        r->close_last.set_view(h + o_last, n, n);
+        r->close_max.set_view(h + o_max, n, n);
+        r->close_runs.set_view(h + o_runs, 0, cap);
+        r->far_runs.set_view(h + o_runs, 0, 0);                  // (placed behind the close runs once their number is known)
+    } else if (!r->close_off.resize((size_t)n + 1) || !r->far_off.resize((size_t)n + 1) || !r->rc_flag.resize(n) ||
+               !r->close_last.resize(n) || !r->close_max.resize(n) || !r->close_runs.resize(n ? cap : 0) || !r->far_runs.resize(n ? cap : 0))
         return bail(fail(ctx, PG_E_NOMEM, "pinned host memory for the result"));
     const double t_res = now_ms();
     double t_search = t_res;
@@ -1373,34 +1499,44 @@ static int search_host(pg_ctx *ctx, const pg_read_batch *reads, int mode, pg_res
         if (!ctx->copy_stream) TRY3(hipStreamCreate(&ctx->copy_stream));
         if (!ctx->dl_stream) TRY3(hipStreamCreate(&ctx->dl_stream));
         if (!ctx->stream2) TRY3(hipStreamCreate(&ctx->stream2));
-        static const uint32_t chunk = getenv("PG_HOST_CHUNK") ? (uint32_t)std::min<long>(std::max(1, atoi(getenv("PG_HOST_CHUNK"))), PG_DELIVER_CHUNK)
-                                                               : PG_DELIVER_CHUNK;
-        const uint32_t n_chunks = (n + chunk - 1) / chunk;
         while (ctx->events.size() < 2 * (size_t)n_chunks + 1) {
             hipEvent_t ev = nullptr;
             TRY3(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             ctx->events.push_back(ev);
         }
         // delivery buffers (arena): gathered runs, 64-bit offsets, scratch, per-chunk info; pinned mirror of the info
-        pg_run *d_runs[2];
-        unsigned long long *d_off[2], *d_tot, *d_info;
+        pg_run *d_runs[2] = { nullptr, nullptr };
+        unsigned long long *d_off[2], *d_tot = b->run_tot, *d_info;
+        uint8_t *d_block = nullptr, *d_rc = b->rc_flag;
+        uint32_t *d_last = b->close_last;
+        uint16_t *d_max = b->close_max;
         void *d_local, *d_blk;
-        if (!(d_runs[0] = (pg_run *)ctx->arena.take(cap * sizeof(pg_run))) || !(d_runs[1] = (pg_run *)ctx->arena.take(cap * sizeof(pg_run))) ||
-            !(d_off[0] = (unsigned long long *)ctx->arena.take(((size_t)n + 1) * 8)) ||
-            !(d_off[1] = (unsigned long long *)ctx->arena.take(((size_t)n + 1) * 8)) ||
-            !(d_local = ctx->arena.take((size_t)PG_DELIVER_CHUNK * 8)) || !(d_blk = ctx->arena.take(1024 * 8)) ||
-            !(d_tot = (unsigned long long *)ctx->arena.take(64)) || !(d_info = (unsigned long long *)ctx->arena.take((size_t)n_chunks * 64)))
+        if (single) {
+            if (!(d_block = (uint8_t *)ctx->arena.take(blk_bytes))) return bail(fail(ctx, PG_E_NOMEM, "device arena too small for the delivery buffers"));
+            d_off[0] = (unsigned long long *)(d_block + o_coff);
+            d_off[1] = (unsigned long long *)(d_block + o_foff);
+            d_rc = d_block + o_rc;
+            d_last = (uint32_t *)(d_block + o_last);
+            d_max = (uint16_t *)(d_block + o_max);
+            d_runs[0] = (pg_run *)(d_block + o_runs);            // d_runs[1] stays null: the far runs follow the close runs
+        } else if (!(d_runs[0] = (pg_run *)ctx->arena.take(cap * sizeof(pg_run))) || !(d_runs[1] = (pg_run *)ctx->arena.take(cap * sizeof(pg_run))) ||
+                   !(d_off[0] = (unsigned long long *)ctx->arena.take(((size_t)n + 1) * 8)) ||
+                   !(d_off[1] = (unsigned long long *)ctx->arena.take(((size_t)n + 1) * 8)))
+            return bail(fail(ctx, PG_E_NOMEM, "device arena too small for the delivery buffers"));
+        if (!(d_local = ctx->arena.take((size_t)PG_DELIVER_CHUNK * 8)) || !(d_blk = ctx->arena.take(1024 * 8)) ||
+            !(d_info = (unsigned long long *)ctx->arena.take((size_t)n_chunks * 64)))
             return bail(fail(ctx, PG_E_NOMEM, "device arena too small for the delivery buffers"));
         HostBuf<unsigned long long> info;
         if (!info.resize((size_t)n_chunks * 8)) return bail(fail(ctx, PG_E_NOMEM, "pinned host memory"));
         const uint64_t base0 = reads->seq_off[0];
-        TRY3(hipMemsetAsync(b->pool_used, 0, PG_POOL_SHARDS * 16 * sizeof(uint32_t), ctx->stream));
-        TRY3(hipMemsetAsync(d_tot, 0, 64, ctx->stream));
+        const unsigned long long pool_runs = (unsigned long long)b->pool_shard_cap * PG_POOL_SHARDS;
+        // (the run-pool cursors, both sets of read counters and the delivery's running totals are zero from alloc_batch's one
+        // memset of the output block, queued on ctx->stream)
         TRY3(hipEventRecord(ctx->ev0, ctx->stream));
-        TRY3(hipEventRecord(ctx->events[2 * n_chunks], ctx->stream));
+        if (n_chunks > 1) TRY3(hipEventRecord(ctx->events[2 * n_chunks], ctx->stream));
         hipError_t e = hipSuccess;
         for (uint32_t k = 0; k < n_chunks && e == hipSuccess && rc == PG_OK; k++) {
-            const uint32_t lo = k * chunk, hi = (uint32_t)std::min<uint64_t>((uint64_t)lo + chunk, n), cn = hi - lo;
+            const uint32_t lo = bounds[k], hi = bounds[k + 1], cn = hi - lo;
             hipStream_t cs = ctx->copy_stream;
             if (off[hi] > off[lo])
                 e = hipMemcpyAsync(b->seq + off[lo], reads->seq + base0 + off[lo], (size_t)(off[hi] - off[lo]), hipMemcpyHostToDevice, cs);
@@ -1416,12 +1552,12 @@ static int search_host(pg_ctx *ctx, const pg_read_batch *reads, int mode, pg_res
             if (e == hipSuccess && k == 1) e = hipStreamWaitEvent(ks, ctx->events[2 * n_chunks], 0);     // (the memsets above)
             if (e == hipSuccess) e = hipStreamWaitEvent(ks, ctx->events[2 * k], 0);
             if (e == hipSuccess) rc = pack_reads(ctx, b, lo, cn, ks);
-            if (e == hipSuccess && rc == PG_OK) rc = launch_range(ctx, b, mode, lo, cn, ks, (int)(k & 1u));
+            if (e == hipSuccess && rc == PG_OK) rc = launch_range(ctx, b, mode, lo, cn, ks, (int)(k & 1u), k < 2);
             if (e == hipSuccess && rc == PG_OK) {
                 if (k > 0) e = hipStreamWaitEvent(ks, ctx->events[2 * (k - 1) + 1], 0);
                 if (e == hipSuccess)
-                    e = (hipError_t)pg_deliver_chunk(b->out_rec + lo, cn, b->rc_flag + lo, b->close_last + lo, b->close_max + lo, d_local,
-                                                     d_blk, d_tot, d_info + 8 * k, b->pool, d_runs[0], d_runs[1], cap, d_off[0] + lo,
+                    e = (hipError_t)pg_deliver_chunk(b->out_rec + lo, cn, d_rc + lo, d_last + lo, d_max + lo, d_local,
+                                                     d_blk, d_tot, d_info + 8 * k, b->pool, pool_runs, d_runs[0], d_runs[1], cap, d_off[0] + lo,
                                                      d_off[1] + lo, b->pool_used, ks);
                 if (e == hipSuccess) e = hipMemcpyAsync(info.data() + 8 * k, d_info + 8 * k, 64, hipMemcpyDeviceToHost, ks);
                 if (e == hipSuccess) e = hipEventRecord(ctx->events[2 * k + 1], ks);
@@ -1434,15 +1570,23 @@ static int search_host(pg_ctx *ctx, const pg_read_batch *reads, int mode, pg_res
         // as the chunks get delivered: their slices to the host
         unsigned long long tot[2] = { 0, 0 };
         for (uint32_t k = 0; k < n_chunks && e == hipSuccess && rc == PG_OK && !whole_batch; k++) {
-            const uint32_t lo = k * chunk, hi = (uint32_t)std::min<uint64_t>((uint64_t)lo + chunk, n), cn = hi - lo;
+            const uint32_t lo = bounds[k], hi = bounds[k + 1], cn = hi - lo;
             e = hipEventSynchronize(ctx->events[2 * k + 1]);
             if (e != hipSuccess) break;
             const unsigned long long *in = info.data() + 8 * k;
-            if (in[0] + in[2] > cap || in[1] + in[3] > cap || in[5] || in[4] > b->pool_shard_cap) {
+            if ((single ? in[2] + in[3] > cap : (in[0] + in[2] > cap || in[1] + in[3] > cap)) || in[5] || in[4] > b->pool_shard_cap) {
                 whole_batch = true;
                 break;
             }
             hipStream_t ds = ctx->dl_stream;
+            if (single) {
+                // offsets, summaries, close runs, far runs: one copy
+                e = hipMemcpyAsync(r->block.data(), d_block, o_runs + (size_t)(in[2] + in[3]) * sizeof(pg_run), hipMemcpyDeviceToHost, ds);
+                r->far_runs.set_view(r->block.data() + o_runs + (size_t)in[2] * sizeof(pg_run), (size_t)in[3], (size_t)in[3]);
+                tot[0] = in[2];
+                tot[1] = in[3];
+                break;
+            }
             if (in[2]) e = hipMemcpyAsync(r->close_runs.data() + in[0], d_runs[0] + in[0], (size_t)in[2] * sizeof(pg_run), hipMemcpyDeviceToHost, ds);
             if (e == hipSuccess && in[3])
                 e = hipMemcpyAsync(r->far_runs.data() + in[1], d_runs[1] + in[1], (size_t)in[3] * sizeof(pg_run), hipMemcpyDeviceToHost, ds);

@@ -158,8 +158,9 @@ int pg_unpack_results(const PgOutRec *out, const PgSoaOut *soa, uint32_t n, void
 #define PG_DELIVER_CHUNK (1u << 18)
 int pg_deliver_chunk(const PgOutRec *out, uint32_t cnt, uint8_t *rc_flag, uint32_t *close_last, uint16_t *close_max,
                      void *local, void *blk, unsigned long long *run_tot, unsigned long long *info,
-                     const pg_run *pool, pg_run *close_runs, pg_run *far_runs, unsigned long long cap,
-                     unsigned long long *close_off, unsigned long long *far_off, const uint32_t *pool_used, void *stream);
+                     const pg_run *pool, unsigned long long pool_runs, pg_run *close_runs, pg_run *far_runs /* null: behind the close runs */,
+                     unsigned long long cap, unsigned long long *close_off, unsigned long long *far_off, const uint32_t *pool_used,
+                     void *stream);
 int pg_compact_runs(const pg_run *pool, const uint32_t *off, const uint32_t *cnt, uint32_t *csr,
                     pg_run *out, uint32_t n, void *tmp, size_t tmp_bytes, int gather, void *stream);
 #ifdef __cplusplus

@@ -862,6 +862,46 @@ struct Counter {
                 : PG_CTR5, [ta] "=&s"(ta), [tb] "=&s"(tb), [tc] "=&s"(tc), [ma] "=&v"(ma), [mb] "=&v"(mb), [mc] "=&v"(mc),
                   [s0] "=&v"(s0), [s1] "=&v"(s1), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES, [ja] "s"(ja), [jb] "s"(jb), [jc] "s"(jc) : "scc");
     }
+    // --- base(s) whose shift is known already (a second window word of the same lane: see seed_filter_pair)
+    __device__ __forceinline__ void shift1(u32 lo, u32 hi, u32 ja)
+    {
+        u32 ma, k0, k1;
+        if (NS == 3)
+            asm(PG_SHIFT("ma", "ja") PG_ADD1 PG_UP3 : PG_CTR3, [ma] "=&v"(ma), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES, [ja] "s"(ja));
+        else if (NS == 4)
+            asm(PG_SHIFT("ma", "ja") PG_ADD1 PG_UP4 : PG_CTR4, [ma] "=&v"(ma), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES, [ja] "s"(ja));
+        else
+            asm(PG_SHIFT("ma", "ja") PG_ADD1 PG_UP5 : PG_CTR5, [ma] "=&v"(ma), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES, [ja] "s"(ja));
+    }
+    __device__ __forceinline__ void shift2(u32 lo, u32 hi, u32 ja, u32 jb)
+    {
+        u32 ma, mb, s0, k0, k1;
+        if (NS == 3)
+            asm(PG_SHIFT("ma", "ja") PG_SHIFT("mb", "jb") PG_ADD2 PG_UP3
+                : PG_CTR3, [ma] "=&v"(ma), [mb] "=&v"(mb), [s0] "=&v"(s0), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES, [ja] "s"(ja), [jb] "s"(jb));
+        else if (NS == 4)
+            asm(PG_SHIFT("ma", "ja") PG_SHIFT("mb", "jb") PG_ADD2 PG_UP4
+                : PG_CTR4, [ma] "=&v"(ma), [mb] "=&v"(mb), [s0] "=&v"(s0), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES, [ja] "s"(ja), [jb] "s"(jb));
+        else
+            asm(PG_SHIFT("ma", "ja") PG_SHIFT("mb", "jb") PG_ADD2 PG_UP5
+                : PG_CTR5, [ma] "=&v"(ma), [mb] "=&v"(mb), [s0] "=&v"(s0), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES, [ja] "s"(ja), [jb] "s"(jb));
+    }
+    __device__ __forceinline__ void shift3(u32 lo, u32 hi, u32 ja, u32 jb, u32 jc)
+    {
+        u32 ma, mb, mc, s0, s1, k0, k1;
+        if (NS == 3)
+            asm(PG_SHIFT("ma", "ja") PG_SHIFT("mb", "jb") PG_SHIFT("mc", "jc") PG_ADD3 PG_UP3
+                : PG_CTR3, [ma] "=&v"(ma), [mb] "=&v"(mb), [mc] "=&v"(mc), [s0] "=&v"(s0), [s1] "=&v"(s1), [k0] "=&v"(k0), [k1] "=&v"(k1)
+                : PG_PLANES, [ja] "s"(ja), [jb] "s"(jb), [jc] "s"(jc));
+        else if (NS == 4)
+            asm(PG_SHIFT("ma", "ja") PG_SHIFT("mb", "jb") PG_SHIFT("mc", "jc") PG_ADD3 PG_UP4
+                : PG_CTR4, [ma] "=&v"(ma), [mb] "=&v"(mb), [mc] "=&v"(mc), [s0] "=&v"(s0), [s1] "=&v"(s1), [k0] "=&v"(k0), [k1] "=&v"(k1)
+                : PG_PLANES, [ja] "s"(ja), [jb] "s"(jb), [jc] "s"(jc));
+        else
+            asm(PG_SHIFT("ma", "ja") PG_SHIFT("mb", "jb") PG_SHIFT("mc", "jc") PG_ADD3 PG_UP5
+                : PG_CTR5, [ma] "=&v"(ma), [mb] "=&v"(mb), [mc] "=&v"(mc), [s0] "=&v"(s0), [s1] "=&v"(s1), [k0] "=&v"(k0), [k1] "=&v"(k1)
+                : PG_PLANES, [ja] "s"(ja), [jb] "s"(jb), [jc] "s"(jc));
+    }
 };
 
 // Every base of the (wave-uniform) set pm goes into the counter(s).  Kind F: the base at bit j reads the pair
@@ -961,7 +1001,7 @@ __device__ __forceinline__ void seed_filter_run(const Search &S, const Query<NB>
     if (DUAL) mB = seed2 & (snap2 | fin2);
 }
 
-template <int NB, bool DUAL>
+template <int NB, int NS, bool DUAL>
 __device__ __forceinline__ void seed_filter(const Search &S, const Query<NB> &Q, bool kindB, bool wide, int lane,
                                             u32 &mF, u32 &mB)
 {
@@ -1000,10 +1040,113 @@ __device__ __forceinline__ void seed_filter(const Search &S, const Query<NB> &Q,
     // (levels only grow with L); later lengths are covered by the "alive after J bases" test
     if (cap0 > S.cap_state) cap0 = S.cap_state;
     // counts up to 7 decide everything when T <= 8 (cap0 <= T - 1 <= 7): three slices + overflow; four up to 16 levels,
-    // five up to 32 (-e 0.05 on 300-base reads)
-    if (T <= 8) seed_filter_run<NB, 3, DUAL>(S, Q, kindB, lane, J, jb, cap0, mF, mB);
-    else if (T <= 16) seed_filter_run<NB, 4, DUAL>(S, Q, kindB, lane, J, jb, cap0, mF, mB);
-    else seed_filter_run<NB, 5, DUAL>(S, Q, kindB, lane, J, jb, cap0, mF, mB);
+    // five up to 32 (-e 0.05 on 300-base reads).  NS is a parameter of the launch (the largest T of the batch, `levels`):
+    // with all three counter widths behind a run-time switch at every call site the headline kernel was 246 KB of code
+    // with 219 SGPR spills and scratch; one width: 100 KB, 200, none.
+    seed_filter_run<NB, NS, DUAL>(S, Q, kindB, lane, J, jb, cap0, mF, mB);
+}
+
+// WIDE FAR-END WINDOWS: two window words per lane (-DPG_PAIR_FILTER; an experiment that is NOT in the shipped build: results
+// identical, -x 5 1.5 % faster, but its four counters cost the fused kernel 17 VGPR spills and scratch, and the default
+// -x 2 path 0.8 % -- profiles/r04/kernel_experiments.txt).  The chunks of a wide window are taken two per LDS fill; lane l filters
+// words 2 l and 2 l + 1 -- 64 positions of each kind -- in ONE walk over the read's bases: the scalar bookkeeping (which base
+// comes next for this symbol, its shift, the mirrored shift: ~110 scalar instructions per run, as many as the vector work
+// of one counter) is paid once for the four counters instead of once per chunk.
+template <int NS>
+__device__ __forceinline__ void add_bases_pair(bool group, u32 pm, Counter<NS> &Fa, u32 fa_lo, u32 fa_hi, Counter<NS> &Ba, u32 ba_lo, u32 ba_hi,
+                                               Counter<NS> &Fb, u32 fb_lo, u32 fb_hi, Counter<NS> &Bb, u32 bb_lo, u32 bb_hi)
+{
+    u32 ja, jb, jc;
+    if (group) {
+        int n = __popc(pm);
+        while (n >= 3) {
+            Fa.take3(pm, fa_lo, fa_hi, ja, jb, jc);
+            Fb.shift3(fb_lo, fb_hi, ja, jb, jc);
+            const u32 ta = 32u - ja, tb = 32u - jb, tc = 32u - jc;
+            Ba.shift3(ba_lo, ba_hi, ta, tb, tc);
+            Bb.shift3(bb_lo, bb_hi, ta, tb, tc);
+            n -= 3;
+        }
+        if (n == 2) {
+            Fa.take2(pm, fa_lo, fa_hi, ja, jb);
+            Fb.shift2(fb_lo, fb_hi, ja, jb);
+            const u32 ta = 32u - ja, tb = 32u - jb;
+            Ba.shift2(ba_lo, ba_hi, ta, tb);
+            Bb.shift2(bb_lo, bb_hi, ta, tb);
+        }
+    }
+    while (pm != 0u) {
+        Fa.take1(pm, fa_lo, fa_hi, ja);
+        Fb.shift1(fb_lo, fb_hi, ja);
+        const u32 ta = 32u - ja;
+        Ba.shift1(ba_lo, ba_hi, ta);
+        Bb.shift1(bb_lo, bb_hi, ta);
+    }
+}
+
+// one-hot plane X (0..3 = A C G T, 4 = not N) of a window word given as code planes
+__device__ __forceinline__ u32 onehot(const uint4 &p, int X)
+{
+    switch (X) {
+    case 0: return ~(p.x | p.y | p.z);
+    case 1: return p.x & ~(p.y | p.z);
+    case 2: return p.y & ~(p.x | p.z);
+    case 3: return p.x & p.y & ~p.z;
+    default: return ~p.z;
+    }
+}
+
+// both kinds of the window words 2 `lane` and 2 `lane` + 1 of the LDS window (a chunk pair = 128 words): as two calls of
+// seed_filter<NB, NS, true>(.., wide = true, word, ..), bit for bit.  Adjacent words, not words 64 apart: the four counters
+// then read four window words (previous, own two, next) instead of six, which is what keeps them in registers.
+template <int NB, int NS>
+__device__ __forceinline__ void seed_filter_pair(const Search &S, const Query<NB> &Q, int lane, u32 &mFa, u32 &mBa, u32 &mFb, u32 &mBb)
+{
+    const int T = S.T;
+    PG_DG(const_cast<Search &>(S), 8);
+    PG_DG(const_cast<Search &>(S), 8);
+    const int J = seed_depth(S.len, T, true);
+    const int jb = S.bps < J ? S.bps : J;
+    int cap0 = S.mm_j[1] + S.add_mm;
+    if (cap0 > T - 1) cap0 = T - 1;
+    if (cap0 > S.cap_state) cap0 = S.cap_state;
+    u32 lo = (u32)uni((int)(u32)q_lo<NB>(Q, 0)), hi = (u32)uni((int)(u32)q_hi<NB>(Q, 0));
+    const u32 nn = (u32)uni((int)(u32)q_nn<NB>(Q, 0)), oo = (u32)uni((int)(u32)q_oo<NB>(Q, 0));
+    if (Q.cF) { lo = ~lo; hi = ~hi; }
+    const u32 acgt = ~(nn | oo);
+    const u32 jmask = bits32(1, J), g0mask = bits32(1, jb);
+    const u32 sym[5] = { ~lo & ~hi & acgt, lo & ~hi & acgt, ~lo & hi & acgt, lo & hi & acgt, nn };
+    const int a = 2 * NB + 2 * lane;
+    const uint4 wm = S.win[a - 1], w0 = S.win[a], w1 = S.win[a + 1], w2 = S.win[a + 2];      // code planes
+    const int o_pre = __popc(oo & g0mask), o_all = __popc(oo & jmask);
+    Counter<NS> Fa, Ba, Fb, Bb;
+    Fa.reset();
+    Ba.reset();
+    Fb.reset();
+    Bb.reset();
+    u32 snFa = 0u, snBa = 0u, snFb = 0u, snBb = 0u;
+#pragma unroll
+    for (int it = 0; it < 10; it++) {
+        const int X = it >= 5 ? it - 5 : it;
+        const int X2 = X < 4 ? 3 - X : X;                              // the complementary symbol (kind B)
+        if (it == 5) {
+            Fa.template le<true>(Ba, cap0 - o_pre, snFa, snBa);
+            Fb.template le<true>(Bb, cap0 - o_pre, snFb, snBb);
+        }
+        const u32 pm = sym[X] & (it >= 5 ? (jmask & ~g0mask) : g0mask);
+        if (pm == 0u) continue;                                        // uniform
+        const u32 x1 = onehot(w1, X), y0 = onehot(w0, X2);
+        add_bases_pair<NS>(X < 4, pm, Fa, onehot(w0, X), x1, Ba, onehot(wm, X2), y0, Fb, x1, onehot(w2, X), Bb, y0, onehot(w1, X2));
+    }
+    u32 fFa, fBa, fFb, fBb;
+    Fa.template le<true>(Ba, T - 1 - o_all, fFa, fBa);
+    Fb.template le<true>(Bb, T - 1 - o_all, fFb, fBb);
+    // the seed: the position's own base equals the first read base / its complement (kind B)
+    const u32 l0 = (lo & 1u) ? ~0u : 0u, h0 = (hi & 1u) ? ~0u : 0u;
+    mFa = ~((w0.x ^ l0) | (w0.y ^ h0) | w0.z) & (snFa | fFa);
+    mBa = ~((w0.x ^ ~l0) | (w0.y ^ ~h0) | w0.z) & (snBa | fBa);
+    mFb = ~((w1.x ^ l0) | (w1.y ^ h0) | w1.z) & (snFb | fFb);
+    mBb = ~((w1.x ^ ~l0) | (w1.y ^ ~h0) | w1.z) & (snBb | fBb);
 }
 
 // Scan the positions of [s, e) outside [xs, xe) (wo = word index of AbsLoc 0 of the chromosome).
@@ -1012,7 +1155,7 @@ __device__ __forceinline__ void seed_filter(const Search &S, const Query<NB> &Q,
 // word per candidate kind (seed_filter); the survivors get queue slots from a wave prefix sum of the
 // per-lane popcounts and go through fold_candidates 64 at a time.  cache*: filter masks of chunk 0 of
 // the far-end window, computed once and reused by the nested ranges.
-template <int NB, typename Id, bool MIXED>
+template <int NB, int NS, typename Id, bool MIXED>
 __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
                                           const Query<NB> &Q, Acc<NB, Id> &A, long long wo, int g0, int s, int e,
                                           int e_max, int xs, int xe, int origin, u32 region, int lane,
@@ -1047,6 +1190,7 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
             // the rest after the last half
             int h = 0, end = 0, slot = 0;
             u32 mF = 0u, mB = 0u, pos0 = 0u;
+            u32 pF1 = 0u, pB1 = 0u;                           // the second half's masks until the first half's survivors are queued
             for (;;) {
                 while (mF != 0u && slot < WAVE) {
                     const int bit = __ffs((int)mF) - 1;
@@ -1063,11 +1207,21 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
                 int n;
                 if (end >= WAVE) n = WAVE;
                 else if (h < nh) {                            // every survivor so far is queued: the next half
+#ifdef PG_PAIR_FILTER
+                    const int word = nh == 2 ? 2 * lane + h : lane;   // (a pair: the lane's two words are adjacent)
+#else
                     const int word = 64 * h + lane;
-                    seed_filter<NB, true>(S, Q, false, true, word, mF, mB);
+#endif
+#ifdef PG_PAIR_FILTER
+                    if (nh == 2) {                            // both halves in one walk over the read's bases (seed_filter_pair)
+                        if (h == 0) seed_filter_pair<NB, NS>(S, Q, lane, mF, mB, pF1, pB1);
+                        else { mF = pF1; mB = pB1; }
+                    } else
+#endif
+                    seed_filter<NB, NS, true>(S, Q, false, true, word, mF, mB);
 #if defined(PG_DUP) && PG_DUP == 3
                     u32 dF, dB;
-                    seed_filter<NB, true>(S, Q, false, true, opaque(word), dF, dB);
+                    seed_filter<NB, NS, true>(S, Q, false, true, opaque(word), dF, dB);
                     mF &= dF | (u32)opaque(0);
                     mB &= dB | (u32)opaque(0);
 #endif
@@ -1120,15 +1274,15 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
         } else {
             if (MIXED) {
                 // far end: kind B reads the complement of what kind F reads (cF != cB), both kinds in one pass
-                seed_filter<NB, true>(S, Q, false, false, lane, mF, mB);
+                seed_filter<NB, NS, true>(S, Q, false, false, lane, mF, mB);
             } else {
                 u32 unused;
-                if (Q.allowF) seed_filter<NB, false>(S, Q, false, false, lane, mF, unused);
-                if (Q.allowB) seed_filter<NB, false>(S, Q, true, false, lane, mB, unused);
+                if (Q.allowF) seed_filter<NB, NS, false>(S, Q, false, false, lane, mF, unused);
+                if (Q.allowB) seed_filter<NB, NS, false>(S, Q, true, false, lane, mB, unused);
 #if defined(PG_DUP) && PG_DUP == 3
                 u32 d = 0u;
-                if (Q.allowF) { seed_filter<NB, false>(S, Q, false, false, opaque(lane), d, unused); mF &= d | (u32)opaque(0); }
-                if (Q.allowB) { seed_filter<NB, false>(S, Q, true, false, opaque(lane), d, unused); mB &= d | (u32)opaque(0); }
+                if (Q.allowF) { seed_filter<NB, NS, false>(S, Q, false, false, opaque(lane), d, unused); mF &= d | (u32)opaque(0); }
+                if (Q.allowB) { seed_filter<NB, NS, false>(S, Q, true, false, opaque(lane), d, unused); mB &= d | (u32)opaque(0); }
 #endif
             }
             if (use_cache && k == 0) { cacheF = mF; cacheB = mB; }
@@ -1174,7 +1328,7 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
     }
 }
 
-template <int NB, typename Id>
+template <int NB, int NS, typename Id>
 __device__ __forceinline__ void scan_range(const PgDevRef &ref, Search &S,
                                            const Query<NB> &Q, Acc<NB, Id> &A, long long wo, int g0, int s, int e,
                                            int e_max, int xs, int xe, int origin, u32 region, int lane,
@@ -1183,10 +1337,10 @@ __device__ __forceinline__ void scan_range(const PgDevRef &ref, Search &S,
     // window coordinates come out of LDS / per-read loads: tell the compiler they are wave-uniform
     g0 = uni(g0); s = uni(s); e = uni(e); e_max = uni(e_max); xs = uni(xs); xe = uni(xe); origin = uni(origin);
     if (Q.allowF && Q.allowB)
-        scan_impl<NB, Id, true>(ref, S, Q, A, wo, g0, s, e, e_max, xs, xe, origin, region, lane,
+        scan_impl<NB, NS, Id, true>(ref, S, Q, A, wo, g0, s, e, e_max, xs, xe, origin, region, lane,
                                 use_cache, cacheF, cacheB, cache_valid);
     else
-        scan_impl<NB, Id, false>(ref, S, Q, A, wo, g0, s, e, e_max, xs, xe, origin, region, lane,
+        scan_impl<NB, NS, Id, false>(ref, S, Q, A, wo, g0, s, e, e_max, xs, xe, origin, region, lane,
                                  use_cache, cacheF, cacheB, cache_valid);
 }
 
@@ -1415,7 +1569,7 @@ __device__ __forceinline__ bool first_base_ok(const Query<NB> &Q)
 //   close end   attempts (R0,seq) (R0,RC) (R1,RC) (R1,seq) until one yields points    pindel.cpp:2537-2575
 //   far end     BreakDancer cluster (if the read has one), then the ranges
 //               r = 1 .. MaxRangeIndex+1 until goodFarEndFound                          pindel.cpp:1006-1070
-template <int NB, typename Id, int mode>
+template <int NB, int NS, typename Id, int mode>
 __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevParams &prm, const PgDevBatch &B,
                                             Search &S, u64 *qplanes, const uint32_t rid, const int slot, const int lane,
                                             const u32 res_base, const bool res_fits)
@@ -1557,7 +1711,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                 // one call site: attempt 0 on its own grid unless the R = 1 window fits a chunk, the retries on the grid
                 // of the R = 1 window
                 const bool own_grid = att == 0 && !shared_grid;
-                scan_range<NB, Id>(ref, S, Q, A, chr_wo, own_grid ? s1 : w1s, s1, e1, own_grid ? e1 : w1e, ps, pe, w1s, 0u,
+                scan_range<NB, NS, Id>(ref, S, Q, A, chr_wo, own_grid ? s1 : w1s, s1, e1, own_grid ? e1 : w1e, ps, pe, w1s, 0u,
                                    opaque(lane), att == 1 || att == 2 || shared_grid, cr0, cr1, vr);
                 ps = s1;
                 pe = e1;
@@ -1667,7 +1821,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                     const int csz = chr_size_of(ref, S, uni(bw.chr_id));
                     const int s = st < 0 ? 0 : st, e = bw.end > csz ? csz : bw.end;
                     far_bases += (e > s ? e - s : 0) + 2 * len;
-                    scan_range<NB, Id>(ref, S, Q, A, chr_word_off_of(ref, S, uni(bw.chr_id)), s, s, e, e, 0, 0, st,
+                    scan_range<NB, NS, Id>(ref, S, Q, A, chr_word_off_of(ref, S, uni(bw.chr_id)), s, s, e, e, 0, 0, st,
                                        (u32)w, opaque(lane), false, unused0, unused1, unused_valid);
                 }
                 if (S.nsurv > 0) far_update(0, bd, 15);
@@ -1719,7 +1873,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                         if (!(chr_wo == S.win_wo && S.wbase == wb && se + 64 * NB <= S.win_hi))
                             stage_window<NB>(ref, S, chr_wo, wb, se + 64 * NB, lane);
                         u32 mF = 0u, mB = 0u;
-                        seed_filter<NB, true>(S, Q, false, false, lane, mF, mB);
+                        seed_filter<NB, NS, true>(S, Q, false, false, lane, mF, mB);
                         cacheF = mF;
                         cacheB = mB;
                         cache_valid = true;
@@ -1783,7 +1937,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                     int s, e;
                     range_of(span, s, e);
                     if (s < e) {
-                        scan_range<NB, Id>(ref, S, Q, A, chr_wo, g0, s, e, emax, ps, pe, origin, 0u, opaque(lane), true,
+                        scan_range<NB, NS, Id>(ref, S, Q, A, chr_wo, g0, s, e, emax, ps, pe, origin, 0u, opaque(lane), true,
                                            cacheF, cacheB, cache_valid);
                         if (ps < pe) {
                             ps = s < ps ? s : ps;
@@ -1829,7 +1983,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
 // Persistent 64-thread workgroups.  The reads of the launch are split into PG_N_XCD contiguous parts; a
 // workgroup (which the dispatcher places on XCD blockIdx % 8) claims PG_CLAIM reads at a time from its own
 // part's counter and moves on to the next part when that one is exhausted.
-template <int NB, typename Id, int mode>
+template <int NB, int NS, typename Id, int mode>
 __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevRef ref, PgDevParams prm,
                                                          PgDevBatch B, uint32_t max_len, uint32_t levels)
 {
@@ -1880,6 +2034,8 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
     // reads claimed per atomic: PG_CLAIM, fewer when the launch is small (a 50 000-read flush is ten reads per resident
     // wave: with claims of eight some waves would search sixteen reads and most eight)
     const uint32_t per_wg = n / gridDim.x;
+    // (claims of ONE read for the last round and a half of a launch, to shorten its tail, were measured and rejected: a claim
+    // is a dependent chain atomic -> records -> first window, 2 us that eight reads share -- 262 144 reads 0.94 -> 0.98 ms)
     const uint32_t claim = per_wg >= 24u ? PG_CLAIM : (per_wg >= 6u ? 2u : 1u);
     const uint32_t per = n / PG_N_XCD;
     uint32_t part = blockIdx.x % PG_N_XCD, tried = 0;
@@ -1910,7 +2066,7 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
             const bool res_fits = (u64)res + (u64)(claim * PG_RESERVE) <= (u64)B.pool_shard_cap;
             res += shard * B.pool_shard_cap;
             for (uint32_t i = first; i < end; i++)
-                search_read<NB, Id, mode>(ref, prm, B, S, qplanes, B.first_read + i, (int)(i - first), opaque(lane),
+                search_read<NB, NS, Id, mode>(ref, prm, B, S, qplanes, B.first_read + i, (int)(i - first), opaque(lane),
                                           res + (i - first) * PG_RESERVE, res_fits);
             PG_T(S, 10);
         }
@@ -1924,8 +2080,8 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
 }
 
 // ---------------------------------------------------------------------------------
-template <int NB, typename Id>
-static void launch(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch *batch, int mode,
+template <int NB, int NS, typename Id>
+static void launch_ns(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch *batch, int mode,
                    uint32_t max_len, uint32_t levels, hipStream_t st, unsigned lds_pad)
 {
     // a few resident workgroups per CU (the launch is persistent); more than fit simply queue up and find
@@ -1943,7 +2099,7 @@ static void launch(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch
     // close end + far end in one launch; PG_SPLIT_LAUNCH=1 runs the two seams as separate launches
     const bool fused = getenv("PG_SPLIT_LAUNCH") == nullptr;
     if (mode == PG_MODE_BOTH && fused) {
-        hipLaunchKernelGGL((pg_search_kernel<NB, Id, PG_MODE_BOTH>), grid, block, lds_pad, st,
+        hipLaunchKernelGGL((pg_search_kernel<NB, NS, Id, PG_MODE_BOTH>), grid, block, lds_pad, st,
                            *ref, *prm, *batch, max_len, levels);
         return;
     }
@@ -1951,13 +2107,27 @@ static void launch(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch
     abort();          // experiment builds (scripts/build_variant.sh -DPG_ONLY_BENCH): only the fused kernel exists
 #else
     if (mode & PG_MODE_CLOSE)
-        hipLaunchKernelGGL((pg_search_kernel<NB, Id, PG_MODE_CLOSE>), grid, block, lds_pad, st,
+        hipLaunchKernelGGL((pg_search_kernel<NB, NS, Id, PG_MODE_CLOSE>), grid, block, lds_pad, st,
                            *ref, *prm, *batch, max_len, levels);
     if (mode & PG_MODE_FAR) {
         if (mode & PG_MODE_CLOSE) (void)hipMemsetAsync(batch->work_ctr, 0, PG_N_XCD * 16u * sizeof(uint32_t), st);
-        hipLaunchKernelGGL((pg_search_kernel<NB, Id, PG_MODE_FAR>), grid, block, lds_pad, st,
+        hipLaunchKernelGGL((pg_search_kernel<NB, NS, Id, PG_MODE_FAR>), grid, block, lds_pad, st,
                            *ref, *prm, *batch, max_len, levels);
     }
+#endif
+}
+
+// the seed filter's counter width follows the batch's largest number of mismatch levels (validate_and_measure)
+template <int NB, typename Id>
+static void launch(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch *batch, int mode,
+                   uint32_t max_len, uint32_t levels, hipStream_t st, unsigned lds_pad)
+{
+    if (levels <= 8) launch_ns<NB, 3, Id>(ref, prm, batch, mode, max_len, levels, st, lds_pad);
+#ifdef PG_ONLY_BENCH
+    else abort();     // experiment builds: default parameters only
+#else
+    else if (levels <= 16) launch_ns<NB, 4, Id>(ref, prm, batch, mode, max_len, levels, st, lds_pad);
+    else launch_ns<NB, 5, Id>(ref, prm, batch, mode, max_len, levels, st, lds_pad);
 #endif
 }
 
@@ -2244,16 +2414,16 @@ extern "C" int pg_debug_occupancy(uint32_t max_len, uint32_t levels, int small_i
     hipError_t e1, e2;
 #ifdef PG_ONLY_BENCH
     (void)small_ids;
-    e1 = e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(far_blocks, pg_search_kernel<2, u32, PG_MODE_BOTH>, WAVE, 0);
+    e1 = e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(far_blocks, pg_search_kernel<2, 3, u32, PG_MODE_BOTH>, WAVE, 0);
     *close_blocks = *far_blocks;
     return (int)e1;
 #endif
     if (small_ids) {
-        e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(close_blocks, pg_search_kernel<2, u32, PG_MODE_CLOSE>, WAVE, 0);
-        e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(far_blocks, pg_search_kernel<2, u32, PG_MODE_BOTH>, WAVE, 0);
+        e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(close_blocks, pg_search_kernel<2, 3, u32, PG_MODE_CLOSE>, WAVE, 0);
+        e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(far_blocks, pg_search_kernel<2, 3, u32, PG_MODE_BOTH>, WAVE, 0);
     } else {
-        e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(close_blocks, pg_search_kernel<2, u64, PG_MODE_CLOSE>, WAVE, 0);
-        e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(far_blocks, pg_search_kernel<2, u64, PG_MODE_BOTH>, WAVE, 0);
+        e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(close_blocks, pg_search_kernel<2, 3, u64, PG_MODE_CLOSE>, WAVE, 0);
+        e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(far_blocks, pg_search_kernel<2, 3, u64, PG_MODE_BOTH>, WAVE, 0);
     }
     return (int)e1 | (int)e2;
 }
@@ -2353,9 +2523,10 @@ __global__ __launch_bounds__(1024) void pg_deliver_scan2(uint2 *blk, uint32_t nb
 }
 
 __global__ __launch_bounds__(256) void pg_deliver_gather(const PgOutRec *out, uint32_t cnt, const uint2 *local, const uint2 *blk,
-                                                         const unsigned long long *info, const pg_run *pool, pg_run *close_runs,
-                                                         pg_run *far_runs, unsigned long long cap, unsigned long long *close_off,
-                                                         unsigned long long *far_off, unsigned long long *overflow)
+                                                         const unsigned long long *info, const pg_run *pool, unsigned long long pool_runs,
+                                                         pg_run *close_runs, pg_run *far_runs, unsigned long long cap,
+                                                         unsigned long long *close_off, unsigned long long *far_off,
+                                                         unsigned long long *overflow)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= cnt) return;
@@ -2364,7 +2535,21 @@ __global__ __launch_bounds__(256) void pg_deliver_gather(const PgOutRec *out, ui
     const unsigned long long oc = info[0] + b.x + l.x, of = info[1] + b.y + l.y;
     close_off[i] = oc;
     far_off[i] = of;
-    if (oc + r.close_cnt > cap || of + r.far_cnt > cap) {
+    // far_runs == null (a batch delivered in ONE chunk): the far runs follow the close runs in the same buffer of `cap`
+    // runs, so that offsets, summaries and both lists reach the host in one copy
+    if (!far_runs) {
+        if (info[2] + info[3] > cap) {
+            *overflow = 1ull;
+            return;
+        }
+        far_runs = close_runs + info[2];
+    } else if (oc + r.close_cnt > cap || of + r.far_cnt > cap) {
+        *overflow = 1ull;
+        return;
+    }
+    // a launch whose run pool overflowed leaves offsets past the pool: the host repeats the launch with a larger pool,
+    // this copy must not run off the buffer meanwhile
+    if ((unsigned long long)r.close_off + r.close_cnt > pool_runs || (unsigned long long)r.far_off + r.far_cnt > pool_runs) {
         *overflow = 1ull;
         return;
     }
@@ -2376,15 +2561,16 @@ __global__ __launch_bounds__(256) void pg_deliver_gather(const PgOutRec *out, ui
 
 extern "C" int pg_deliver_chunk(const PgOutRec *out, uint32_t cnt, uint8_t *rc_flag, uint32_t *close_last, uint16_t *close_max,
                                 void *local, void *blk, unsigned long long *run_tot, unsigned long long *info,
-                                const pg_run *pool, pg_run *close_runs, pg_run *far_runs, unsigned long long cap,
-                                unsigned long long *close_off, unsigned long long *far_off, const uint32_t *pool_used, void *stream)
+                                const pg_run *pool, unsigned long long pool_runs, pg_run *close_runs, pg_run *far_runs,
+                                unsigned long long cap, unsigned long long *close_off, unsigned long long *far_off,
+                                const uint32_t *pool_used, void *stream)
 {
     if (!cnt || cnt > PG_DELIVER_CHUNK) return cnt ? (int)hipErrorInvalidValue : 0;
     hipStream_t st = (hipStream_t)stream;
     const uint32_t nblk = (cnt + 255u) / 256u;
     pg_deliver_scan1<<<nblk, 256, 0, st>>>(out, cnt, rc_flag, close_last, close_max, (uint2 *)local, (uint2 *)blk);
     pg_deliver_scan2<<<1, 1024, 0, st>>>((uint2 *)blk, nblk, run_tot, info, pool_used);
-    pg_deliver_gather<<<nblk, 256, 0, st>>>(out, cnt, (const uint2 *)local, (const uint2 *)blk, info, pool, close_runs, far_runs,
-                                           cap, close_off, far_off, info + 5);
+    pg_deliver_gather<<<nblk, 256, 0, st>>>(out, cnt, (const uint2 *)local, (const uint2 *)blk, info, pool, pool_runs, close_runs,
+                                           far_runs, cap, close_off, far_off, info + 5);
     return (int)hipGetLastError();
 }

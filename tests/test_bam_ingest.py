@@ -795,3 +795,18 @@ def test_damaged_bam_is_an_error_not_a_short_file(tmp_path):
     open(p2, "wb").write(data[:len(data) * 2 // 3])
     assert not try_ingest(p2, False)
     assert b"BAM read failed" in L.pgh_last_error()
+    # cut INSIDE a record's 4-byte length word, exactly at a block boundary, followed by a clean end-of-file marker: every
+    # block is intact and the file ends properly, yet the last record is missing its body -- not a clean end either
+    import struct
+    head = b"BAM\1" + struct.pack("<i", 0) + struct.pack("<i", 1) + struct.pack("<i", 5) + b"chrZ\0" + struct.pack("<i", 1_000_000)
+    body = b"".join(bw.encode_record(r) for r in recs[:40])
+    whole = head + body
+    p3 = tmp_path / "lenword.bam"
+    open(p3, "wb").write(bw._bgzf_block(whole + bw.encode_record(recs[40])[:2]) + bw._EOF)
+    assert not try_ingest(p3, False), "a file cut inside a length word was read as a short file"
+    assert b"BAM read failed" in L.pgh_last_error()
+    p4 = tmp_path / "clean.bam"
+    open(p4, "wb").write(bw._bgzf_block(whole) + bw._EOF)                 # the same records, ended properly: fine
+    h = try_ingest(p4, False)
+    assert h
+    L.pgh_bam_ingest_free(h)

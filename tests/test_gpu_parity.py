@@ -233,6 +233,27 @@ def test_delivery_overflow_falls_back_to_the_whole_batch_download(engine_factory
     compare_result(eng.close_end_batch(batch), orc, batch.n, check_far=False)
 
 
+def test_one_block_delivery_equals_chunked_delivery(engine_factory, small_ref, monkeypatch):
+    """A batch of one chunk (Pindel's own flush size) comes back in ONE device-to-host copy, the result's arrays being views
+    into one pinned block; the same batch through the copy-per-array path and through seven small chunks gives the same
+    result, and the views behave as results do (pg_far_end_batch extends a close result in place)."""
+    eng = engine_factory()
+    eng.load_reference(small_ref)
+    batch = synth.make_reads(small_ref[0][1], 6500, seed=16)
+    orc = run_oracle({}, small_ref, batch)
+    compare_result(eng.search_batch(batch), orc, batch.n)
+    close = eng.close_end_batch(batch)
+    compare_result(close, orc, batch.n, check_far=False)
+    compare_result(eng.far_end_batch(batch, close), orc, batch.n)
+    monkeypatch.setenv("PG_NO_SINGLE_BLOCK", "1")
+    compare_result(eng.search_batch(batch), orc, batch.n)
+    monkeypatch.delenv("PG_NO_SINGLE_BLOCK")
+    monkeypatch.setenv("PG_HOST_CHUNK", "1000")
+    compare_result(eng.search_batch(batch), orc, batch.n)
+    close = eng.close_end_batch(batch)
+    compare_result(eng.far_end_batch(batch, close), orc, batch.n)
+
+
 def test_wide_cells_and_split_launches(engine_factory, small_ref, monkeypatch):
     """The 64-bit candidate ids and the two-launch form (close kernel, then far kernel) on a default
     workload give the same result as the default (32-bit ids, one fused launch)."""
