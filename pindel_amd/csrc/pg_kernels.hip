@@ -52,6 +52,32 @@
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
+// KERNEL ARGUMENTS ON DEMAND.  The kernel's by-value arguments (reference planes, parameters, batch: ~45 dwords of pointers
+// and sizes) are used a handful of times per read, but as ordinary arguments they sit in scalar registers from the first
+// instruction to the last -- a third of the 102 the wave has, in a kernel whose every loop nest wants all of them: 200 SGPR
+// spills, 117 of the 480 reloads (v_readlane, a slow-rate VALU instruction) four or five loops deep.  KA(obj, member) /
+// KAP(member) fetch an argument from the kernarg segment where it is used (s_load + wait: the scalar cache holds the segment
+// after the first wave) and nothing stays live: 102 spills, 5 reloads at depth >= 4, configs[2] -4.3 %, -x 5 -7.6 %
+// (profiles/r04/kernel_experiments.txt).  PgKArgs mirrors pg_search_kernel's parameter list (natural alignment = the layout
+// of the kernarg segment).
+struct PgKArgs { PgDevRef ref; PgDevParams prm; PgDevBatch B; uint32_t max_len, levels; };
+template <typename T>
+__device__ __forceinline__ T karg_load(int off)
+{
+    const auto k = __builtin_amdgcn_kernarg_segment_ptr();
+    if (sizeof(T) == 8) {
+        unsigned long long v;
+        asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(k), "n"(off));
+        return (T)v;
+    } else {
+        unsigned int v;
+        asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(k), "n"(off));
+        return (T)v;
+    }
+}
+#define KA(obj, member) karg_load<decltype(obj.member)>((int)offsetof(PgKArgs, obj.member))
+#define KAP(member) karg_load<decltype(PgDevParams::member)>((int)offsetof(PgKArgs, prm.member))
+
 #define WAVE 64
 #ifndef PG_N_XCD
 #define PG_N_XCD 8u        // MI355X: 8 accelerator complex dies, 32 CUs and one L2 each
@@ -182,14 +208,20 @@ __device__ __forceinline__ Id make_id(u32 rel, bool isB, u32 region)
 // is 'N', is other (never matches).
 enum { QP_LO = 0, QP_HI = 1, QP_NN = 2, QP_OO = 3 };
 
-// Everything a search needs to know about the query.
+// Everything a search needs to know about the query.  (Plain bools on purpose: they are compile-time constants along each
+// path of search_read once everything is inlined; as bits of one flags word -- tried, to save scalar registers -- they turn
+// into run-time data and the fused kernel's SGPR spills went from 96 to 130.)
 template <int NB>
 struct Query {
     const u64 *qp;       // planes of the base orientation (before complement): qp[plane * NB + block]
-    bool allowF, allowB; // candidate kinds searched
-    bool cF, cB;         // complement flag per kind
-    bool antisenseF, antisenseB;  // Strand reported for a point of that kind
-    bool first_ok;       // first consumed base is one of ACGT
+    bool allowF_, allowB_; // candidate kinds searched
+    bool cF_, cB_;         // complement flag per kind
+    bool first_ok_;        // first consumed base is one of ACGT
+    __device__ __forceinline__ bool allowF() const { return allowF_; }
+    __device__ __forceinline__ bool allowB() const { return allowB_; }
+    __device__ __forceinline__ bool cF() const { return cF_; }
+    __device__ __forceinline__ bool cB() const { return cB_; }
+    __device__ __forceinline__ bool first_ok() const { return first_ok_; }
 };
 template <int NB> __device__ __forceinline__ u64 q_lo(const Query<NB> &Q, int b) { return Q.qp[QP_LO * NB + b]; }
 template <int NB> __device__ __forceinline__ u64 q_hi(const Query<NB> &Q, int b) { return Q.qp[QP_HI * NB + b]; }
@@ -250,7 +282,7 @@ struct Lds {
 };
 
 struct Search {
-    int len, T, M, add_mm, bps, min_perfect, thr;
+    int len, T, M, add_mm, bps, min_perfect, thr;     // (add_mm / min_perfect: fetched once per read)
     uint16_t *queue;
     uint4 *win;
     uint4 *bufA;
@@ -267,7 +299,7 @@ struct Search {
     long long win_wo;
     int win_lo, win_hi, wbase;
     int nsurv;           // candidates folded since the state was reset
-    int nsurv_total;     // ... since the read started (diagnostics: survivors of the seed filter)
+    u32 nsurv_total;     // ... since the read started (diagnostics: survivors of the seed filter); kept in a VGPR on purpose
 #ifdef PG_TIMING
     u64 *t_last;         // diagnostics build (LDS): s_memtime at the last phase boundary, cycles per phase so far
     u32 *t_acc;
@@ -283,9 +315,14 @@ struct Search {
 #define PG_DG(S, sh) ((void)0)
 #endif
     int cap_state;       // state-dependent relevance bound for seeds (see evaluate); T - 1 = none
-    bool want_cap;       // more window chunks will be filtered after the next evaluation: keep cap_state up to date
-    bool tierA;          // the short-lived tier is usable: bps + 16 <= 32 and CheckMismatches' "L > m" test cannot fail
-    bool len_check;      // Min_Perfect_Match_Around_BP >= bps: the "L > m" test of CheckMismatches can fail
+    // bits of one word (a wave-uniform bool costs two scalar registers):
+    //   SF_WANT_CAP   more window chunks will be filtered after the next evaluation: keep cap_state up to date
+    //   SF_TIER_A     the short-lived tier is usable: bps + 16 <= 32 and CheckMismatches' "L > m" test cannot fail
+    //   SF_LEN_CHECK  Min_Perfect_Match_Around_BP >= bps: the "L > m" test of CheckMismatches can fail
+    u32 sf;
+    __device__ __forceinline__ bool want_cap() const { return (sf & 1u) != 0u; }
+    __device__ __forceinline__ bool tierA() const { return (sf & 2u) != 0u; }
+    __device__ __forceinline__ bool len_check() const { return (sf & 4u) != 0u; }
 };
 
 // Running reduction of a search.  Tier B: lane owns L = bps + 64 r + lane in round r; round 0 lives in
@@ -343,13 +380,13 @@ __device__ __forceinline__ long long chr_word_off_of(const PgDevRef &ref, const 
 {
     if (c < PG_CHR_TAB)
         return (long long)((u64)(u32)uni((int)S.chr_tab[3 * c]) | ((u64)(u32)uni((int)S.chr_tab[3 * c + 1]) << 32));
-    const u64 w = ref.chr_word_off[c];
+    const u64 w = KA(ref, chr_word_off)[c];
     return (long long)((u64)(u32)uni((int)(u32)w) | ((u64)(u32)uni((int)(u32)(w >> 32)) << 32));
 }
 __device__ __forceinline__ int chr_size_of(const PgDevRef &ref, const Search &S, int c)
 {
     if (c < PG_CHR_TAB) return uni((int)S.chr_tab[3 * c + 2]);
-    return uni((int)ref.chr_size[c]);
+    return uni((int)KA(ref, chr_size)[c]);
 }
 
 // ---------------------------------------------------------------------------------
@@ -463,7 +500,7 @@ __device__ __forceinline__ void fold_tier_b(const Search &S, const Query<NB> &Q,
                 if (b + 1 >= r) bad |= (m ^ QN[b]) & BP[b];        // L - m >= 64 r - 64 (m <= 64 <= 64 + bps)
             }
             u32 okc = bad == 0ull ? (h.y >> 31) : 0u;
-            if (S.len_check) okc = (u32)L >= ((h.y >> 24) & 0x7fu) ? okc : 0u;   // uniform branch
+            if (S.len_check()) okc = (u32)L >= ((h.y >> 24) & 0x7fu) ? okc : 0u;   // uniform branch
             const Id cid = sizeof(Id) == 8 ? (Id)((u64)h.x | ((u64)(h.y & 0xffffffu) << 32)) : (Id)h.x;
             fold<Id>(m1, m2, wid, ok, k, cid, okc);
         }
@@ -484,13 +521,13 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
     PG_DG(const_cast<Search &>(S), 16);
     bool valid = lane < n;
     int p = 0;
-    bool isB = MIXED ? false : Q.allowB;
+    bool isB = MIXED ? false : Q.allowB();
     if (valid) {
         u32 e = S.queue[lane];
         if (MIXED) isB = e & 1u;
         p = wbase + (int)(e >> 1);
     }
-    const bool comp = isB ? Q.cB : Q.cF;
+    const bool comp = isB ? Q.cB() : Q.cF();
     // Per 64-base block: the mismatch word goes straight into the candidate's tier B entry (LDS);
     // only popcounts stay in registers.  Words of blocks that are not computed keep stale bits: they can
     // only add mismatches to a candidate that is dead there anyway.
@@ -532,7 +569,7 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
     const u32 hamok = cum >= S.thr ? 0x80000000u : 0u;
     valid = valid && lvl0 < S.T;                           // dead before the first length: never counts
     bool lng = valid;
-    if (S.tierA) lng = valid && kA < S.T;
+    if (S.tierA()) lng = valid && kA < S.T;
     const Id id = make_id<Id>((u32)(p - origin), isB, region);
     const u32 lenthr = (u32)(S.min_perfect + (isB ? 0 : 1));           // FORWARD: L > m, BACKWARD: L >= m
     const u32 meta = (u32)((u64)id >> 32) | (lenthr << 24) | hamok;     // id bits 32..55 | CheckMismatches' length bound | Hamming verdict
@@ -624,7 +661,7 @@ __device__ __forceinline__ void stage_window(const PgDevRef &ref, Search &S, lon
     PG_SYNC();
     {
         const long long g0 = wo + (long long)(lo >> 5);     // arithmetic shift = floor
-        const u32 *glo = ref.lo + g0, *ghi = ref.hi + g0, *gnn = ref.nn + g0;
+        const u32 *glo = KA(ref, lo) + g0, *ghi = KA(ref, hi) + g0, *gnn = KA(ref, nn) + g0;
         for (int i = lane; i < nw; i += WAVE) {
             const u32 x = __builtin_amdgcn_alignbit(glo[i + 1], glo[i], sh);
             const u32 y = __builtin_amdgcn_alignbit(ghi[i + 1], ghi[i], sh);
@@ -940,7 +977,7 @@ __device__ __forceinline__ void seed_filter_run(const Search &S, const Query<NB>
 {
     u32 lo = (u32)uni((int)(u32)q_lo<NB>(Q, 0)), hi = (u32)uni((int)(u32)q_hi<NB>(Q, 0));
     const u32 nn = (u32)uni((int)(u32)q_nn<NB>(Q, 0)), oo = (u32)uni((int)(u32)q_oo<NB>(Q, 0));
-    if (DUAL ? Q.cF : (kindB ? Q.cB : Q.cF)) { lo = ~lo; hi = ~hi; }
+    if (DUAL ? Q.cF() : (kindB ? Q.cB() : Q.cF())) { lo = ~lo; hi = ~hi; }
     const u32 acgt = ~(nn | oo);
     const u32 jmask = bits32(1, J), g0mask = bits32(1, jb);
     // read symbols A C G T N (in the orientation of the single kind / of kind F); bases [1, jb) first,
@@ -1112,7 +1149,7 @@ __device__ __forceinline__ void seed_filter_pair(const Search &S, const Query<NB
     if (cap0 > S.cap_state) cap0 = S.cap_state;
     u32 lo = (u32)uni((int)(u32)q_lo<NB>(Q, 0)), hi = (u32)uni((int)(u32)q_hi<NB>(Q, 0));
     const u32 nn = (u32)uni((int)(u32)q_nn<NB>(Q, 0)), oo = (u32)uni((int)(u32)q_oo<NB>(Q, 0));
-    if (Q.cF) { lo = ~lo; hi = ~hi; }
+    if (Q.cF()) { lo = ~lo; hi = ~hi; }
     const u32 acgt = ~(nn | oo);
     const u32 jmask = bits32(1, J), g0mask = bits32(1, jb);
     const u32 sym[5] = { ~lo & ~hi & acgt, lo & ~hi & acgt, ~lo & hi & acgt, lo & hi & acgt, nn };
@@ -1161,7 +1198,7 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
                                           int e_max, int xs, int xe, int origin, u32 region, int lane,
                                           bool use_cache, u32 &cacheF, u32 &cacheB, bool &cache_valid)
 {
-    if (!Q.first_ok || s >= e) return;
+    if (!Q.first_ok() || s >= e) return;
     const int k0 = (s - g0) >> PG_CHUNK_SHIFT, k1 = (e - 1 - g0) >> PG_CHUNK_SHIFT;   // floor
     for (int k = k0; k <= k1; k++) {
         const int cs = g0 + (k << PG_CHUNK_SHIFT);
@@ -1240,7 +1277,7 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
                 else if (end > 0) n = end;
                 else break;
                 S.nsurv += n;
-                S.nsurv_total += n;
+                S.nsurv_total += (u32)n;
                 PG_SYNC();
                 PG_T(S, S.t_base);
                 fold_candidates<NB, Id, MIXED>(S, Q, A, wb, origin, region, n, lane, Rings{ false, 0, 0, 0, 0 }, nullptr);
@@ -1277,12 +1314,12 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
                 seed_filter<NB, NS, true>(S, Q, false, false, lane, mF, mB);
             } else {
                 u32 unused;
-                if (Q.allowF) seed_filter<NB, NS, false>(S, Q, false, false, lane, mF, unused);
-                if (Q.allowB) seed_filter<NB, NS, false>(S, Q, true, false, lane, mB, unused);
+                if (Q.allowF()) seed_filter<NB, NS, false>(S, Q, false, false, lane, mF, unused);
+                if (Q.allowB()) seed_filter<NB, NS, false>(S, Q, true, false, lane, mB, unused);
 #if defined(PG_DUP) && PG_DUP == 3
                 u32 d = 0u;
-                if (Q.allowF) { seed_filter<NB, NS, false>(S, Q, false, false, opaque(lane), d, unused); mF &= d | (u32)opaque(0); }
-                if (Q.allowB) { seed_filter<NB, NS, false>(S, Q, true, false, opaque(lane), d, unused); mB &= d | (u32)opaque(0); }
+                if (Q.allowF()) { seed_filter<NB, NS, false>(S, Q, false, false, opaque(lane), d, unused); mF &= d | (u32)opaque(0); }
+                if (Q.allowB()) { seed_filter<NB, NS, false>(S, Q, true, false, opaque(lane), d, unused); mB &= d | (u32)opaque(0); }
 #endif
             }
             if (use_cache && k == 0) { cacheF = mF; cacheB = mB; }
@@ -1312,7 +1349,7 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
             }
             const int n = total - base < WAVE ? total - base : WAVE;
             S.nsurv += n;
-            S.nsurv_total += n;
+            S.nsurv_total += (u32)n;
             PG_SYNC();
 #if defined(PG_DUP) && PG_DUP == 4
             {   // diagnostics: the same pass into a throw-away copy of the state
@@ -1336,7 +1373,7 @@ __device__ __forceinline__ void scan_range(const PgDevRef &ref, Search &S,
 {
     // window coordinates come out of LDS / per-read loads: tell the compiler they are wave-uniform
     g0 = uni(g0); s = uni(s); e = uni(e); e_max = uni(e_max); xs = uni(xs); xe = uni(xe); origin = uni(origin);
-    if (Q.allowF && Q.allowB)
+    if (Q.allowF() && Q.allowB())
         scan_impl<NB, NS, Id, true>(ref, S, Q, A, wo, g0, s, e, e_max, xs, xe, origin, region, lane,
                                 use_cache, cacheF, cacheB, cache_valid);
     else
@@ -1389,7 +1426,7 @@ __device__ __forceinline__ void evaluate(Search &S, const Acc<NB, Id> &A, u32 mm
     // tier A lives in four 16-lane quarters: bring quarters 1..3 to quarter 0 through LDS and merge
     u32 t1 = A.m1, t2 = A.m2, tok = A.ok;
     Id tid = A.id;
-    if (S.tierA) {
+    if (S.tierA()) {
         u32 a1 = PG_BIG, a2 = PG_BIG, aok = 0u;
         Id aid = 0;
         if (lane < 16) { a1 = A.a1; a2 = A.a2; aok = A.aok; aid = A.aid; }
@@ -1409,7 +1446,7 @@ __device__ __forceinline__ void evaluate(Search &S, const Acc<NB, Id> &A, u32 mm
         }
         merge<Id>(t1, t2, tid, tok, a1, a2, aid, aok);
     }
-    if (S.want_cap) {
+    if (S.want_cap()) {
         // max over L in [bps, J] of the lowest level present (none present: no bound), + ADD; J as in seed_filter
         // for the chunks of wide windows (the only ones filtered after an evaluation)
         const int J = seed_depth(S.len, S.T, true);
@@ -1533,13 +1570,13 @@ __device__ __forceinline__ void emit_runs(const Search &S, bool antiF, bool anti
 template <int NB>
 __device__ __forceinline__ u64 request_planes(const PgDevBatch &B, uint32_t rid, int lane)
 {
-    const u32 pb = B.plane_blocks;
-    return (u32)lane < 8u * pb ? B.planes[(size_t)rid * 8u * pb + (u32)lane] : 0ull;
+    const u32 pb = KA(B, plane_blocks);
+    return (u32)lane < 8u * pb ? KA(B, planes)[(size_t)rid * 8u * pb + (u32)lane] : 0ull;
 }
 template <int NB>
 __device__ __forceinline__ void store_planes(const PgDevBatch &B, u64 v, int lane, u64 *qp)
 {
-    const u32 pb = B.plane_blocks;
+    const u32 pb = KA(B, plane_blocks);
     PG_SYNC();
     if ((u32)lane < 8u * pb) qp[pb == (u32)NB ? (u32)lane : ((u32)lane / pb) * NB + (u32)lane % pb] = v;
     PG_SYNC();
@@ -1552,10 +1589,10 @@ __device__ __forceinline__ u32 pool_alloc(const PgDevBatch &B, int n, int lane, 
 {
     const u32 shard = blockIdx.x & (PG_POOL_SHARDS - 1u);
     u32 off = 0;
-    if (n > 0 && lane == 0) off = atomicAdd(B.pool_used + shard * 16u, (u32)n);
+    if (n > 0 && lane == 0) off = atomicAdd(KA(B, pool_used) + shard * 16u, (u32)n);
     off = (u32)uni((int)off);
-    fits = (u64)off + (u64)n <= (u64)B.pool_shard_cap;
-    return shard * B.pool_shard_cap + off;
+    fits = (u64)off + (u64)n <= (u64)KA(B, pool_shard_cap);
+    return shard * KA(B, pool_shard_cap) + off;
 }
 
 template <int NB>
@@ -1576,7 +1613,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
 {
     S.win_wo = -1;
     S.win_hi = S.wbase = 0;
-    S.nsurv_total = 0;
+    S.nsurv_total = (u32)opaque(0);
 #ifdef PG_TIMING
     S.t_base = 1;
 #endif
@@ -1584,14 +1621,14 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     S.dg = 0u;
 #endif
     S.cap_state = 255;
-    S.want_cap = false;
+    S.sf = 0u;
     // the read's packed record (rid is wave-uniform)
     uint4 r0, r1;
     if (PG_REC_LDS(NB)) {
         r0 = S.rec[2 * slot];
         r1 = S.rec[2 * slot + 1];
     } else {
-        const uint4 *rp = (const uint4 *)(B.in + rid);
+        const uint4 *rp = (const uint4 *)(B.in + rid);     // (reads over 256 bases only; as an ordinary argument: the compiler makes this a scalar load)
         r0 = rp[0];
         r1 = rp[1];
     }
@@ -1600,7 +1637,9 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     const long long chr_wo = chr_word_off_of(ref, S, chr);
     S.len = len;
     S.M = uni((int)(r1.y >> 24));
-    S.T = S.M + prm.add_mm + 1;
+    S.add_mm = KA(prm, add_mm);
+    S.min_perfect = KA(prm, min_perfect);
+    S.T = S.M + S.add_mm + 1;
     S.thr = uni((int)(r1.y & 0xffffu));
     // g_maxMismatch at the two filter depths (<= M: the breakpoints from index M on lie beyond the read)
     {
@@ -1613,7 +1652,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     const u64 planes_of_read = request_planes<NB>(B, rid, lane);
     if (mode & PG_MODE_CLOSE) {
         const int strand0 = uni((int)((r1.y >> 16) & 0xffu));
-        if (len - 1 >= prm.min_close && (strand0 == '+' || strand0 == '-')) {
+        if (len - 1 >= KA(prm, min_close) && (strand0 == '+' || strand0 == '-')) {
             const int apos0 = uni((int)r0.z), isz0 = uni((int)(short)(r1.x >> 16));
             int s1 = strand0 == '+' ? apos0 : apos0 - isz0, e1 = s1 + isz0;           // attempt 0: R = 0
 #ifndef PG_NO_SHARED_CLOSE_GRID
@@ -1645,10 +1684,10 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
         const int apos = uni((int)r0.z);
         const int isz = uni((int)(short)(r1.x >> 16));
         int close_bases = 0;
-        if (len - 1 >= prm.min_close && (strand == '+' || strand == '-')) {
-            S.bps = prm.min_close;
-            S.len_check = prm.min_perfect >= S.bps;        // Min_Perfect_Match_Around_BP >= the first evaluated length
-            S.tierA = S.bps + 16 <= 32 && !S.len_check;
+        if (len - 1 >= KA(prm, min_close) && (strand == '+' || strand == '-')) {
+            S.bps = KA(prm, min_close);
+            // Min_Perfect_Match_Around_BP >= the first evaluated length: CheckMismatches' length test can fail, no short-lived tier
+            S.sf = S.min_perfect >= S.bps ? 4u : (S.bps + 16 <= 32 ? 2u : 0u);
             const u32 mm0 = mm_of<NB>(S, S.bps + lane);
             // Attempt 0 (the one that succeeds for most reads) stages and filters exactly its own window.  The
             // retries share work: the window of the attempts with R = 1 contains the one with R = 0, so from
@@ -1683,17 +1722,16 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                 Q.qp = qplanes + (!flipped ? 4 * NB : 0);
                 int s1, e1;
                 if (strand == '+') {
-                    Q.cF = !flipped; Q.cB = false; Q.allowF = true; Q.allowB = false;
+                    Q.cF_ = !flipped; Q.cB_ = false; Q.allowF_ = true; Q.allowB_ = false;
                     s1 = apos - Rg * isz;
                     e1 = s1 + (2 * Rg + 1) * isz;
                 } else {
-                    Q.cB = flipped; Q.cF = false; Q.allowF = false; Q.allowB = true;
+                    Q.cB_ = flipped; Q.cF_ = false; Q.allowF_ = false; Q.allowB_ = true;
                     e1 = apos + Rg * isz;
                     s1 = e1 - (2 * Rg + 1) * isz;
                 }
-                Q.antisenseF = true;      // CheckLeft_Close: FORWARD, ANTISENSE
-                Q.antisenseB = false;     // CheckRight_Close: BACKWARD, SENSE
-                Q.first_ok = first_base_ok<NB>(Q);
+                // (points: CheckLeft_Close FORWARD / ANTISENSE, CheckRight_Close BACKWARD / SENSE: emit_runs' arguments)
+                Q.first_ok_ = first_base_ok<NB>(Q);
                 close_bases = e1 > s1 ? e1 - s1 : 0;
                 if (att != 2) {           // attempt 2 continues attempt 1's reduction
                     A.reset();
@@ -1733,7 +1771,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                             fits = res_fits;
                         } else
                             close_base = pool_alloc(B, n_close, lane, fits);
-                        if (fits) emit_runs<NB, Id>(S, true, false, chr, w1s, nullptr, E, kept, B.pool + close_base, opaque(lane));
+                        if (fits) emit_runs<NB, Id>(S, true, false, chr, w1s, nullptr, E, kept, KA(B, pool) + close_base, opaque(lane));
                         // AbsLoc of the last point (getLastAbsLocCloseEnd)
                         const u64 idl = (u64)E.id_last;
                         const int pl = w1s + (int)(u32)(idl & ((1ull << IdFmt<Id>::RB) - 1ull));
@@ -1747,7 +1785,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
         alg = (u32)(8 * len + 3 * (close_bases + 2 * len) + 96 * n_close);   // x 8: the read once, 3 bits per base, 12 bytes per run
     } else {
         // far-end launch: the close-end summary of the earlier launch
-        const uint4 o1 = ((const uint4 *)(B.out + rid))[1];
+        const uint4 o1 = ((const uint4 *)(KA(B, out) + rid))[1];
         close_last = (u32)uni((int)o1.x);
         close_max = uni((int)(o1.y & 0xffffu));
         flipped = uni((int)((o1.y >> 16) & 0xffu));
@@ -1764,18 +1802,15 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     // "if (CurrentBase == 'N' || MaxLenCloseEnd() == 0) return;" (farend_searcher.cpp:60-66)
     if (do_far && close_max > 0 && len - 1 >= 10) {
         S.bps = 10;               // farend_searcher.cpp:90
-        S.len_check = prm.min_perfect >= 10;
-        S.tierA = !S.len_check;
+        S.sf = S.min_perfect >= 10 ? 4u : 2u;
         // cur = flipped ? RC(orig) : orig.  Plus strand consumes cur left to right, Minus strand
         // consumes complement(cur) walking the reference right to left.
         Query<NB> Q;
         Q.qp = qplanes + (flipped ? 4 * NB : 0);
-        Q.cF = flipped; Q.cB = !flipped;
-        Q.allowF = Q.allowB = true;
-        Q.antisenseF = false;     // FORWARD, SENSE
-        Q.antisenseB = true;      // BACKWARD, ANTISENSE
-        Q.first_ok = first_base_ok<NB>(Q);
-        if (Q.first_ok) {
+        Q.cF_ = flipped; Q.cB_ = !flipped;                // (points: FORWARD / SENSE, BACKWARD / ANTISENSE)
+        Q.allowF_ = Q.allowB_ = true;
+        Q.first_ok_ = first_base_ok<NB>(Q);
+        if (Q.first_ok_) {
             const u32 mm0 = mm_of<NB>(S, 10 + lane);
             const int chr_size = chr_size_of(ref, S, chr);
             int far_bases = 0;
@@ -1803,15 +1838,15 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                             far_base = pool_alloc(B, n_far, lane, f2);
                             fits = fits && f2;
                         }
-                        if (fits) emit_runs<NB, Id>(S, false, true, chr, origin, bdw, E, kept, B.pool + far_base, opaque(lane));
+                        if (fits) emit_runs<NB, Id>(S, false, true, chr, origin, bdw, E, kept, KA(B, pool) + far_base, opaque(lane));
                     }
                 }
             };
             bool done = false;
             // BreakDancer / read-pair cluster of this read first (pindel.cpp:1006-1018)
-            if (B.bd && r1.z != 0u) {
+            if (KA(B, bd) && r1.z != 0u) {
                 const int nbd = uni((int)r1.z);
-                const pg_window *bd = B.bd + uni((int)r1.w);
+                const pg_window *bd = KA(B, bd) + uni((int)r1.w);
                 A.reset();
                 S.cap_state = 255;
                 S.nsurv = 0;
@@ -1833,23 +1868,25 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                 // did not cover are scanned.  Chunk grid: the innermost 2048 positions are one chunk (one LDS
                 // fill and one seed-filter pass serve the ranges up to 1024).
                 const int center = (int)close_last;
-                const int maxspan = 64 << (2 * prm.max_range_index);
+                const int k_mri = KA(prm, max_range_index);
+                const u32 k_spacer = KA(prm, spacer);
+                const int maxspan = 64 << (2 * k_mri);
                 const int origin = center - maxspan;
                 const int g0 = center - (int)PG_CHUNK / 2;
                 int emax;
-                if ((u32)center + (u32)maxspan + prm.spacer < (u32)chr_size) emax = center + maxspan;
-                else emax = chr_size - (int)prm.spacer;
+                if ((u32)center + (u32)maxspan + k_spacer < (u32)chr_size) emax = center + maxspan;
+                else emax = chr_size - (int)k_spacer;
                 u32 cacheF = 0u, cacheB = 0u;                    // seed-filter masks of the innermost chunk
                 bool cache_valid = false;
                 int ps = 0, pe = 0, nsurv_eval = 0;
                 A.reset();
                 S.cap_state = 255;
-                S.want_cap = prm.max_range_index >= 3;     // ranges beyond the cached innermost chunk will be filtered
+                if (k_mri >= 3) S.sf |= 1u;     // ranges beyond the cached innermost chunk will be filtered
                 S.nsurv = 0;
                 auto range_of = [&](int span, int &s, int &e) {
-                    if ((u32)center > (u32)span + prm.spacer) s = center - span; else s = (int)prm.spacer;
-                    if ((u32)center + (u32)span + prm.spacer < (u32)chr_size) e = center + span;
-                    else e = chr_size - (int)prm.spacer;
+                    if ((u32)center > (u32)span + k_spacer) s = center - span; else s = (int)k_spacer;
+                    if ((u32)center + (u32)span + k_spacer < (u32)chr_size) e = center + span;
+                    else e = chr_size - (int)k_spacer;
                 };
                 int r_first = 0;
 #ifndef PG_NO_FUSED_RANGES
@@ -1859,7 +1896,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                 // candidates are folded just before range r is evaluated, its short-lived ones sit in their own tier A
                 // quarter(s).  A read that needs all three ranges pays one pass instead of three.
                 {
-                    const int R = prm.max_range_index < 2 ? prm.max_range_index : 2;
+                    const int R = k_mri < 2 ? k_mri : 2;
                     int rs[3], re[3];
 #pragma unroll
                     for (int r = 0; r < 3; r++) {
@@ -1904,7 +1941,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                                     slot++;
                                 }
                                 S.nsurv += total;
-                                S.nsurv_total += total;
+                                S.nsurv_total += (u32)total;
                                 PG_SYNC();
                                 int ring_n[3];
                                 PG_T(S, 7);
@@ -1933,7 +1970,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                 }
 #endif
                 int span = 64 << (2 * r_first);
-                for (int r = r_first; r <= prm.max_range_index && !done; r++, span *= 4) {
+                for (int r = r_first; r <= k_mri && !done; r++, span *= 4) {
                     int s, e;
                     range_of(span, s, e);
                     if (s < e) {
@@ -1962,7 +1999,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     PG_T(S, 9);
     alg = (alg + 4u) >> 3;
     if (lane == 0) {
-        uint4 *op = (uint4 *)(B.out + rid);
+        uint4 *op = (uint4 *)(KA(B, out) + rid);
         if (do_close) {
             op[0] = make_uint4(close_base, (u32)n_close, far_base, (u32)n_far);
 #ifdef PG_DIAG
@@ -2016,8 +2053,6 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
     S.mm_tab = lds.mm_tab;
     S.chr_tab = lds.chr_tab;
     S.rec = lds.rec;
-    S.add_mm = prm.add_mm;
-    S.min_perfect = prm.min_perfect;
     u64 *qplanes = lds.qp;                        // [0]: forward, [1]: reversed consumption order
     if (lane < 8 * NB) qplanes[lane] = 0ull;      // (blocks beyond the batch's plane layout are never written)
 #ifdef PG_TIMING
@@ -2030,19 +2065,19 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
     S.t_base = 1;
 #endif
 
-    const uint32_t n = B.n_reads;
     // reads claimed per atomic: PG_CLAIM, fewer when the launch is small (a 50 000-read flush is ten reads per resident
-    // wave: with claims of eight some waves would search sixteen reads and most eight)
-    const uint32_t per_wg = n / gridDim.x;
-    // (claims of ONE read for the last round and a half of a launch, to shorten its tail, were measured and rejected: a claim
-    // is a dependent chain atomic -> records -> first window, 2 us that eight reads share -- 262 144 reads 0.94 -> 0.98 ms)
-    const uint32_t claim = per_wg >= 24u ? PG_CLAIM : (per_wg >= 6u ? 2u : 1u);
-    const uint32_t per = n / PG_N_XCD;
+    // wave: with claims of eight some waves would search sixteen reads and most eight).
+    // (Claims of ONE read for the last round and a half of a launch, to shorten its tail, were measured and rejected: a claim
+    // is a dependent chain atomic -> records -> first window, 2 us that eight reads share -- 262 144 reads 0.94 -> 0.98 ms.)
+    // Nothing but `part` and `tried` lives from one claim to the next: the launch's size comes from the kernarg segment again.
     uint32_t part = blockIdx.x % PG_N_XCD, tried = 0;
     while (tried < PG_N_XCD) {
+        const uint32_t n = KA(B, n_reads);
+        const uint32_t claim = n >= 24u * gridDim.x ? PG_CLAIM : (n >= 6u * gridDim.x ? 2u : 1u);
+        const uint32_t per = n / PG_N_XCD;
         const uint32_t lo = part * per, hi = part + 1 == PG_N_XCD ? n : lo + per;
         uint32_t got = 0;
-        if (lane == 0) got = atomicAdd(B.work_ctr + part * 16u, claim);
+        if (lane == 0) got = atomicAdd(KA(B, work_ctr) + part * 16u, claim);
         got = (u32)uni((int)got);
         if (got >= hi - lo) {                             // this part is exhausted
             part = part + 1 == PG_N_XCD ? 0 : part + 1;
@@ -2053,7 +2088,7 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
         if (PG_REC_LDS(NB)) {
             PG_SYNC();
             if ((uint32_t)lane < 8u * (end - first))
-                ((u32 *)lds.rec)[lane] = ((const u32 *)(B.in + B.first_read + first))[lane];
+                ((u32 *)lds.rec)[lane] = ((const u32 *)(KA(B, in) + KA(B, first_read) + first))[lane];
             PG_SYNC();
         }
         PG_T(S, 11);
@@ -2061,19 +2096,19 @@ __global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevR
         u32 res = 0u;
         {
             const u32 shard = blockIdx.x & (PG_POOL_SHARDS - 1u);
-            if (lane == 0) res = atomicAdd(B.pool_used + shard * 16u, claim * PG_RESERVE);
+            if (lane == 0) res = atomicAdd(KA(B, pool_used) + shard * 16u, claim * PG_RESERVE);
             res = (u32)uni((int)res);
-            const bool res_fits = (u64)res + (u64)(claim * PG_RESERVE) <= (u64)B.pool_shard_cap;
-            res += shard * B.pool_shard_cap;
+            const bool res_fits = (u64)res + (u64)(claim * PG_RESERVE) <= (u64)KA(B, pool_shard_cap);
+            res += shard * KA(B, pool_shard_cap);
             for (uint32_t i = first; i < end; i++)
-                search_read<NB, NS, Id, mode>(ref, prm, B, S, qplanes, B.first_read + i, (int)(i - first), opaque(lane),
+                search_read<NB, NS, Id, mode>(ref, prm, B, S, qplanes, KA(B, first_read) + i, (int)(i - first), opaque(lane),
                                           res + (i - first) * PG_RESERVE, res_fits);
             PG_T(S, 10);
         }
     }
 #ifdef PG_TIMING
     if (lane == 0) {
-        u64 *dg = (u64 *)(B.work_ctr + PG_WORK_CTRS * 16u);
+        u64 *dg = (u64 *)(KA(B, work_ctr) + PG_WORK_CTRS * 16u);
         for (int k = 0; k < 12; k++) atomicAdd((unsigned long long *)(dg + k), (unsigned long long)S.t_acc[k]);
     }
 #endif
