@@ -30,7 +30,7 @@ if ROOT not in sys.path:
 
 CHR20_LEN = 62_435_964       # demo/hs_ref_chr20.fa.fai:1
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r04")
 TRAFFIC_FILE = "hbm_traffic.json"
 PMC_FILE = "pmc_sq.txt"
 
@@ -100,19 +100,19 @@ def measured_traffic(args, reads_per_launch):
     with open(path) as fh:
         t = json.load(fh)
     per_read = t["fetch_bytes_per_read"] + t["write_bytes_per_read_uncalibrated"]
-    return per_read * reads_per_launch, (f"profiles/r03/{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+    return per_read * reads_per_launch, (f"profiles/r04/{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                           "separate passes, per read x reads per launch)")
 
 
 def issue_model(args, kernel_ms, reads_per_launch):
     """The kernel is instruction-issue bound, not HBM bound.  Instructions per read and lane
-    occupancy from the committed PMC passes of this round (profiles/r03/pmc_sq.txt); issue costs from the microbenchmark
+    occupancy from the committed PMC passes of this round (profiles/r04/pmc_sq.txt); issue costs from the microbenchmark
     (profiles/r03/ubench_issue_rates.txt, MI355X): a SIMD issues a fast-rate wave64 VALU op (plain logic / add / v_bitop3
     on VGPR or constant operands) every 2.0 cycles and a slow-rate one (an SGPR operand, funnel shifts, compares, selects,
     DPP, lane reads: 44 % of this kernel's VALU instructions statically) every 3.2 cycles, the CU's one scalar unit
     1.0-1.35 ops per cycle.  Both VALU bounds are given; the truth lies between them.  `ns_per_instruction` = SIMD time
     per read / (VALU + SALU instructions per read); `in_situ_ns_per_extra_instruction` = what 128 more instructions
-    per seed-filter run were measured to cost inside this kernel (profiles/r03/issue_calibration.txt)."""
+    per seed-filter run were measured to cost inside this kernel (profiles/r04/issue_calibration.txt)."""
     path = os.path.join(PROFILE_DIR, PMC_FILE)
     if not default_workload(args) or not os.path.exists(path) or kernel_ms <= 0:
         return None
@@ -133,7 +133,7 @@ def issue_model(args, kernel_ms, reads_per_launch):
            "salu_busy_frac_at_1_per_cu_cycle": salu * reads_per_launch / 256.0 / cyc,
            "ns_per_instruction": kernel_ms * 1e6 / per_simd / (valu + salu),
            "in_situ_ns_per_extra_instruction": {"salu": 1.24, "valu_fast_rate": 0.98, "valu_slow_rate": 1.24},
-           "source": f"profiles/r03/{PMC_FILE} + profiles/r03/ubench_issue_rates.txt + profiles/r03/issue_calibration.txt, "
+           "source": f"profiles/r04/{PMC_FILE} + profiles/r03/ubench_issue_rates.txt + profiles/r04/issue_calibration.txt, "
                      "256 CUs x 4 SIMDs, 2.4 GHz nominal"}
     if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_ACTIVE_INST_VALU"):
         # active lanes per executed VALU instruction (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU), of 64
@@ -395,7 +395,7 @@ def main():
             st, keep = binding._batch_struct(batch.slice(0, nb))
             L = binding.lib()
             best_t = None
-            for _ in range(3):                        # the first call pins the result buffers / grows the device arena
+            for _ in range(5):                        # the first calls pin the result buffers / grow the device arena
                 h = C.c_void_p()
                 th = time.perf_counter()
                 rc = L.pg_search_batch(eng._h, C.byref(st), C.byref(h))

@@ -625,8 +625,8 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, PodVec<uint6
         need += 2 * (((n + 1) * 4 + 511) & ~(size_t)255) + (size_t)b->pool_shard_cap * PG_POOL_SHARDS * sizeof(pg_run) +
                 pg_scan_tmp_bytes((uint32_t)n) + 4096;
         // ... and for the chunk-by-chunk delivery of search_host: gathered runs (2 lists), 64-bit offsets (2 lists), scratch
-        need += 2 * (deliver_cap(n) * sizeof(pg_run) + 512) + 2 * ((n + 1) * 8 + 512) + PG_DELIVER_CHUNK * 8 + 1024 * 8 +
-                (n / PG_DELIVER_CHUNK + 2) * 64 + 8192 + 8 * n + 4096;      // (+ the summaries of a one-block delivery)
+        need += 2 * (deliver_cap(n) * sizeof(pg_run) + 512) + 2 * ((n + 1) * 8 + 512) + PG_DELIVER_CHUNK * 8 + 4096 * 8 +
+                (n / (PG_HOST_CHUNK / 4) + 16) * 64 + 8192 + 8 * n + 4096;      // (+ the summaries of a one-block delivery)
         if (need > ctx->arena.cap) {
             if (ctx->arena.base) (void)hipFree(ctx->arena.base);
             ctx->arena.base = nullptr;
@@ -1419,7 +1419,7 @@ int pg_device_batch_algorithmic_bytes(pg_ctx *ctx, pg_device_batch *b, double *b
 }
 
 // ---------------------------------------------------------------- host in / host out
-// Host buffers in, host results out, as a three-stage pipeline over chunks of PG_DELIVER_CHUNK reads:
+// Host buffers in, host results out, as a three-stage pipeline over chunks of 64 k to 1 M reads (see `bounds` below):
 //   copy stream      the chunk's inputs, host -> HBM
 //   compute stream   pack, search (the kernel takes a read range of the batch), delivery kernels: the chunk's runs
 //                    gathered in read order behind the earlier chunks', its 64-bit CSR offsets (pg_deliver_chunk)
@@ -1456,13 +1456,20 @@ static int search_host(pg_ctx *ctx, const pg_read_batch *reads, int mode, pg_res
     r = new pg_result();
     r->n = n;
     const char *chunk_env = getenv("PG_HOST_CHUNK");             // (tests: several chunks on a small batch)
-    const uint32_t chunk = chunk_env ? (uint32_t)std::min<long>(std::max(1, atoi(chunk_env)), PG_DELIVER_CHUNK) : PG_DELIVER_CHUNK;
-    // chunk boundaries: a batch of several chunks starts with two smaller ones (a quarter and a half chunk), so that the
-    // first kernel launches after 0.15 ms of input copies instead of 0.6 ms
+    const uint32_t chunk = chunk_env ? (uint32_t)std::min<long>(std::max(1, atoi(chunk_env)), PG_DELIVER_CHUNK) : PG_HOST_CHUNK;
+    // Chunk boundaries.  A launch of 256 k reads runs at 278 M reads/s, one of 1 M at ~310, one of 10 M at 323 (ramp-up and
+    // tail of the launch itself: profiles/r04/kernel_experiments.txt), but the first chunk's copy and the last chunk's
+    // delivery + download are exposed: small chunks first (a quarter of the base chunk, doubling), up to 2^20 reads in the
+    // middle, a third of what is left towards the end.
     std::vector<uint32_t> bounds(1, 0u);
     if (n > chunk && !chunk_env) {
-        bounds.push_back(chunk / 4);
-        bounds.push_back(chunk / 4 + chunk / 2);
+        uint64_t ramp = chunk / 4;
+        while (bounds.back() < n) {
+            const uint64_t left = n - bounds.back();
+            const uint64_t mid = std::min<uint64_t>(std::max<uint64_t>(left / 3, chunk), PG_DELIVER_CHUNK);
+            bounds.push_back((uint32_t)(bounds.back() + std::min<uint64_t>(std::min(ramp, mid), left)));
+            ramp *= 2;
+        }
     }
     while (bounds.back() < n) bounds.push_back((uint32_t)std::min<uint64_t>((uint64_t)bounds.back() + chunk, n));
     const uint32_t n_chunks = (uint32_t)bounds.size() - 1;
@@ -1523,7 +1530,7 @@ static int search_host(pg_ctx *ctx, const pg_read_batch *reads, int mode, pg_res
                    !(d_off[0] = (unsigned long long *)ctx->arena.take(((size_t)n + 1) * 8)) ||
                    !(d_off[1] = (unsigned long long *)ctx->arena.take(((size_t)n + 1) * 8)))
             return bail(fail(ctx, PG_E_NOMEM, "device arena too small for the delivery buffers"));
-        if (!(d_local = ctx->arena.take((size_t)PG_DELIVER_CHUNK * 8)) || !(d_blk = ctx->arena.take(1024 * 8)) ||
+        if (!(d_local = ctx->arena.take((size_t)PG_DELIVER_CHUNK * 8)) || !(d_blk = ctx->arena.take(4096 * 8)) ||
             !(d_info = (unsigned long long *)ctx->arena.take((size_t)n_chunks * 64)))
             return bail(fail(ctx, PG_E_NOMEM, "device arena too small for the delivery buffers"));
         HostBuf<unsigned long long> info;

@@ -153,9 +153,10 @@ int pg_pack_reads(const PgSoaIn *soa, PgInRec *in, uint32_t lo, uint32_t cnt, vo
 int pg_pack_close_summary(const PgSoaOut *soa, PgOutRec *out, uint32_t n, void *stream);
 int pg_unpack_results(const PgOutRec *out, const PgSoaOut *soa, uint32_t n, void *stream);
 // One chunk (cnt <= PG_DELIVER_CHUNK reads) of a searched batch to read-order CSR behind the earlier chunks: see the
-// delivery kernels in pg_kernels.hip.  local / blk: scratch of cnt and 1024 uint2; run_tot: 2 running totals (zeroed
+// delivery kernels in pg_kernels.hip.  local / blk: scratch of cnt and 4096 uint2; run_tot: 2 running totals (zeroed
 // per batch); info: 4 values for the host {close base, far base, close runs, far runs}.
-#define PG_DELIVER_CHUNK (1u << 18)
+#define PG_DELIVER_CHUNK (1u << 20)     // reads a delivery handles at most (scan2: 4096 blocks of 256)
+#define PG_HOST_CHUNK (1u << 18)        // reads per chunk the host path starts from (and the largest batch that is ONE chunk)
 int pg_deliver_chunk(const PgOutRec *out, uint32_t cnt, uint8_t *rc_flag, uint32_t *close_last, uint16_t *close_max,
                      void *local, void *blk, unsigned long long *run_tot, unsigned long long *info,
                      const pg_run *pool, unsigned long long pool_runs, pg_run *close_runs, pg_run *far_runs /* null: behind the close runs */,

@@ -2539,12 +2539,26 @@ __global__ __launch_bounds__(1024) void pg_deliver_scan2(uint2 *blk, uint32_t nb
     __shared__ typename Scan::TempStorage tc, tf;
     __shared__ typename Reduce::TempStorage tr;
     const uint32_t worst = Reduce(tr).Reduce(threadIdx.x < PG_POOL_SHARDS ? pool_used[threadIdx.x * 16u] : 0u, hipcub::Max());
-    uint2 v = make_uint2(0u, 0u);
-    if (threadIdx.x < nblk) v = blk[threadIdx.x];
+    // four consecutive block sums per thread: chunks of up to 4096 x 256 = 2^20 reads
+    uint2 v[4];
+    uint32_t tx = 0u, ty = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t idx = threadIdx.x * 4u + (uint32_t)j;
+        v[j] = idx < nblk ? blk[idx] : make_uint2(0u, 0u);
+        tx += v[j].x;
+        ty += v[j].y;
+    }
     uint32_t ec, ef, sc, sf;
-    Scan(tc).ExclusiveSum(v.x, ec, sc);
-    Scan(tf).ExclusiveSum(v.y, ef, sf);
-    if (threadIdx.x < nblk) blk[threadIdx.x] = make_uint2(ec, ef);
+    Scan(tc).ExclusiveSum(tx, ec, sc);
+    Scan(tf).ExclusiveSum(ty, ef, sf);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t idx = threadIdx.x * 4u + (uint32_t)j;
+        if (idx < nblk) blk[idx] = make_uint2(ec, ef);
+        ec += v[j].x;
+        ef += v[j].y;
+    }
     if (threadIdx.x == 0) {
         info[0] = run_tot[0];
         info[1] = run_tot[1];

@@ -82,6 +82,23 @@ if [ -f pindel_amd/libpindel_pg_diag.so ]; then
     } 2>/dev/null > "$out/per_read_event_counts.txt"
 fi
 
+# the pack stage on the 10 M-read batch: HIP events (scripts/pack_rate.py) and the tracer's view of the same kernel
+python scripts/pack_rate.py pindel_amd/libpindel_pg.so 10000000 2>/dev/null | tail -1 > "$out/pack_rate.txt"
+PG_LEN=150 python scripts/pack_rate.py pindel_amd/libpindel_pg.so 10000000 2>/dev/null | tail -1 >> "$out/pack_rate.txt"
+( cd /tmp && rm -rf /tmp/rp_pack && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_pack -- python "$root/scripts/pack_rate.py" "$LIBSO" 10000000 > /tmp/rp_pack.log 2>&1
+  f=$(find /tmp/rp_pack -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && grep -E '"Name"|pg_pack_kernel|pg_search_kernel' "$f" > "$out/kernel_stats_pack.csv" )
+cat "$out/pack_rate.txt"
+
+# what one more instruction costs inside the shipped kernel (-DPG_PAD_* builds: 128 extra dependent instructions per filter run)
+if [ -f pindel_amd/libpindel_pg_pad_s.so ]; then
+    bash scripts/variants.sh plain pad_s pad_vf pad_vs > "$out/issue_calibration_raw.txt" 2>&1
+    cat "$out/issue_calibration_raw.txt"
+fi
+
+# Pindel's own flush size and a 4 M-read batch through the host-buffer entry, steady state (six calls each)
+python scripts/host_path_calls.py 50000 4000000 > "$out/host_path_calls.txt" 2>&1
+tail -4 "$out/host_path_calls.txt"
+
 # the other workloads and parameter points quoted in DESIGN.md section 8 (one bench line each)
 {
     for w in colo-bd repeat-rich wgs-bins grch38-150; do
