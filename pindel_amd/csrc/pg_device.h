@@ -136,6 +136,14 @@ struct PgSoaOut {
 // fill, where the extra KB of LDS would cost a resident wave per SIMD.
 #define PG_PAIR_CHUNKS(nb) ((nb) <= 3)
 #define PG_WIN_WORDS(nb) (((PG_PAIR_CHUNKS(nb) ? 2u : 1u) * PG_CHUNK + 2u * (64u * (nb))) / 32u + 6u)
+// ... of which this many are STATIC LDS.  For 129..192-base reads (nb = 3) the second chunk's words are dynamic LDS that only
+// launches with -x >= 3 ask for: the static part, 6.3 KB, then fits 24 workgroups per CU (6 waves per SIMD) at the default -x 2,
+// where nothing ever takes two chunks per fill.  The dynamic part starts where the static LDS ends (the window is the last
+// member of the kernel's one static LDS object), so the window stays one array with compile-time addresses.
+// (LDS is handed out in granules of 1280 bytes on gfx950: 24 workgroups per CU need <= 6400 bytes each -- hence + 4 words of
+// slack here, not + 6: a fill writes 78 words and a candidate reads up to word 76 of a one-chunk window)
+#define PG_WIN_STATIC_WORDS(nb) ((nb) == 3 ? (PG_CHUNK + 2u * (64u * (nb))) / 32u + 4u : PG_WIN_WORDS(nb))
+#define PG_WIN_DYN_BYTES(nb) ((PG_WIN_WORDS(nb) - PG_WIN_STATIC_WORDS(nb)) * 16u)
 
 #ifdef __cplusplus
 extern "C" {

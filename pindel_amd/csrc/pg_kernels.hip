@@ -82,8 +82,16 @@ __device__ __forceinline__ T karg_load(int off)
 #ifndef PG_N_XCD
 #define PG_N_XCD 8u        // MI355X: 8 accelerator complex dies, 32 CUs and one L2 each
 #endif
-#ifndef PG_WAVES_PER_EU
-#define PG_WAVES_PER_EU 5   // register budget the kernel is compiled for (waves per SIMD): 96 VGPRs
+// Register budget the kernel is compiled for, in waves per SIMD (= resident single-wave workgroups per CU / 4).  Six (80 VGPRs)
+// where the LDS lets 24 workgroups in: reads of up to 192 bases with 32-bit candidate ids.  Since the kernel's arguments stopped occupying scalar
+// registers (round 4) the sixth wave pays: 100 bp 6.03 -> 5.60 ms per 2 M reads, -x 5 28.9 -> 27.1; four waves: +13 %; seven
+// (72 VGPRs, spills): +-0.  Longer reads (7.3 KB of LDS and up) stay at five.
+// (LDS comes in granules of 1280 bytes: 24 workgroups per CU = at most five granules = 6400 bytes each; pg_waves<NB, Id>()
+// below, behind the Lds struct, decides by its size)
+#ifdef PG_WAVES_PER_EU
+#define PG_WAVES(NB, Id) PG_WAVES_PER_EU
+#else
+#define PG_WAVES(NB, Id) (sizeof(Lds<NB, Id>) <= 6400 ? 6 : 5)
 #endif
 #ifndef PG_CLAIM
 #define PG_CLAIM 8u         // reads claimed per atomic
@@ -261,7 +269,6 @@ template <> struct AccB<u64> {
 
 template <int NB, typename Id>
 struct Lds {
-    uint4 win[PG_WIN_WORDS(NB)];              // staged window: code planes (lo, hi, N)
     uint4 bufA[68];                           // tier A entries {mis0 lo, sne0 lo, id lo, meta}; scratch for the quarter merge
     uint2 bufB[64 * NB];                      // tier B entries: the mismatch bitmap, NB x {mis lo, mis hi} per candidate
     uint2 hdrB[64];                           // ... and their {id lo, meta}
@@ -278,7 +285,11 @@ struct Lds {
 #ifdef PG_TIMING
     u64 t_last;
     u32 t_acc[12];
+    u32 t_pad[2];
 #endif
+    // staged window: code planes (lo, hi, N).  LAST member: for NB = 3 its second chunk's words are the launch's dynamic LDS,
+    // which begins where this object ends (PG_WIN_STATIC_WORDS, pg_device.h; checked at the start of the kernel)
+    uint4 win[PG_WIN_STATIC_WORDS(NB)];
 };
 
 struct Search {
@@ -299,7 +310,7 @@ struct Search {
     long long win_wo;
     int win_lo, win_hi, wbase;
     int nsurv;           // candidates folded since the state was reset
-    u32 nsurv_total;     // ... since the read started (diagnostics: survivors of the seed filter); kept in a VGPR on purpose
+    u32 nsurv_total;     // ... since the read started (diagnostics: survivors of the seed filter)
 #ifdef PG_TIMING
     u64 *t_last;         // diagnostics build (LDS): s_memtime at the last phase boundary, cycles per phase so far
     u32 *t_acc;
@@ -1213,7 +1224,10 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
             // when the next one has work too: one LDS fill and, more importantly, one pass of fold_candidates for the handful
             // of survivors of both.  (Its own loop: kept apart from the common path below, which it slowed down.)
             int nh = 1;
-            if (PG_PAIR_CHUNKS(NB) && k + 1 <= k1 && !(use_cache && k + 1 == 0)) {
+            // (129..192-base reads: only when the launch brought the second chunk's LDS, i.e. -x >= 3 -- which is when the
+            // ranges set want_cap; cluster windows of more than a chunk at -x <= 2 go chunk by chunk)
+            const bool pair_ok = PG_PAIR_CHUNKS(NB) && (PG_WIN_DYN_BYTES(NB) == 0u || S.want_cap());
+            if (pair_ok && k + 1 <= k1 && !(use_cache && k + 1 == 0)) {
                 const int c1 = cs + (int)PG_CHUNK;
                 const int ns1 = s > c1 ? s : c1, ne1 = e < c1 + (int)PG_CHUNK ? e : c1 + (int)PG_CHUNK;
                 if (!(ns1 >= xs && ne1 <= xe)) nh = 2;
@@ -1412,13 +1426,14 @@ __device__ __forceinline__ u32 mm_of(const Search &S, int L)
 // The reference's rules for every L (lanes own L): "if (minimumNumberOfMismatches > g_maxMismatch[L]) return"
 // (searcher.cpp:167, pindel.cpp:2836), emission iff the lowest level holds exactly one position and the
 // levels up to +ADDITIONAL_MISMATCH hold no other (searcher.cpp:171-191, pindel.cpp:2849-2893), after
-// CheckMismatches (already folded into the state).  mm0 = g_maxMismatch[bps + lane] (round 0).  The
+// CheckMismatches (already folded into the state).  The
 // reduction itself is not modified.
 // qmask: the tier A quarters that belong to the state (bit q; all four unless the pass kept the rings of the nested
 // far-end ranges apart, see Rings).
 template <int NB, typename Id>
-__device__ __forceinline__ void evaluate(Search &S, const Acc<NB, Id> &A, u32 mm0, Eval<NB, Id> &E, int lane, int qmask = 15)
+__device__ __forceinline__ void evaluate(Search &S, const Acc<NB, Id> &A, Eval<NB, Id> &E, int lane, int qmask = 15)
 {
+    const u32 mm0 = mm_of<NB>(S, S.bps + lane);       // (one LDS read per evaluation; a VGPR per phase otherwise: the sixth wave's budget)
     E.n_runs = 0;
     E.max_len = 0;
     E.id_last = 0;
@@ -1613,7 +1628,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
 {
     S.win_wo = -1;
     S.win_hi = S.wbase = 0;
-    S.nsurv_total = (u32)opaque(0);
+    S.nsurv_total = 0u;
 #ifdef PG_TIMING
     S.t_base = 1;
 #endif
@@ -1623,15 +1638,15 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     S.cap_state = 255;
     S.sf = 0u;
     // the read's packed record (rid is wave-uniform)
-    uint4 r0, r1;
-    if (PG_REC_LDS(NB)) {
-        r0 = S.rec[2 * slot];
-        r1 = S.rec[2 * slot + 1];
-    } else {
-        const uint4 *rp = (const uint4 *)(B.in + rid);     // (reads over 256 bases only; as an ordinary argument: the compiler makes this a scalar load)
-        r0 = rp[0];
-        r1 = rp[1];
-    }
+    auto rec0 = [&]() -> uint4 {
+        if (PG_REC_LDS(NB)) return S.rec[2 * opaque(slot)];
+        return ((const uint4 *)(B.in + rid))[0];          // (reads over 256 bases only; as an ordinary argument: the compiler makes this a scalar load)
+    };
+    auto rec1 = [&]() -> uint4 {
+        if (PG_REC_LDS(NB)) return S.rec[2 * opaque(slot) + 1];
+        return ((const uint4 *)(B.in + rid))[1];
+    };
+    const uint4 r0 = rec0(), r1 = rec1();
     const int len = uni((int)(r1.x & 0xffffu));
     const int chr = uni((int)r0.w);
     const long long chr_wo = chr_word_off_of(ref, S, chr);
@@ -1680,15 +1695,16 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
 
     // ------------------------------------------------------------------------------- close end
     if (do_close) {
-        const int strand = uni((int)((r1.y >> 16) & 0xffu));
-        const int apos = uni((int)r0.z);
-        const int isz = uni((int)(short)(r1.x >> 16));
+        // (the record's words are read again where they are used -- from LDS up to 256-base reads -- instead of eight VGPRs of
+        // wave-uniform data living through the whole read: what the sixth wave per SIMD is paid with)
+        const int strand = uni((int)((rec1().y >> 16) & 0xffu));
+        const int apos = uni((int)rec0().z);
+        const int isz = uni((int)(short)(rec1().x >> 16));
         int close_bases = 0;
         if (len - 1 >= KA(prm, min_close) && (strand == '+' || strand == '-')) {
             S.bps = KA(prm, min_close);
             // Min_Perfect_Match_Around_BP >= the first evaluated length: CheckMismatches' length test can fail, no short-lived tier
             S.sf = S.min_perfect >= S.bps ? 4u : (S.bps + 16 <= 32 ? 2u : 0u);
-            const u32 mm0 = mm_of<NB>(S, S.bps + lane);
             // Attempt 0 (the one that succeeds for most reads) stages and filters exactly its own window.  The
             // retries share work: the window of the attempts with R = 1 contains the one with R = 0, so from
             // attempt 1 on the chunk grid is anchored at the R = 1 window, which is staged once; attempts 1 and 2
@@ -1757,10 +1773,10 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                     nsurv_eval = S.nsurv;
                     Eval<NB, Id> E;
 #if defined(PG_DUP) && PG_DUP == 5
-                    evaluate<NB, Id>(S, A, mm0, E, opaque(lane));
+                    evaluate<NB, Id>(S, A, E, opaque(lane));
                     if (E.n_runs == 0x12345) A.m1 = (u32)E.max_len;      // diagnostics: the evaluation twice
 #endif
-                    evaluate<NB, Id>(S, A, mm0, E, opaque(lane));
+                    evaluate<NB, Id>(S, A, E, opaque(lane));
                     close_max = uni(E.max_len);
                     if (uni(E.n_runs) > 0) {
                         u64 kept[NB];
@@ -1811,17 +1827,16 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
         Q.allowF_ = Q.allowB_ = true;
         Q.first_ok_ = first_base_ok<NB>(Q);
         if (Q.first_ok_) {
-            const u32 mm0 = mm_of<NB>(S, 10 + lane);
             const int chr_size = chr_size_of(ref, S, chr);
             int far_bases = 0;
             // a search window's result replaces UP_Far if its MaxLen is >= (NewUPFarIsBetter, farend_searcher.cpp:30-44)
             auto far_update = [&](int origin, const pg_window *bdw, int qmask) {
                 Eval<NB, Id> E;
 #if defined(PG_DUP) && PG_DUP == 5
-                evaluate<NB, Id>(S, A, mm0, E, opaque(lane), qmask);
+                evaluate<NB, Id>(S, A, E, opaque(lane), qmask);
                 if (E.n_runs == 0x12345) A.m1 = (u32)E.max_len;
 #endif
-                evaluate<NB, Id>(S, A, mm0, E, opaque(lane), qmask);
+                evaluate<NB, Id>(S, A, E, opaque(lane), qmask);
                 const int mx = uni(E.max_len);
                 if (mx >= far_max) {
                     far_max = mx;
@@ -1844,9 +1859,11 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
             };
             bool done = false;
             // BreakDancer / read-pair cluster of this read first (pindel.cpp:1006-1018)
-            if (KA(B, bd) && r1.z != 0u) {
-                const int nbd = uni((int)r1.z);
-                const pg_window *bd = KA(B, bd) + uni((int)r1.w);
+            const pg_window *bd_all = KA(B, bd);
+            const uint4 rbd = rec1();
+            if (bd_all && uni((int)rbd.z) != 0) {
+                const int nbd = uni((int)rbd.z);
+                const pg_window *bd = bd_all + uni((int)rbd.w);
                 A.reset();
                 S.cap_state = 255;
                 S.nsurv = 0;
@@ -2021,11 +2038,16 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
 // workgroup (which the dispatcher places on XCD blockIdx % 8) claims PG_CLAIM reads at a time from its own
 // part's counter and moves on to the next part when that one is exhausted.
 template <int NB, int NS, typename Id, int mode>
-__global__ __launch_bounds__(WAVE, PG_WAVES_PER_EU) void pg_search_kernel(PgDevRef ref, PgDevParams prm,
+__global__ __launch_bounds__(WAVE, PG_WAVES(NB, Id)) void pg_search_kernel(PgDevRef ref, PgDevParams prm,
                                                          PgDevBatch B, uint32_t max_len, uint32_t levels)
 {
     __shared__ Lds<NB, Id> lds;
     const int lane = threadIdx.x;
+    if (PG_WIN_DYN_BYTES(NB) != 0u) {
+        // the window's dynamic tail must begin where the static LDS object ends (see Lds::win)
+        extern __shared__ uint4 pg_dyn_lds[];
+        if ((const char *)pg_dyn_lds != (const char *)&lds + sizeof(lds)) __builtin_trap();
+    }
     if (PG_MM_IN_WIN(NB)) {
         for (int w = lane; w < 16 * NB + 16; w += WAVE) {
             u32 v = 0u;
@@ -2129,8 +2151,9 @@ static void launch_ns(const PgDevRef *ref, const PgDevParams *prm, const PgDevBa
         if (n_cu <= 0) n_cu = 256;
     }
     const uint32_t chunks = (batch->n_reads + PG_CLAIM - 1) / PG_CLAIM + PG_N_XCD;
-    const uint32_t want = (uint32_t)n_cu * 4u * (uint32_t)PG_WAVES_PER_EU;
+    const uint32_t want = (uint32_t)n_cu * 4u * (uint32_t)PG_WAVES(NB, Id);
     dim3 grid(chunks < want ? chunks : want), block(WAVE);
+    if (PG_WIN_DYN_BYTES(NB) != 0u && prm->max_range_index >= 3) lds_pad += PG_WIN_DYN_BYTES(NB);   // two chunks per fill need their LDS
     // close end + far end in one launch; PG_SPLIT_LAUNCH=1 runs the two seams as separate launches
     const bool fused = getenv("PG_SPLIT_LAUNCH") == nullptr;
     if (mode == PG_MODE_BOTH && fused) {
