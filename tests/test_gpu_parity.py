@@ -198,6 +198,35 @@ def test_wide_ranges_streaming_windows(engine_factory, small_ref):
     compare_result(gpu, orc, batch.n)
 
 
+@pytest.mark.parametrize("read_len", [150, 192])
+def test_chunk_pairs_in_dynamic_lds_for_129_to_192_base_reads(engine_factory, small_ref, read_len):
+    """129..192-base reads keep ONE window chunk in static LDS (6.3 KB: 24 workgroups per CU); the second chunk of a chunk
+    pair is dynamic LDS that only -x >= 3 launches request.  -x 4 (chunk pairs through the dynamic tail) and -x 2 with window
+    clusters wider than a chunk (no dynamic LDS: chunk by chunk) against the oracle."""
+    from pindel_amd.binding import WINDOW_DTYPE
+    batch = synth.make_reads(small_ref[0][1], 700, seed=70 + read_len, read_len=read_len, max_del=60000, mix=(0.6, 0.1, 0.1, 0.1, 0.1))
+    eng = engine_factory(max_range_index=4)
+    eng.load_reference(small_ref)
+    orc = run_oracle(dict(max_range_index=4), small_ref, batch)
+    assert (orc["far_cnt"] > 0).sum() > 300
+    compare_result(eng.search_batch(batch), orc, batch.n)
+    # default -x 2 with 9 000-base window clusters (four and a half chunks each)
+    eng2 = engine_factory()
+    eng2.load_reference(small_ref)
+    close = eng2.close_end_batch(batch)
+    rng = np.random.default_rng(read_len)
+    size = len(small_ref[0][1])
+    wins, offs = [], [0]
+    for i in range(batch.n):
+        if close.close_off[i + 1] > close.close_off[i] and rng.random() < 0.5:
+            c = int(np.clip(int(batch.anchor_pos[i]) + 100000 + int(rng.integers(-40000, 40000)), 110000, size - 110000))
+            wins.append((0, c - 4500, c + 4500))
+        offs.append(len(wins))
+    bd, bd_off = np.array(wins, dtype=WINDOW_DTYPE), np.array(offs, dtype=np.uint64)
+    orc2 = run_oracle({}, small_ref, batch, bd=bd, bd_off=bd_off)
+    compare_result(eng2.far_end_batch(batch, close, bd=bd, bd_off=bd_off), orc2, batch.n)
+
+
 def test_long_reads_and_wide_close_windows(engine_factory, small_ref):
     """300-450 bp reads (8 blocks of 64 bases per read) and insert size 1200: the R=1 close-end
     window (3 x InsertSize = 3600 bases) spans two LDS fills."""
