@@ -147,28 +147,6 @@ struct HostBuf {
     }
 };
 
-// A plain host array that is NOT zero-filled on allocation (std::vector::resize writes every element first: 3 ms for the
-// 32 MB of offsets of a 4 M-read batch)
-template <typename T>
-struct PodVec {
-    T *p = nullptr;
-    size_t n = 0;
-    PodVec() {}
-    PodVec(const PodVec &) = delete;
-    PodVec &operator=(const PodVec &) = delete;
-    ~PodVec() { free(p); }
-    void resize(size_t k)
-    {
-        free(p);
-        p = (T *)malloc(std::max<size_t>(k, 1) * sizeof(T));
-        n = p ? k : 0;
-    }
-    T *data() { return p; }
-    const T *data() const { return p; }
-    T &operator[](size_t i) { return p[i]; }
-    const T &operator[](size_t i) const { return p[i]; }
-};
-
 // Grow-only device arena of a ctx: the buffers of a host-path batch (pg_search_batch & co) are carved out of
 // it instead of ~25 hipMalloc / hipFree per call.
 struct DevArena {
@@ -573,13 +551,12 @@ static size_t deliver_cap(size_t n) { return getenv("PG_TEST_TINY_DELIVERY") ? n
 // Validates the batch and allocates its device buffers.  copy = true also copies the inputs
 // (synchronously); otherwise the caller streams them in (search_host).  off = read offsets rebased to 0.
 // use_arena: carve the buffers out of the ctx arena (host-path calls: the batch dies with the call).
-int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, PodVec<uint64_t> &off, pg_device_batch **out,
+int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, HostBuf<uint64_t> &off, pg_device_batch **out,
                 bool use_arena = false)
 {
     uint32_t max_len = 0, levels = 0;
     int32_t max_isz = 0;
-    off.resize((size_t)(reads ? reads->n_reads : 0) + 1);
-    if (!off.data()) return fail(ctx, PG_E_NOMEM, "host memory for the read offsets");
+    if (!off.resize((size_t)(reads ? reads->n_reads : 0) + 1)) return fail(ctx, PG_E_NOMEM, "host memory for the read offsets");
     int rc = validate_and_measure(ctx, reads, &max_len, &levels, &max_isz, off.data());
     if (rc) return rc;
     pg_device_batch *b = new pg_device_batch();
@@ -726,7 +703,9 @@ int unpack_results(pg_ctx *ctx, pg_device_batch *b)
 
 int upload_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_device_batch **out)
 {
-    PodVec<uint64_t> off;
+    // (pinned, from the cache: as a malloc'd array the runtime locks its pages for the copy and the free() of 80 MB after a
+    // 10 M-read call spent 13 ms in munmap + unpinning)
+    HostBuf<uint64_t> off;
     int rc = alloc_batch(ctx, reads, true, off, out);
     if (rc) return rc;
     if ((rc = pack_reads(ctx, *out, 0, (*out)->n))) {
@@ -1431,7 +1410,9 @@ static int search_host(pg_ctx *ctx, const pg_read_batch *reads, int mode, pg_res
     if (!ctx || !out) return PG_E_INVALID;
     *out = nullptr;
     pg_device_batch *b = nullptr;
-    PodVec<uint64_t> off;
+    // (pinned, from the cache: as a malloc'd array the runtime locks its pages for the copy and the free() of 80 MB after a
+    // 10 M-read call spent 13 ms in munmap + unpinning)
+    HostBuf<uint64_t> off;
     const double t_start = now_ms();
     int rc = alloc_batch(ctx, reads, false, off, &b, true);
     if (rc) return rc;
@@ -1664,7 +1645,10 @@ int pg_close_end_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_result **out)
 
 int pg_search_batch(pg_ctx *ctx, const pg_read_batch *reads, pg_result **out)
 {
-    return search_host(ctx, reads, PG_MODE_BOTH, out);
+    const double t0 = now_ms();
+    const int rc = search_host(ctx, reads, PG_MODE_BOTH, out);
+    if (g_host_timing) fprintf(stderr, "pg_search_batch: %.2f ms in all\n", now_ms() - t0);
+    return rc;
 }
 
 int pg_search_batch_multi(pg_ctx *const *ctxs, int32_t n_ctx, const pg_read_batch *reads, pg_result **out)
@@ -1817,7 +1801,7 @@ static int far_end_impl(pg_ctx *ctx, const pg_read_batch *reads, const uint8_t *
                         const uint16_t *close_max, const pg_windows *bd_hints, pg_result *dst)
 {
     pg_device_batch *b = nullptr;
-    PodVec<uint64_t> off0;
+    HostBuf<uint64_t> off0;
     int rc = alloc_batch(ctx, reads, true, off0, &b, true);
     if (rc) return rc;
     auto bail = [&](int code) {
