@@ -61,6 +61,17 @@ typedef unsigned int u32;
 // (profiles/r04/kernel_experiments.txt).  PgKArgs mirrors pg_search_kernel's parameter list (natural alignment = the layout
 // of the kernarg segment).
 struct PgKArgs { PgDevRef ref; PgDevParams prm; PgDevBatch B; uint32_t max_len, levels; };
+// A pointer out of the kernarg segment points to global memory.  Said so (a cast through address space 1, which the compiler
+// propagates to the uses), its loads and stores are global_* instructions; left generic they are flat_*, which count on the LDS
+// counter too -- every wait for an LDS read then also waits for the HBM loads in flight, and "request early, use late" is lost.
+template <typename T> struct KaGlobal { static __device__ __forceinline__ T of(unsigned long long v) { return (T)v; } };
+template <typename E> struct KaGlobal<E *> {
+#ifdef PG_FLAT_KARGS       // (ablation)
+    static __device__ __forceinline__ E *of(unsigned long long v) { return (E *)v; }
+#else
+    static __device__ __forceinline__ E *of(unsigned long long v) { return (E *)(__attribute__((address_space(1))) E *)v; }
+#endif
+};
 template <typename T>
 __device__ __forceinline__ T karg_load(int off)
 {
@@ -68,12 +79,23 @@ __device__ __forceinline__ T karg_load(int off)
     if (sizeof(T) == 8) {
         unsigned long long v;
         asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(k), "n"(off));
-        return (T)v;
+        return KaGlobal<T>::of(v);
     } else {
         unsigned int v;
         asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(k), "n"(off));
         return (T)v;
     }
+}
+// three consecutive 64-bit kernel arguments with one wait
+template <int OFF, typename T>
+__device__ __forceinline__ void karg_load3(T &a, T &b, T &c)
+{
+    static_assert(sizeof(T) == 8, "pointers");
+    const auto k = __builtin_amdgcn_kernarg_segment_ptr();
+    unsigned long long x, y, z;
+    asm volatile("s_load_dwordx2 %0, %3, %4\n\ts_load_dwordx2 %1, %3, %5\n\ts_load_dwordx2 %2, %3, %6\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(x), "=&s"(y), "=&s"(z) : "s"(k), "n"(OFF), "n"(OFF + 8), "n"(OFF + 16));
+    a = KaGlobal<T>::of(x); b = KaGlobal<T>::of(y); c = KaGlobal<T>::of(z);
 }
 #define KA(obj, member) karg_load<decltype(obj.member)>((int)offsetof(PgKArgs, obj.member))
 #define KAP(member) karg_load<decltype(PgDevParams::member)>((int)offsetof(PgKArgs, prm.member))
@@ -102,7 +124,11 @@ __device__ __forceinline__ T karg_load(int off)
 #define PG_CHR_TAB 24       // chromosomes whose word offset / size are kept in LDS (a read's first dependent load otherwise)
 #define PG_MM_IN_WIN(nb) ((nb) <= 4)
 
-__device__ __forceinline__ u64 ballot64(bool p) { return __ballot(p); }
+// Lane masks.  ballot64 of ONE compare is that compare's result register; of a compound condition the compiler first builds the
+// condition per lane and then turns it into a mask with a 0 / 1 select and a second compare -- so compound conditions are written
+// as scalar ANDs of single-compare ballots, and lane_bit() turns a mask back into a per-lane condition for free.
+__device__ __forceinline__ u64 ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool lane_bit(u64 m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 // DPP lane shifts (no LDS round trip).  row_shr:n moves lane i-n -> i inside each 16-lane row and
 // yields 0 where i-n leaves the row; wave_shr:1 moves lane i-1 -> i across the whole wave.
 template <int N>
@@ -178,6 +204,26 @@ __device__ __forceinline__ u32 low32_lane(int n)
     u32 m;
     asm("v_bfm_b32 %0, %1, 0" : "=v"(m) : "v"(t));
     return m | (0u - ((u32)t >> 5));
+}
+// low_bits for a per-lane n: two halves of four instructions (v_med3, v_bfm, v_bfe_i32 for the width-32 case, v_or), no compare /
+// select pairs and their wait states
+__device__ __forceinline__ u32 low32_lane4(int n)
+{
+    int t, f;
+    asm("v_med3_i32 %0, %1, 0, 32" : "=v"(t) : "v"(n));
+    u32 m;
+    asm("v_bfm_b32 %0, %1, 0" : "=v"(m) : "v"(t));
+    asm("v_bfe_i32 %0, %1, 5, 1" : "=v"(f) : "v"(t));      // -1 for t = 32
+    return m | (u32)f;
+}
+__device__ __forceinline__ u64 low_bits_lane(int n)
+{
+    return (u64)low32_lane4(n) | ((u64)low32_lane4(n - 32) << 32);
+}
+// bits of a (wave-uniform) mask below the calling lane
+__device__ __forceinline__ int count_below(u64 m)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
 }
 __device__ __forceinline__ u64 bit_range(int lo, int hi)  // bits [lo,hi), clamped to [0,64]
 {
@@ -471,19 +517,30 @@ template <int NB, typename Id>
 __device__ __forceinline__ void fold_tier_b(const Search &S, const Query<NB> &Q, Acc<NB, Id> &A, const u64 *longm, int lane)
 {
     constexpr int EW = NB;
+    {
+        u64 any = 0ull;
+#pragma unroll
+        for (int r = 0; r < NB; r++) any |= longm[r];
+        if (any == 0ull) return;                          // uniform
+    }
+    // The per-lane masks of round r and block b depend on b - r only (L - 64 b = bps + lane + 64 (r - b)): five masks serve
+    // every round.  W = the bases consumed at length L, P = those before CheckMismatches' window of min_perfect bases.
+    const int lB = opaque(lane);
+    const int n0 = S.bps + lB, p0 = n0 - S.min_perfect;
+    const u64 W0 = low_bits_lane(n0), W1 = low_bits_lane(n0 - 64);               // b = r, b = r + 1  (b < r: every base)
+    const u64 BP0 = W0 & ~low_bits_lane(p0), BP1 = W1 & ~low_bits_lane(p0 - 64), BPm = ~low_bits_lane(p0 + 64);
 #pragma unroll
     for (int r = 0; r < NB; r++) {
         const int L0 = S.bps + 64 * r;
         if (L0 > S.len - 1) break;                        // uniform
         u64 mask = longm[r];
         if (mask == 0ull) continue;                       // uniform
-        const int lB = opaque(lane);
         const int L = L0 + lB;
         u64 Mk[NB], BP[NB], QN[NB];
 #pragma unroll
         for (int b = 0; b < NB; b++) {
-            Mk[b] = low_bits(L - 64 * b);
-            BP[b] = bit_range(L - S.min_perfect - 64 * b, L - 64 * b);
+            Mk[b] = b == r ? W0 : (b == r + 1 ? W1 : ~0ull);                      // (b > r + 1 is not read)
+            BP[b] = b == r ? BP0 : (b == r + 1 ? BP1 : BPm);                      // (b < r - 1 is not read)
             QN[b] = q_nn<NB>(Q, b);
         }
         u32 m1 = A.m1, m2 = A.m2, ok = A.ok;
@@ -530,10 +587,11 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
 {
     constexpr int EW = NB;                                // 64-base blocks per tier B entry
     PG_DG(const_cast<Search &>(S), 16);
-    bool valid = lane < n;
+    // (conditions as lane masks in scalar registers: see ballot64)
+    const u64 inm = low_bits(n);                          // lanes with a candidate
     int p = 0;
     bool isB = MIXED ? false : Q.allowB();
-    if (valid) {
+    if (lane_bit(inm)) {
         u32 e = S.queue[lane];
         if (MIXED) isB = e & 1u;
         p = wbase + (int)(e >> 1);
@@ -547,12 +605,13 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
     u32 m0lo = 0u, s0lo = 0u;
 #pragma unroll
     for (int r = 0; r < NB; r++) kk[r] = 0;
-    bool need = valid;
+    u64 needm = inm;
+    const int alive = S.T > S.thr ? S.T : S.thr;
 #pragma unroll
     for (int b = 0; b < NB; b++) {
         if (64 * b >= S.len) break;                      // uniform
-        if (!__any(need)) break;                          // uniform
-        if (need) {
+        if (needm == 0ull) break;
+        if (lane_bit(needm)) {
             u64 rlo, rhi, rnn, m, s;
             int q = isB ? p - 64 * b - 63 : p + 64 * b;
             if (MIXED) fetch_lds(S.win, wbase, q, isB, rlo, rhi, rnn);
@@ -575,17 +634,18 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
         }
         // later blocks matter only while the candidate is alive (fewer than T mismatches so far) or its
         // whole-read Hamming count has not reached CheckMismatches' threshold yet
-        need = need && (cum < S.T || cum < S.thr);
+        needm &= ballot64(cum < alive);
     }
     const u32 hamok = cum >= S.thr ? 0x80000000u : 0u;
-    valid = valid && lvl0 < S.T;                           // dead before the first length: never counts
-    bool lng = valid;
-    if (S.tierA()) lng = valid && kA < S.T;
+    const u64 validm = inm & ballot64(lvl0 < S.T);         // dead before the first length: never counts
+    u64 lngm = validm;
+    if (S.tierA()) lngm &= ballot64(kA < S.T);
+    const bool lng = lane_bit(lngm);
     const Id id = make_id<Id>((u32)(p - origin), isB, region);
     const u32 lenthr = (u32)(S.min_perfect + (isB ? 0 : 1));           // FORWARD: L > m, BACKWARD: L >= m
     const u32 meta = (u32)((u64)id >> 32) | (lenthr << 24) | hamok;     // id bits 32..55 | CheckMismatches' length bound | Hamming verdict
-    const bool sht = valid && !lng;
-    const u64 shortm = ballot64(sht);
+    const u64 shortm = validm & ~lngm;
+    const bool sht = lane_bit(shortm);
     u64 longm[NB];
     // tier A lists: the short-lived candidates sit in bufA sorted by ring (one list without rings); a quarter walks its
     // list from qb in steps of qs up to qe
@@ -594,8 +654,11 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
     {
         const int qd = opaque(lane) >> 4;
         if (MIXED && R.on) {
-            const int ring = (p >= R.s0 && p < R.e0) ? 0 : ((p >= R.s1 && p < R.e1) ? 1 : 2);
-            const u64 in0 = ballot64(lane < n && ring == 0), in1 = ballot64(lane < n && ring == 1);
+            // (the rings are nested intervals around one centre: ring 0 inside ring 1)
+            const u32 w0 = R.e0 > R.s0 ? (u32)(R.e0 - R.s0) : 0u, w1 = R.e1 > R.s1 ? (u32)(R.e1 - R.s1) : 0u;
+            const u64 in0 = inm & ballot64((u32)(p - R.s0) < w0);
+            const u64 in1 = inm & ~in0 & ballot64((u32)(p - R.s1) < w1);
+            const int ring = lane_bit(in0) ? 0 : (lane_bit(in1) ? 1 : 2);
             ring_n[0] = __popcll(in0);
             ring_n[1] = __popcll(in1);
             ring_n[2] = n - ring_n[0] - ring_n[1];
@@ -603,7 +666,7 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
             const int n0 = __popcll(sh0), n1 = __popcll(sh1), n2 = nA - n0 - n1;
             if (sht) {
                 const u64 mine = ring == 0 ? sh0 : (ring == 1 ? sh1 : sh2);
-                const int rank = __popcll(mine & low_bits(lane)) + (ring == 0 ? 0 : (ring == 1 ? n0 : n0 + n1));
+                const int rank = count_below(mine) + (ring == 0 ? 0 : (ring == 1 ? n0 : n0 + n1));
                 S.bufA[rank] = make_uint4(m0lo, s0lo, (u32)id, meta);
             }
             qb = qd == 0 ? 0 : (qd == 1 ? n0 : n0 + n1 + (qd - 2));
@@ -615,26 +678,26 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
             const u64 inl[3] = { in0, in1, ~(in0 | in1) };
 #pragma unroll
             for (int x = 0; x < 3; x++) {
-                const u64 l0 = ballot64(lng) & inl[x];
+                const u64 l0 = lngm & inl[x];
                 if (lane == 0) S.ringB[x * NB] = l0;
 #pragma unroll
                 for (int r = 1; r < NB; r++) {
-                    const u64 lr = ballot64(lng && kk[r] < S.T) & inl[x];
+                    const u64 lr = lngm & ballot64(kk[r] < S.T) & inl[x];
                     if (lane == 0) S.ringB[x * NB + r] = lr;
                 }
             }
         } else {
             if (sht) {
-                const int rank = __popcll(shortm & low_bits(lane));
+                const int rank = count_below(shortm);
                 S.bufA[rank] = make_uint4(m0lo, s0lo, (u32)id, meta);
             }
             qb = qd;
             qs = 4;
             qe = nA;
             n_iter = (nA + 3) >> 2;
-            longm[0] = ballot64(lng);
+            longm[0] = lngm;
 #pragma unroll
-            for (int r = 1; r < NB; r++) longm[r] = ballot64(lng && kk[r] < S.T);
+            for (int r = 1; r < NB; r++) longm[r] = lngm & ballot64(kk[r] < S.T);
         }
     }
     if (lng) S.hdrB[lane] = make_uint2((u32)id, meta);
@@ -672,12 +735,29 @@ __device__ __forceinline__ void stage_window(const PgDevRef &ref, Search &S, lon
     PG_SYNC();
     {
         const long long g0 = wo + (long long)(lo >> 5);     // arithmetic shift = floor
-        const u32 *glo = KA(ref, lo) + g0, *ghi = KA(ref, hi) + g0, *gnn = KA(ref, nn) + g0;
-        for (int i = lane; i < nw; i += WAVE) {
-            const u32 x = __builtin_amdgcn_alignbit(glo[i + 1], glo[i], sh);
-            const u32 y = __builtin_amdgcn_alignbit(ghi[i + 1], ghi[i], sh);
-            const u32 z = __builtin_amdgcn_alignbit(gnn[i + 1], gnn[i], sh);
-            *(uint3 *)__builtin_assume_aligned(&S.win[i], 16) = make_uint3(x, y, z);        // (the fourth dword holds the table above)
+        const u32 *glo, *ghi, *gnn;
+        karg_load3<(int)offsetof(PgKArgs, ref.lo)>(glo, ghi, gnn);   // (one wait for the three plane pointers, not three)
+        glo += g0; ghi += g0; gnn += g0;
+        // two window words per lane and pass, all six loads in flight before the first is used: a 2048-base window with its
+        // overhangs is 74-78 words, and 64 + 10 in two dependent passes was two HBM round trips.  (Hand-written: the compiler
+        // sinks the second set of loads behind the first set's wait however the source is arranged.)
+        for (int i = lane; i < nw; i += 2 * WAVE) {
+            const int j = i + WAVE;
+            const bool two = j < nw;
+            const u32 oi = 4u * (u32)i, oj = 4u * (u32)(two ? j : i);
+            u64 a, b, c, d, e, f;
+            asm volatile("global_load_dwordx2 %0, %6, %8\n\tglobal_load_dwordx2 %1, %6, %9\n\tglobal_load_dwordx2 %2, %6, %10\n\t"
+                         "global_load_dwordx2 %3, %7, %8\n\tglobal_load_dwordx2 %4, %7, %9\n\tglobal_load_dwordx2 %5, %7, %10\n\t"
+                         "s_waitcnt vmcnt(0)"
+                         : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e), "=&v"(f)
+                         : "v"(oi), "v"(oj), "s"(glo), "s"(ghi), "s"(gnn) : "memory");
+            *(uint3 *)__builtin_assume_aligned(&S.win[i], 16) =
+                make_uint3(__builtin_amdgcn_alignbit((u32)(a >> 32), (u32)a, sh), __builtin_amdgcn_alignbit((u32)(b >> 32), (u32)b, sh),
+                           __builtin_amdgcn_alignbit((u32)(c >> 32), (u32)c, sh));          // (the fourth dword holds the table above)
+            if (two)
+                *(uint3 *)__builtin_assume_aligned(&S.win[j], 16) =
+                    make_uint3(__builtin_amdgcn_alignbit((u32)(d >> 32), (u32)d, sh), __builtin_amdgcn_alignbit((u32)(e >> 32), (u32)e, sh),
+                               __builtin_amdgcn_alignbit((u32)(f >> 32), (u32)f, sh));
         }
     }
     PG_SYNC();
@@ -1500,20 +1580,19 @@ __device__ __forceinline__ void evaluate(Search &S, const Acc<NB, Id> &A, Eval<N
             }
         }
         const u32 lo = m1 <= (u32)S.M ? m1 : (u32)S.M + 1u;
-        const u64 ab = ballot64(valid && lo > mmL);
-        const int first_abort = ab ? __ffsll((long long)ab) - 1 : WAVE;
-        const bool cand = valid && lane < first_abort && m1 <= (u32)S.M && m2 > m1 + (u32)S.add_mm &&
-                          (u32)L >= (u32)S.bps + m1 && ok != 0u;
+        const u64 vm = ballot64(valid);
+        const u64 ab = vm & ballot64(lo > mmL);
+        // a point at L: below the first abort, lowest level <= M and alone up to + ADDITIONAL_MISMATCH, L >= bps + level, CheckMismatches
+        const u64 cm = vm & (~ab & (ab - 1ull)) & ballot64(m1 <= (u32)S.M) & ballot64(m2 > m1 + (u32)S.add_mm) &
+                       ballot64((u32)L >= (u32)S.bps + m1) & ballot64(ok != 0u);
         // run-length encode consecutive points of the same candidate / level (a run never spans two rounds)
-        const u32 lok = cand ? lo + 1u : 0u;               // 0 = no point here
+        const u32 lok = lane_bit(cm) ? lo + 1u : 0u;       // 0 = no point here
         const u32 plok = wave_shr1(lok);                   // lane 0 gets 0
-        bool same = wave_shr1((u32)wid) == (u32)wid;
-        if (sizeof(Id) == 8) same = same && wave_shr1((u32)((u64)wid >> 32)) == (u32)((u64)wid >> 32);
-        const bool start = cand && !(plok == lok && same);
-        const u64 cm = ballot64(cand);
+        u64 samem = ballot64(plok == lok) & ballot64(wave_shr1((u32)wid) == (u32)wid);
+        if (sizeof(Id) == 8) samem &= ballot64(wave_shr1((u32)((u64)wid >> 32)) == (u32)((u64)wid >> 32));
         E.id[r] = wid;
         E.lo[r] = lo;
-        E.startm[r] = ballot64(start);
+        E.startm[r] = cm & ~samem;
         E.brkm[r] = E.startm[r] | ~cm;
         E.n_runs += __popcll(E.startm[r]);
         if (cm) {
@@ -1554,7 +1633,7 @@ __device__ __forceinline__ void emit_runs(const Search &S, bool antiF, bool anti
         if (kept[r] == 0ull) continue;                    // uniform
         if ((kept[r] >> lane) & 1ull) {
             const int L = S.bps + 64 * r + lane;
-            const u64 higher = lane == 63 ? 0ull : (E.brkm[r] & ~low_bits(lane + 1));
+            const u64 higher = E.brkm[r] & ~low_bits_lane(lane + 1);
             const int end_lane = higher ? __ffsll((long long)higher) - 2 : WAVE - 1;
             const u64 id = (u64)E.id[r];
             const u32 rel = (u32)(id & ((1ull << F::RB) - 1ull));
@@ -1568,7 +1647,7 @@ __device__ __forceinline__ void emit_runs(const Search &S, bool antiF, bool anti
             const int p = origin + (int)rel;
             const bool anti = isB ? antiB : antiF;
             // pg_run as three dwords: abs_loc_first | len_first, len_last | mismatches, flags, chr_id
-            u32 *dst = (u32 *)(out + written + __popcll(kept[r] & low_bits(lane)));
+            u32 *dst = (u32 *)(out + written + count_below(kept[r]));
             dst[0] = isB ? (u32)(p - L + 1) : (u32)(p + L - 1);
             dst[1] = (u32)L | ((u32)(S.bps + 64 * r + end_lane) << 16);
             dst[2] = E.lo[r] | ((isB ? PG_RUN_BACKWARD : 0u) << 8) | ((anti ? PG_RUN_ANTISENSE : 0u) << 8) |

@@ -1,7 +1,7 @@
 """Diagnostics: run the device-resident search of the bench workload with another build of the library
 (e.g. one compiled with -DPG_STOP=n or -DPG_DUP=n), for rocprofv3 counter passes and A/B timing.  Prints the kernel
 time, the candidates per read and a digest of the downloaded result (equal digests = bit-identical results).
-  PG_X=<n> selects -x n, PG_LEN=<bases> the read length."""
+  PG_X=<n> selects -x n, PG_LEN=<bases> the read length, PG_SORT=1 the reads in coordinate order."""
 import hashlib
 import os
 import sys
@@ -20,6 +20,14 @@ if os.environ.get("PG_X"):
 if os.environ.get("PG_LEN"):
     rkw["read_len"] = int(os.environ["PG_LEN"])
 batch = synth.make_reads(ref, n, seed=20260928, device=dev, **rkw)
+if os.environ.get("PG_SORT"):
+    # coordinate order (every window a neighbour's window: the L2-resident upper bound of any prefetching)
+    import numpy as np
+    order = np.argsort(batch.anchor_pos, kind="stable")
+    L = rkw.get("read_len", 100)
+    batch = type(batch)(seq=batch.seq.reshape(batch.n, L)[order].reshape(-1), seq_off=batch.seq_off,
+                        anchor_strand=batch.anchor_strand[order], anchor_pos=batch.anchor_pos[order],
+                        insert_size=batch.insert_size[order], chr_id=batch.chr_id[order])
 eng = binding.Engine(**kw)
 eng.load_reference([("20", ref)])
 db = eng.upload(batch)
