@@ -1287,7 +1287,7 @@ template <int NB, int NS, typename Id, bool MIXED>
 __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
                                           const Query<NB> &Q, Acc<NB, Id> &A, long long wo, int g0, int s, int e,
                                           int e_max, int xs, int xe, int origin, u32 region, int lane,
-                                          bool use_cache, u32 &cacheF, u32 &cacheB, bool &cache_valid)
+                                          u32 use_cache, u32 &cacheF, u32 &cacheB, u32 &cache_valid)
 {
     if (!Q.first_ok() || s >= e) return;
     const int k0 = (s - g0) >> PG_CHUNK_SHIFT, k1 = (e - 1 - g0) >> PG_CHUNK_SHIFT;   // floor
@@ -1397,7 +1397,7 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
         }
         const int pbase = cs + 32 * lane;
         const u32 rmask = (low32_lane(ne - pbase) & ~low32_lane(ns - pbase)) & ~(low32_lane(xe - pbase) & ~low32_lane(xs - pbase));
-        const bool cached = use_cache && k == 0 && cache_valid;
+        const bool cached = use_cache && k == 0 && cache_valid != 0u;
         u32 mF = 0u, mB = 0u;
         if (cached) {
             mF = cacheF;
@@ -1420,7 +1420,7 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
         }
         mF &= rmask;
         mB &= rmask;
-        if (use_cache && k == 0) cache_valid = true;
+        if (use_cache && k == 0) cache_valid = 1u;
         // queue slots: exclusive prefix sum of the per-lane survivor counts (a lane's F survivors first)
         const u32 cnt = (u32)(__popc(mF) + __popc(mB));
         const u32 incl = wave_scan(cnt);
@@ -1463,7 +1463,7 @@ template <int NB, int NS, typename Id>
 __device__ __forceinline__ void scan_range(const PgDevRef &ref, Search &S,
                                            const Query<NB> &Q, Acc<NB, Id> &A, long long wo, int g0, int s, int e,
                                            int e_max, int xs, int xe, int origin, u32 region, int lane,
-                                           bool use_cache, u32 &cacheF, u32 &cacheB, bool &cache_valid)
+                                           u32 use_cache, u32 &cacheF, u32 &cacheB, u32 &cache_valid)
 {
     // window coordinates come out of LDS / per-read loads: tell the compiler they are wave-uniform
     g0 = uni(g0); s = uni(s); e = uni(e); e_max = uni(e_max); xs = uni(xs); xe = uni(xe); origin = uni(origin);
@@ -1559,7 +1559,7 @@ __device__ __forceinline__ void evaluate(Search &S, const Acc<NB, Id> &A, Eval<N
         const int cap = (int)mx + S.add_mm;
         S.cap_state = cap < S.T - 1 ? cap : S.T - 1;
     }
-    bool aborted = false;
+    u32 aborted = 0u;
 #pragma unroll
     for (int r = 0; r < NB; r++) {
         E.startm[r] = 0ull;
@@ -1600,7 +1600,7 @@ __device__ __forceinline__ void evaluate(Search &S, const Acc<NB, Id> &A, Eval<N
             E.max_len = r0 + top;
             E.id_last = read_lane(wid, top);
         }
-        if (ab) aborted = true;
+        if (ab) aborted = 1u;
     }
 }
 
@@ -1679,13 +1679,13 @@ __device__ __forceinline__ void store_planes(const PgDevBatch &B, u64 v, int lan
 // Bump-allocates n runs in this workgroup's pool shard (one atomic per wave); returns the pool
 // offset.  fits = the allocation lies inside the shard (otherwise the host repeats the launch with a
 // larger pool).
-__device__ __forceinline__ u32 pool_alloc(const PgDevBatch &B, int n, int lane, bool &fits)
+__device__ __forceinline__ u32 pool_alloc(const PgDevBatch &B, int n, int lane, u32 &fits)
 {
     const u32 shard = blockIdx.x & (PG_POOL_SHARDS - 1u);
     u32 off = 0;
     if (n > 0 && lane == 0) off = atomicAdd(KA(B, pool_used) + shard * 16u, (u32)n);
     off = (u32)uni((int)off);
-    fits = (u64)off + (u64)n <= (u64)KA(B, pool_shard_cap);
+    fits = (u64)off + (u64)n <= (u64)KA(B, pool_shard_cap) ? 1u : 0u;
     return shard * KA(B, pool_shard_cap) + off;
 }
 
@@ -1703,7 +1703,7 @@ __device__ __forceinline__ bool first_base_ok(const Query<NB> &Q)
 template <int NB, int NS, typename Id, int mode>
 __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevParams &prm, const PgDevBatch &B,
                                             Search &S, u64 *qplanes, const uint32_t rid, const int slot, const int lane,
-                                            const u32 res_base, const bool res_fits)
+                                            const u32 res_base, const u32 res_fits)
 {
     S.win_wo = -1;
     S.win_hi = S.wbase = 0;
@@ -1764,13 +1764,16 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     store_planes<NB>(B, planes_of_read, lane, qplanes);
 
     PG_T(S, 0);
+#if defined(PG_STOP) && PG_STOP == 1       // diagnostics (wrong results): what do the claim and the start of a read cost?
+    if (uni(opaque(1))) return;
+#endif
     const bool do_close = (mode & PG_MODE_CLOSE) != 0, do_far = (mode & PG_MODE_FAR) != 0;
     int flipped = 0, close_max = 0, n_close = 0;
     u32 close_last = 0, close_base = 0, alg = 0u;
     u32 unused0 = 0u, unused1 = 0u;
-    bool unused_valid = false;
+    u32 unused_valid = 0u;     // (wave-uniform flags as words: a bool is a 64-bit lane mask, two scalar registers and mask arithmetic)
     Acc<NB, Id> A;
-    bool fits = true;
+    u32 fits = 1u;
 
     // ------------------------------------------------------------------------------- close end
     if (do_close) {
@@ -1795,14 +1798,14 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
             // attempts 0 and 3 -- same orientation, nested windows -- share their seed-filter masks the way attempts 1
             // and 2 do: a read without a close end costs two filter runs and one fill instead of three and two.
 #ifndef PG_NO_SHARED_CLOSE_GRID
-            const bool shared_grid = isz > 0 && 3 * isz <= (int)PG_CHUNK;
+            const u32 shared_grid = isz > 0 && 3 * isz <= (int)PG_CHUNK ? 1u : 0u;
 #else
-            const bool shared_grid = false;
+            const u32 shared_grid = 0u;
 #endif
             u32 cr0 = 0u, cr1 = 0u;                       // cached masks of the orientation in hand ...
-            bool vr = false;
+            u32 vr = 0u;
             u32 co0 = 0u, co1 = 0u;                       // ... and of the other one (swapped at attempts 1 and 3)
-            bool vo = false;
+            u32 vo = 0u;
             int ps = 0, pe = 0, nsurv_eval = 0;
             for (int att = 0; att < 4; att++) {
                 const int Rg = att >> 1;
@@ -1837,7 +1840,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                 }
                 if (att == 1 || att == 3) {               // the read turns round: the other orientation's masks
                     const u32 t0 = cr0, t1 = cr1;
-                    const bool tv = vr;
+                    const u32 tv = vr;
                     cr0 = co0; cr1 = co1; vr = vo;
                     co0 = t0; co1 = t1; vo = tv;
                 }
@@ -1845,15 +1848,25 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                 // of the R = 1 window
                 const bool own_grid = att == 0 && !shared_grid;
                 scan_range<NB, NS, Id>(ref, S, Q, A, chr_wo, own_grid ? s1 : w1s, s1, e1, own_grid ? e1 : w1e, ps, pe, w1s, 0u,
-                                   opaque(lane), att == 1 || att == 2 || shared_grid, cr0, cr1, vr);
+                                   opaque(lane), (att == 1 || att == 2 ? 1u : 0u) | shared_grid, cr0, cr1, vr);
                 ps = s1;
                 pe = e1;
                 if (S.nsurv != nsurv_eval) {
                     nsurv_eval = S.nsurv;
                     Eval<NB, Id> E;
 #if defined(PG_DUP) && PG_DUP == 5
-                    evaluate<NB, Id>(S, A, E, opaque(lane));
-                    if (E.n_runs == 0x12345) A.m1 = (u32)E.max_len;      // diagnostics: the evaluation twice
+                    {   // diagnostics: the evaluation twice (on an opaque copy of the state: two calls on the same state are merged)
+                        Acc<NB, Id> A2 = A;
+                        A2.m1 = (u32)opaque((int)A.m1); A2.a1 = (u32)opaque((int)A.a1);
+                        Eval<NB, Id> E2;
+                        evaluate<NB, Id>(S, A2, E2, opaque(lane));
+                        {
+                            u32 chk = (u32)E2.n_runs ^ (u32)E2.max_len ^ (u32)E2.id_last;
+#pragma unroll
+                            for (int r = 0; r < NB; r++) chk ^= (u32)E2.id[r] ^ E2.lo[r] ^ (u32)E2.startm[r] ^ (u32)(E2.brkm[r] >> 32);
+                            if (__builtin_amdgcn_ballot_w64(chk == 0x12345u) == ~0ull) A.m1 = chk;
+                        }
+                    }
 #endif
                     evaluate<NB, Id>(S, A, E, opaque(lane));
                     close_max = uni(E.max_len);
@@ -1866,6 +1879,9 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                             fits = res_fits;
                         } else
                             close_base = pool_alloc(B, n_close, lane, fits);
+#if defined(PG_DUP) && PG_DUP == 7
+                        if (fits) emit_runs<NB, Id>(S, true, false, chr, opaque(w1s), nullptr, E, kept, KA(B, pool) + close_base, opaque(lane));
+#endif
                         if (fits) emit_runs<NB, Id>(S, true, false, chr, w1s, nullptr, E, kept, KA(B, pool) + close_base, opaque(lane));
                         // AbsLoc of the last point (getLastAbsLocCloseEnd)
                         const u64 idl = (u64)E.id_last;
@@ -1895,6 +1911,9 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     int n_far = 0, far_max = 0;
     u32 far_base = 0;
     // "if (CurrentBase == 'N' || MaxLenCloseEnd() == 0) return;" (farend_searcher.cpp:60-66)
+#if defined(PG_STOP) && PG_STOP == 2       // diagnostics (wrong results): no far end
+    if (uni(opaque(1))) close_max = 0;
+#endif
     if (do_far && close_max > 0 && len - 1 >= 10) {
         S.bps = 10;               // farend_searcher.cpp:90
         S.sf = S.min_perfect >= 10 ? 4u : 2u;
@@ -1912,8 +1931,18 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
             auto far_update = [&](int origin, const pg_window *bdw, int qmask) {
                 Eval<NB, Id> E;
 #if defined(PG_DUP) && PG_DUP == 5
-                evaluate<NB, Id>(S, A, E, opaque(lane), qmask);
-                if (E.n_runs == 0x12345) A.m1 = (u32)E.max_len;
+                {
+                    Acc<NB, Id> A2 = A;
+                    A2.m1 = (u32)opaque((int)A.m1); A2.a1 = (u32)opaque((int)A.a1);
+                    Eval<NB, Id> E2;
+                    evaluate<NB, Id>(S, A2, E2, opaque(lane), qmask);
+                    {
+                        u32 chk = (u32)E2.n_runs ^ (u32)E2.max_len ^ (u32)E2.id_last;
+#pragma unroll
+                        for (int r = 0; r < NB; r++) chk ^= (u32)E2.id[r] ^ E2.lo[r] ^ (u32)E2.startm[r] ^ (u32)(E2.brkm[r] >> 32);
+                        if (__builtin_amdgcn_ballot_w64(chk == 0x12345u) == ~0ull) A.m1 = chk;
+                    }
+                }
 #endif
                 evaluate<NB, Id>(S, A, E, opaque(lane), qmask);
                 const int mx = uni(E.max_len);
@@ -1926,12 +1955,15 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                         (void)count_kept<NB, Id>(E, false, kept);
                         if (n_far <= (int)PG_RES_FAR) {          // (a later range's result overwrites an earlier one's slots)
                             far_base = res_base + PG_RES_CLOSE;
-                            fits = fits && res_fits;
+                            fits &= res_fits;
                         } else {
-                            bool f2 = true;
+                            u32 f2 = 1u;
                             far_base = pool_alloc(B, n_far, lane, f2);
-                            fits = fits && f2;
+                            fits &= f2;
                         }
+#if defined(PG_DUP) && PG_DUP == 7
+                        if (fits) emit_runs<NB, Id>(S, false, true, chr, opaque(origin), bdw, E, kept, KA(B, pool) + far_base, opaque(lane));
+#endif
                         if (fits) emit_runs<NB, Id>(S, false, true, chr, origin, bdw, E, kept, KA(B, pool) + far_base, opaque(lane));
                     }
                 }
@@ -1973,7 +2005,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                 if ((u32)center + (u32)maxspan + k_spacer < (u32)chr_size) emax = center + maxspan;
                 else emax = chr_size - (int)k_spacer;
                 u32 cacheF = 0u, cacheB = 0u;                    // seed-filter masks of the innermost chunk
-                bool cache_valid = false;
+                u32 cache_valid = 0u;
                 int ps = 0, pe = 0, nsurv_eval = 0;
                 A.reset();
                 S.cap_state = 255;
@@ -2007,9 +2039,17 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                             stage_window<NB>(ref, S, chr_wo, wb, se + 64 * NB, lane);
                         u32 mF = 0u, mB = 0u;
                         seed_filter<NB, NS, true>(S, Q, false, false, lane, mF, mB);
+#if defined(PG_DUP) && PG_DUP == 8
+                        {
+                            u32 dF, dB;
+                            seed_filter<NB, NS, true>(S, Q, false, false, opaque(lane), dF, dB);
+                            mF &= dF | (u32)opaque(0);
+                            mB &= dB | (u32)opaque(0);
+                        }
+#endif
                         cacheF = mF;
                         cacheB = mB;
-                        cache_valid = true;
+                        cache_valid = 1u;
                         const int pbase = g0 + 32 * lane;
                         const u32 rmask = low32_lane(re[R] - pbase) & ~low32_lane(rs[R] - pbase);
                         mF &= rmask;
@@ -2041,6 +2081,15 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                                 PG_SYNC();
                                 int ring_n[3];
                                 PG_T(S, 7);
+#if defined(PG_DUP) && PG_DUP == 9
+                                {
+                                    Acc<NB, Id> A2 = A;
+                                    int rn2[3];
+                                    fold_candidates<NB, Id, true>(S, Q, A2, wb, origin, 0u, total, opaque(lane),
+                                                                  Rings{ true, rs[0], re[0], rs[1], re[1] }, rn2);
+                                    if (A2.m1 == 0x12345u) A.m1 = A2.m2;
+                                }
+#endif
                                 fold_candidates<NB, Id, true>(S, Q, A, wb, origin, 0u, total, lane,
                                                               Rings{ true, rs[0], re[0], rs[1], re[1] }, ring_n);
                                 PG_T(S, 8);
@@ -2049,6 +2098,13 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                                         u64 longm[NB];
 #pragma unroll
                                         for (int k = 0; k < NB; k++) longm[k] = read_lane(S.ringB[r * NB + k], 0);
+#if defined(PG_DUP) && PG_DUP == 6
+                                        {
+                                            Acc<NB, Id> A2 = A;
+                                            fold_tier_b<NB, Id>(S, Q, A2, longm, opaque(lane));
+                                            if (A2.m1 == 0x12345u) A.m1 = A2.m2;
+                                        }
+#endif
                                         fold_tier_b<NB, Id>(S, Q, A, longm, lane);
                                         far_update(origin, nullptr, r == 0 ? 1 : (r == 1 ? 3 : 15));
                                     }
@@ -2199,7 +2255,7 @@ __global__ __launch_bounds__(WAVE, PG_WAVES(NB, Id)) void pg_search_kernel(PgDev
             const u32 shard = blockIdx.x & (PG_POOL_SHARDS - 1u);
             if (lane == 0) res = atomicAdd(KA(B, pool_used) + shard * 16u, claim * PG_RESERVE);
             res = (u32)uni((int)res);
-            const bool res_fits = (u64)res + (u64)(claim * PG_RESERVE) <= (u64)KA(B, pool_shard_cap);
+            const u32 res_fits = (u64)res + (u64)(claim * PG_RESERVE) <= (u64)KA(B, pool_shard_cap) ? 1u : 0u;
             res += shard * KA(B, pool_shard_cap);
             for (uint32_t i = first; i < end; i++)
                 search_read<NB, NS, Id, mode>(ref, prm, B, S, qplanes, KA(B, first_read) + i, (int)(i - first), opaque(lane),
