@@ -99,6 +99,17 @@ __device__ __forceinline__ void karg_load3(T &a, T &b, T &c)
 }
 #define KA(obj, member) karg_load<decltype(obj.member)>((int)offsetof(PgKArgs, obj.member))
 #define KAP(member) karg_load<decltype(PgDevParams::member)>((int)offsetof(PgKArgs, prm.member))
+// A search parameter inside search_read<..., DEF>: out of the kernarg segment, or -- in the kernels built for Pindel's default parameter
+// set (-x 2 -a 1 -m 3 -H 8, spacer 100000: pg_default_params) -- a constant.  With the five of them known the compiler folds the close
+// end's masks and tier switches, unrolls the range schedule and drops the wide-window bookkeeping: SGPR spills 69 -> 20,
+// 1251 -> 1130 scalar and 1647 -> 1563 vector instructions per read, configs[2] -6.9 %, 150 bp -7.6 % (results identical).  Any other
+// parameter set runs the generic kernels.
+#define PRM(member, dflt) (DEF ? (decltype(PgDevParams::member))(dflt) : KA(prm, member))
+#define PG_DEF_MAX_RANGE_INDEX 2
+#define PG_DEF_ADD_MM 1
+#define PG_DEF_MIN_PERFECT 3
+#define PG_DEF_MIN_CLOSE 8
+#define PG_DEF_SPACER 100000u
 
 #define WAVE 64
 #ifndef PG_N_XCD
@@ -1700,7 +1711,7 @@ __device__ __forceinline__ bool first_base_ok(const Query<NB> &Q)
 //   close end   attempts (R0,seq) (R0,RC) (R1,RC) (R1,seq) until one yields points    pindel.cpp:2537-2575
 //   far end     BreakDancer cluster (if the read has one), then the ranges
 //               r = 1 .. MaxRangeIndex+1 until goodFarEndFound                          pindel.cpp:1006-1070
-template <int NB, int NS, typename Id, int mode>
+template <int NB, int NS, typename Id, int mode, bool DEF>
 __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevParams &prm, const PgDevBatch &B,
                                             Search &S, u64 *qplanes, const uint32_t rid, const int slot, const int lane,
                                             const u32 res_base, const u32 res_fits)
@@ -1731,9 +1742,9 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     const long long chr_wo = chr_word_off_of(ref, S, chr);
     S.len = len;
     S.M = uni((int)(r1.y >> 24));
-    S.add_mm = KA(prm, add_mm);
-    S.min_perfect = KA(prm, min_perfect);
-    S.T = S.M + S.add_mm + 1;
+    S.add_mm = PRM(add_mm, PG_DEF_ADD_MM);
+    S.min_perfect = PRM(min_perfect, PG_DEF_MIN_PERFECT);
+    S.T = uni(S.M + S.add_mm + 1);
     S.thr = uni((int)(r1.y & 0xffffu));
     // g_maxMismatch at the two filter depths (<= M: the breakpoints from index M on lie beyond the read)
     {
@@ -1746,7 +1757,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     const u64 planes_of_read = request_planes<NB>(B, rid, lane);
     if (mode & PG_MODE_CLOSE) {
         const int strand0 = uni((int)((r1.y >> 16) & 0xffu));
-        if (len - 1 >= KA(prm, min_close) && (strand0 == '+' || strand0 == '-')) {
+        if (len - 1 >= PRM(min_close, PG_DEF_MIN_CLOSE) && (strand0 == '+' || strand0 == '-')) {
             const int apos0 = uni((int)r0.z), isz0 = uni((int)(short)(r1.x >> 16));
             int s1 = strand0 == '+' ? apos0 : apos0 - isz0, e1 = s1 + isz0;           // attempt 0: R = 0
 #ifndef PG_NO_SHARED_CLOSE_GRID
@@ -1783,8 +1794,8 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
         const int apos = uni((int)rec0().z);
         const int isz = uni((int)(short)(rec1().x >> 16));
         int close_bases = 0;
-        if (len - 1 >= KA(prm, min_close) && (strand == '+' || strand == '-')) {
-            S.bps = KA(prm, min_close);
+        if (len - 1 >= PRM(min_close, PG_DEF_MIN_CLOSE) && (strand == '+' || strand == '-')) {
+            S.bps = PRM(min_close, PG_DEF_MIN_CLOSE);
             // Min_Perfect_Match_Around_BP >= the first evaluated length: CheckMismatches' length test can fail, no short-lived tier
             S.sf = S.min_perfect >= S.bps ? 4u : (S.bps + 16 <= 32 ? 2u : 0u);
             // Attempt 0 (the one that succeeds for most reads) stages and filters exactly its own window.  The
@@ -1996,8 +2007,8 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                 // did not cover are scanned.  Chunk grid: the innermost 2048 positions are one chunk (one LDS
                 // fill and one seed-filter pass serve the ranges up to 1024).
                 const int center = (int)close_last;
-                const int k_mri = KA(prm, max_range_index);
-                const u32 k_spacer = KA(prm, spacer);
+                const int k_mri = PRM(max_range_index, PG_DEF_MAX_RANGE_INDEX);
+                const u32 k_spacer = PRM(spacer, PG_DEF_SPACER);
                 const int maxspan = 64 << (2 * k_mri);
                 const int origin = center - maxspan;
                 const int g0 = center - (int)PG_CHUNK / 2;
@@ -2172,7 +2183,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
 // Persistent 64-thread workgroups.  The reads of the launch are split into PG_N_XCD contiguous parts; a
 // workgroup (which the dispatcher places on XCD blockIdx % 8) claims PG_CLAIM reads at a time from its own
 // part's counter and moves on to the next part when that one is exhausted.
-template <int NB, int NS, typename Id, int mode>
+template <int NB, int NS, typename Id, int mode, bool DEF>
 __global__ __launch_bounds__(WAVE, PG_WAVES(NB, Id)) void pg_search_kernel(PgDevRef ref, PgDevParams prm,
                                                          PgDevBatch B, uint32_t max_len, uint32_t levels)
 {
@@ -2258,7 +2269,7 @@ __global__ __launch_bounds__(WAVE, PG_WAVES(NB, Id)) void pg_search_kernel(PgDev
             const u32 res_fits = (u64)res + (u64)(claim * PG_RESERVE) <= (u64)KA(B, pool_shard_cap) ? 1u : 0u;
             res += shard * KA(B, pool_shard_cap);
             for (uint32_t i = first; i < end; i++)
-                search_read<NB, NS, Id, mode>(ref, prm, B, S, qplanes, KA(B, first_read) + i, (int)(i - first), opaque(lane),
+                search_read<NB, NS, Id, mode, DEF>(ref, prm, B, S, qplanes, KA(B, first_read) + i, (int)(i - first), opaque(lane),
                                           res + (i - first) * PG_RESERVE, res_fits);
             PG_T(S, 10);
         }
@@ -2272,6 +2283,31 @@ __global__ __launch_bounds__(WAVE, PG_WAVES(NB, Id)) void pg_search_kernel(PgDev
 }
 
 // ---------------------------------------------------------------------------------
+template <int NB, int NS, typename Id, bool DEF>
+static void launch_modes(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch *batch, int mode,
+                         uint32_t max_len, uint32_t levels, hipStream_t st, unsigned lds_pad, dim3 grid, dim3 block)
+{
+    // close end + far end in one launch; PG_SPLIT_LAUNCH=1 runs the two seams as separate launches
+    const bool fused = getenv("PG_SPLIT_LAUNCH") == nullptr;
+    if (mode == PG_MODE_BOTH && fused) {
+        hipLaunchKernelGGL((pg_search_kernel<NB, NS, Id, PG_MODE_BOTH, DEF>), grid, block, lds_pad, st,
+                           *ref, *prm, *batch, max_len, levels);
+        return;
+    }
+#ifdef PG_ONLY_BENCH
+    abort();          // experiment builds (scripts/build_variant.sh -DPG_ONLY_BENCH): only the fused kernel exists
+#else
+    if (mode & PG_MODE_CLOSE)
+        hipLaunchKernelGGL((pg_search_kernel<NB, NS, Id, PG_MODE_CLOSE, DEF>), grid, block, lds_pad, st,
+                           *ref, *prm, *batch, max_len, levels);
+    if (mode & PG_MODE_FAR) {
+        if (mode & PG_MODE_CLOSE) (void)hipMemsetAsync(batch->work_ctr, 0, PG_N_XCD * 16u * sizeof(uint32_t), st);
+        hipLaunchKernelGGL((pg_search_kernel<NB, NS, Id, PG_MODE_FAR, DEF>), grid, block, lds_pad, st,
+                           *ref, *prm, *batch, max_len, levels);
+    }
+#endif
+}
+
 template <int NB, int NS, typename Id>
 static void launch_ns(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch *batch, int mode,
                    uint32_t max_len, uint32_t levels, hipStream_t st, unsigned lds_pad)
@@ -2289,25 +2325,18 @@ static void launch_ns(const PgDevRef *ref, const PgDevParams *prm, const PgDevBa
     const uint32_t want = (uint32_t)n_cu * 4u * (uint32_t)PG_WAVES(NB, Id);
     dim3 grid(chunks < want ? chunks : want), block(WAVE);
     if (PG_WIN_DYN_BYTES(NB) != 0u && prm->max_range_index >= 3) lds_pad += PG_WIN_DYN_BYTES(NB);   // two chunks per fill need their LDS
-    // close end + far end in one launch; PG_SPLIT_LAUNCH=1 runs the two seams as separate launches
-    const bool fused = getenv("PG_SPLIT_LAUNCH") == nullptr;
-    if (mode == PG_MODE_BOTH && fused) {
-        hipLaunchKernelGGL((pg_search_kernel<NB, NS, Id, PG_MODE_BOTH>), grid, block, lds_pad, st,
-                           *ref, *prm, *batch, max_len, levels);
-        return;
+    // Pindel's default parameters have kernels of their own (see PRM): up to 16 mismatch levels, 32-bit candidate ids
+    constexpr bool HAS_DEF = NS <= 4 && sizeof(Id) == 4;
+    const bool def = HAS_DEF && getenv("PG_GENERIC_KERNELS") == nullptr && prm->max_range_index == PG_DEF_MAX_RANGE_INDEX &&
+                     prm->add_mm == PG_DEF_ADD_MM && prm->min_perfect == PG_DEF_MIN_PERFECT && prm->min_close == PG_DEF_MIN_CLOSE &&
+                     prm->spacer == PG_DEF_SPACER;
+    if constexpr (HAS_DEF) {
+        if (def) {
+            launch_modes<NB, NS, Id, true>(ref, prm, batch, mode, max_len, levels, st, lds_pad, grid, block);
+            return;
+        }
     }
-#ifdef PG_ONLY_BENCH
-    abort();          // experiment builds (scripts/build_variant.sh -DPG_ONLY_BENCH): only the fused kernel exists
-#else
-    if (mode & PG_MODE_CLOSE)
-        hipLaunchKernelGGL((pg_search_kernel<NB, NS, Id, PG_MODE_CLOSE>), grid, block, lds_pad, st,
-                           *ref, *prm, *batch, max_len, levels);
-    if (mode & PG_MODE_FAR) {
-        if (mode & PG_MODE_CLOSE) (void)hipMemsetAsync(batch->work_ctr, 0, PG_N_XCD * 16u * sizeof(uint32_t), st);
-        hipLaunchKernelGGL((pg_search_kernel<NB, NS, Id, PG_MODE_FAR>), grid, block, lds_pad, st,
-                           *ref, *prm, *batch, max_len, levels);
-    }
-#endif
+    launch_modes<NB, NS, Id, false>(ref, prm, batch, mode, max_len, levels, st, lds_pad, grid, block);
 }
 
 // the seed filter's counter width follows the batch's largest number of mismatch levels (validate_and_measure)
@@ -2607,16 +2636,16 @@ extern "C" int pg_debug_occupancy(uint32_t max_len, uint32_t levels, int small_i
     hipError_t e1, e2;
 #ifdef PG_ONLY_BENCH
     (void)small_ids;
-    e1 = e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(far_blocks, pg_search_kernel<2, 3, u32, PG_MODE_BOTH>, WAVE, 0);
+    e1 = e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(far_blocks, pg_search_kernel<2, 3, u32, PG_MODE_BOTH, false>, WAVE, 0);
     *close_blocks = *far_blocks;
     return (int)e1;
 #endif
     if (small_ids) {
-        e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(close_blocks, pg_search_kernel<2, 3, u32, PG_MODE_CLOSE>, WAVE, 0);
-        e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(far_blocks, pg_search_kernel<2, 3, u32, PG_MODE_BOTH>, WAVE, 0);
+        e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(close_blocks, pg_search_kernel<2, 3, u32, PG_MODE_CLOSE, false>, WAVE, 0);
+        e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(far_blocks, pg_search_kernel<2, 3, u32, PG_MODE_BOTH, false>, WAVE, 0);
     } else {
-        e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(close_blocks, pg_search_kernel<2, 3, u64, PG_MODE_CLOSE>, WAVE, 0);
-        e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(far_blocks, pg_search_kernel<2, 3, u64, PG_MODE_BOTH>, WAVE, 0);
+        e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(close_blocks, pg_search_kernel<2, 3, u64, PG_MODE_CLOSE, false>, WAVE, 0);
+        e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(far_blocks, pg_search_kernel<2, 3, u64, PG_MODE_BOTH, false>, WAVE, 0);
     }
     return (int)e1 | (int)e2;
 }

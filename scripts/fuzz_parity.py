@@ -76,6 +76,8 @@ def one_iteration(seed, n_reads=1500, verbose=True):
     chroms = [("f", ref)]
     wide = seed >= 200000            # seeds from 200000 on draw from wider ranges (-x up to 6, more insert sizes);
     kw = random_params(rng, wide)    # lower seeds keep their original streams (61026 is a regression seed)
+    if 300000 <= seed < 400000:      # seeds 300000-399999: Pindel's default search parameters (the kernels compiled with them as
+        kw = {k: v for k, v in kw.items() if k in ("max_mismatch_rate", "seq_error_rate", "sensitivity")}   # constants), the rest random
     lens = sorted(set(int(x) for x in rng.choice([24, 36, 50, 64, 76, 100, 101, 128, 129, 150, 192, 200, 250, 300],
                                                  size=int(rng.integers(1, 4)))))
     isz = int(rng.choice([120, 200, 350, 480, 500, 700, 800, 1200] if wide else [200, 350, 500, 800]))

@@ -30,3 +30,11 @@ def test_fuzz_block(block):
 def test_fuzz_block_wide(block):
     for seed in range(200400 + 10 * block, 200410 + 10 * block):
         assert one_iteration(seed, verbose=False), seed
+
+
+# ... and 30 seeds with Pindel's default search parameters (seeds 300000-399999): the kernels that hold the five parameters as
+# compile-time constants, on the same nasty references, read-length mixes, window clusters and error-rate tables
+@pytest.mark.parametrize("block", range(3))
+def test_fuzz_block_default_parameters(block):
+    for seed in range(300000 + 10 * block, 300010 + 10 * block):
+        assert one_iteration(seed, verbose=False), seed

@@ -297,6 +297,35 @@ def test_wide_cells_and_split_launches(engine_factory, small_ref, monkeypatch):
     compare_result(eng.search_batch(batch), orc, batch.n)
 
 
+@pytest.mark.parametrize("read_len", [100, 150, 250])
+def test_generic_kernels_on_the_default_parameters(engine_factory, small_ref, monkeypatch, read_len):
+    """Pindel's default parameter set runs kernels compiled with the five parameters as constants (pg_kernels.hip: PRM);
+    PG_GENERIC_KERNELS=1 sends the same launch through the kernels every other parameter set uses.  Both equal the oracle,
+    fused and as the two seams."""
+    eng = engine_factory()
+    eng.load_reference(small_ref)
+    batch = synth.make_reads(small_ref[0][1], 3000, seed=150 + read_len, read_len=read_len)
+    orc = run_oracle({}, small_ref, batch)
+    for generic in (False, True):
+        if generic:
+            monkeypatch.setenv("PG_GENERIC_KERNELS", "1")
+        compare_result(eng.search_batch(batch), orc, batch.n)
+        close = eng.close_end_batch(batch)
+        compare_result(close, orc, batch.n, check_far=False)
+        compare_result(eng.far_end_batch(batch, close), orc, batch.n)
+
+
+@pytest.mark.parametrize("change", [dict(max_range_index=1), dict(max_range_index=3), dict(additional_mismatch=2),
+                                    dict(min_perfect_match=4), dict(min_close=9), dict(min_close=7)])
+def test_one_parameter_off_the_defaults(engine_factory, small_ref, change):
+    """Each of the parameters the default-parameter kernels hold as constants, changed alone: the launch must take the
+    generic kernels (a constant left in would show here)."""
+    eng = engine_factory(**change)
+    eng.load_reference(small_ref)
+    batch = synth.make_reads(small_ref[0][1], 2500, seed=170 + sum(change.values()))
+    compare_result(eng.search_batch(batch), run_oracle(change, small_ref, batch), batch.n)
+
+
 def test_many_runs_per_search(engine_factory, small_ref):
     """Noisy reads (3 % errors) break the point lists into many runs: close-end lists where CleanUniquePoints
     has several runs to choose from, far-end lists of 3+ runs, runs in both 64-length rounds of a search."""
