@@ -142,7 +142,7 @@ struct PgSoaOut {
 // member of the kernel's one static LDS object), so the window stays one array with compile-time addresses.
 // (LDS is handed out in granules of 1280 bytes on gfx950: 24 workgroups per CU need <= 6400 bytes each -- hence + 4 words of
 // slack here, not + 6: a fill writes 78 words and a candidate reads up to word 76 of a one-chunk window)
-#define PG_WIN_STATIC_WORDS(nb) ((nb) == 3 ? (PG_CHUNK + 2u * (64u * (nb))) / 32u + 4u : PG_WIN_WORDS(nb))
+#define PG_WIN_STATIC_WORDS(nb) ((nb) == 3 || (nb) == 2 ? (PG_CHUNK + 2u * (64u * (nb))) / 32u + 4u : PG_WIN_WORDS(nb))
 #define PG_WIN_DYN_BYTES(nb) ((PG_WIN_WORDS(nb) - PG_WIN_STATIC_WORDS(nb)) * 16u)
 
 #ifdef __cplusplus

@@ -124,7 +124,7 @@ __device__ __forceinline__ void karg_load3(T &a, T &b, T &c)
 #ifdef PG_WAVES_PER_EU
 #define PG_WAVES(NB, Id) PG_WAVES_PER_EU
 #else
-#define PG_WAVES(NB, Id) (sizeof(Lds<NB, Id>) <= 6400 ? 6 : 5)
+#define PG_WAVES(NB, Id) (sizeof(Lds<NB, Id>) <= 5120 ? 7 : (sizeof(Lds<NB, Id>) <= 6400 ? 6 : 5))
 #endif
 #ifndef PG_CLAIM
 #define PG_CLAIM 8u         // reads claimed per atomic
@@ -337,7 +337,8 @@ struct Lds {
     // lives in the fourth dword of the window entries (four lengths per dword; the fills write three dwords): the LDS
     // it would take costs a resident workgroup per CU at NB = 3 and 4.
     uint8_t mm_tab[PG_MM_IN_WIN(NB) ? 4 : 64 * NB + 64];
-    u32 chr_tab[3 * PG_CHR_TAB];              // word offset (lo, hi) and size of the first PG_CHR_TAB chromosomes
+    uint2 chr_tab[PG_CHR_TAB];                // word offset and size of the first PG_CHR_TAB chromosomes (size 0: not in the table --
+                                              // its word offset does not fit 32 bits)
     uint4 rec[PG_REC_LDS(NB) ? 2 * PG_CLAIM : 0];   // the packed records of the claimed reads (one coalesced load per claim)
 #ifdef PG_TIMING
     u64 t_last;
@@ -359,7 +360,7 @@ struct Search {
     u64 *ringB;
     void *accB;
     const uint8_t *mm_tab;
-    const u32 *chr_tab;
+    const uint2 *chr_tab;
     int mm_j[2];         // g_maxMismatch[J] for the two filter depths J of this read (plain, wide): once per read
     const uint4 *rec;    // PG_REC_LDS: the claim's records in LDS    // LDS copy of PgDevParams::mm_bp
     // what the LDS window currently holds: bases [win_lo, win_hi) of the chromosome whose AbsLoc 0 is
@@ -446,14 +447,19 @@ __device__ __forceinline__ int max_mismatch_at(const u32 *mm_bp, int L)
 // word offset / size of a chromosome: from LDS for the first PG_CHR_TAB ones (c is wave-uniform)
 __device__ __forceinline__ long long chr_word_off_of(const PgDevRef &ref, const Search &S, int c)
 {
-    if (c < PG_CHR_TAB)
-        return (long long)((u64)(u32)uni((int)S.chr_tab[3 * c]) | ((u64)(u32)uni((int)S.chr_tab[3 * c + 1]) << 32));
+    if (c < PG_CHR_TAB) {
+        const uint2 e = S.chr_tab[c];
+        if (uni((int)e.y) != 0) return (long long)(u64)(u32)uni((int)e.x);
+    }
     const u64 w = KA(ref, chr_word_off)[c];
     return (long long)((u64)(u32)uni((int)(u32)w) | ((u64)(u32)uni((int)(u32)(w >> 32)) << 32));
 }
 __device__ __forceinline__ int chr_size_of(const PgDevRef &ref, const Search &S, int c)
 {
-    if (c < PG_CHR_TAB) return uni((int)S.chr_tab[3 * c + 2]);
+    if (c < PG_CHR_TAB) {
+        const int sz = uni((int)S.chr_tab[c].y);
+        if (sz != 0) return sz;
+    }
     return uni((int)KA(ref, chr_size)[c]);
 }
 
@@ -2205,9 +2211,7 @@ __global__ __launch_bounds__(WAVE, PG_WAVES(NB, Id)) void pg_search_kernel(PgDev
         for (int L = lane; L < 64 * NB + 64; L += WAVE) lds.mm_tab[L] = (uint8_t)max_mismatch_at(prm.mm_bp, L);
     if (lane < PG_CHR_TAB && lane < ref.n_chr) {
         const u64 wo = ref.chr_word_off[lane];
-        lds.chr_tab[3 * lane] = (u32)wo;
-        lds.chr_tab[3 * lane + 1] = (u32)(wo >> 32);
-        lds.chr_tab[3 * lane + 2] = ref.chr_size[lane];
+        lds.chr_tab[lane] = make_uint2((u32)wo, (wo >> 32) == 0ull ? ref.chr_size[lane] : 0u);
     }
     PG_SYNC();
     Search S;

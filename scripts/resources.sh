@@ -17,9 +17,10 @@ for blk in t.split("\n  - ")[1:]:
         continue
     g = lambda k: (re.search(k + r":\s+(\d+)", blk) or [None, "?"])[1]
     name = m.group(1)
-    d = re.match(r"_Z16pg_search_kernelILi(\d+)ELi(\d+)E([jy])Li(\d)E", name)
+    d = re.match(r"_Z16pg_search_kernelILi(\d+)ELi(\d+)E([jy])Li(\d)ELb([01])E", name)
     if d:
-        name = f"pg_search_kernel<NB={d.group(1)}, NS={d.group(2)}, {'u32' if d.group(3) == 'j' else 'u64'}, {['', 'CLOSE', 'FAR', 'BOTH'][int(d.group(4))]}>"
+        name = (f"pg_search_kernel<NB={d.group(1)}, NS={d.group(2)}, {'u32' if d.group(3) == 'j' else 'u64'}, "
+                f"{['', 'CLOSE', 'FAR', 'BOTH'][int(d.group(4))]}, {'defaults' if d.group(5) == '1' else 'generic'}>")
     else:
         k = re.match(r"_Z(\d+)", name)
         if k:
@@ -27,10 +28,10 @@ for blk in t.split("\n  - ")[1:]:
             name = name[2 + len(k.group(1)):][:n] + name[2 + len(k.group(1)) + n:][:12]
     rows.append((name, g(r"\.vgpr_count"), g(r"\.sgpr_count"), g(r"\.sgpr_spill_count"), g(r"\.vgpr_spill_count"),
                  g(r"\.private_segment_fixed_size"), g(r"\.group_segment_fixed_size")))
-print(f"{'kernel':64s} {'vgpr':>5s} {'sgpr':>5s} {'sgpr_spill':>10s} {'vgpr_spill':>10s} {'scratch B':>9s} {'LDS B':>6s}")
+print(f"{'kernel':72s} {'vgpr':>5s} {'sgpr':>5s} {'sgpr_spill':>10s} {'vgpr_spill':>10s} {'scratch B':>9s} {'LDS B':>6s}")
 for r in sorted(rows):
     if "hipcub" in r[0] or "rocprim" in r[0]:
         continue
-    print(f"{r[0]:64s} {r[1]:>5s} {r[2]:>5s} {r[3]:>10s} {r[4]:>10s} {r[5]:>9s} {r[6]:>6s}")
+    print(f"{r[0]:72s} {r[1]:>5s} {r[2]:>5s} {r[3]:>10s} {r[4]:>10s} {r[5]:>9s} {r[6]:>6s}")
 PY
 rm -rf "$tmp"
