@@ -556,7 +556,10 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, HostBuf<uint
 {
     uint32_t max_len = 0, levels = 0;
     int32_t max_isz = 0;
-    if (!off.resize((size_t)(reads ? reads->n_reads : 0) + 1)) return fail(ctx, PG_E_NOMEM, "host memory for the read offsets");
+    // (room behind the offsets for the four small per-read arrays in the arena's layout: search_host sends a one-chunk batch's
+    // small inputs with ONE copy from this pinned block)
+    const size_t n_in = reads ? reads->n_reads : 0;
+    if (!off.resize(n_in + 1 + (use_arena ? (n_in * 11 + 6 * 512) / 8 + 8 : 0))) return fail(ctx, PG_E_NOMEM, "host memory for the read offsets");
     int rc = validate_and_measure(ctx, reads, &max_len, &levels, &max_isz, off.data());
     if (rc) return rc;
     pg_device_batch *b = new pg_device_batch();
@@ -1526,13 +1529,31 @@ static int search_host(pg_ctx *ctx, const pg_read_batch *reads, int mode, pg_res
         for (uint32_t k = 0; k < n_chunks && e == hipSuccess && rc == PG_OK; k++) {
             const uint32_t lo = bounds[k], hi = bounds[k + 1], cn = hi - lo;
             hipStream_t cs = ctx->copy_stream;
-            if (off[hi] > off[lo])
+            // A one-chunk batch (Pindel's own 50 000-read flush): the five small arrays lie one after the other in the arena
+            // (alloc_batch), so they go as ONE copy from the pinned block that already holds the offsets -- queued before the
+            // bases, whose copy from pageable memory blocks the call.  (Five copies cost 60 us of calls and 40 us of serial DMA.)
+            const char *d0 = (const char *)b->seq_off;
+            const size_t o_str = (size_t)((const char *)b->strand - d0), o_pos = (size_t)((const char *)b->pos - d0),
+                         o_isz = (size_t)((const char *)b->isz - d0), o_chr = (size_t)((const char *)b->chr - d0), span = o_chr + (size_t)n * 4;
+            const bool one_copy = single && b->in_arena && (const char *)b->strand > d0 && o_str < o_pos && o_pos < o_isz && o_isz < o_chr &&
+                                  span <= off.cap_bytes && !getenv("PG_NO_SINGLE_BLOCK");
+            if (one_copy) {
+                char *h = (char *)off.data();
+                memcpy(h + o_str, reads->anchor_strand, n);
+                memcpy(h + o_pos, reads->anchor_pos, (size_t)n * 4);
+                memcpy(h + o_isz, reads->insert_size, (size_t)n * 2);
+                memcpy(h + o_chr, reads->chr_id, (size_t)n * 4);
+                e = hipMemcpyAsync(b->seq_off, h, span, hipMemcpyHostToDevice, cs);
+            }
+            if (e == hipSuccess && off[hi] > off[lo])
                 e = hipMemcpyAsync(b->seq + off[lo], reads->seq + base0 + off[lo], (size_t)(off[hi] - off[lo]), hipMemcpyHostToDevice, cs);
-            if (e == hipSuccess) e = hipMemcpyAsync(b->seq_off + lo, off.data() + lo, (size_t)(cn + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, cs);
-            if (e == hipSuccess) e = hipMemcpyAsync(b->strand + lo, reads->anchor_strand + lo, cn, hipMemcpyHostToDevice, cs);
-            if (e == hipSuccess) e = hipMemcpyAsync(b->pos + lo, reads->anchor_pos + lo, (size_t)cn * sizeof(int32_t), hipMemcpyHostToDevice, cs);
-            if (e == hipSuccess) e = hipMemcpyAsync(b->isz + lo, reads->insert_size + lo, (size_t)cn * sizeof(int16_t), hipMemcpyHostToDevice, cs);
-            if (e == hipSuccess) e = hipMemcpyAsync(b->chr + lo, reads->chr_id + lo, (size_t)cn * sizeof(int32_t), hipMemcpyHostToDevice, cs);
+            if (!one_copy) {
+                if (e == hipSuccess) e = hipMemcpyAsync(b->seq_off + lo, off.data() + lo, (size_t)(cn + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, cs);
+                if (e == hipSuccess) e = hipMemcpyAsync(b->strand + lo, reads->anchor_strand + lo, cn, hipMemcpyHostToDevice, cs);
+                if (e == hipSuccess) e = hipMemcpyAsync(b->pos + lo, reads->anchor_pos + lo, (size_t)cn * sizeof(int32_t), hipMemcpyHostToDevice, cs);
+                if (e == hipSuccess) e = hipMemcpyAsync(b->isz + lo, reads->insert_size + lo, (size_t)cn * sizeof(int16_t), hipMemcpyHostToDevice, cs);
+                if (e == hipSuccess) e = hipMemcpyAsync(b->chr + lo, reads->chr_id + lo, (size_t)cn * sizeof(int32_t), hipMemcpyHostToDevice, cs);
+            }
             if (e == hipSuccess) e = hipEventRecord(ctx->events[2 * k], cs);
             // even chunks on one kernel stream, odd chunks on the other: the next chunk's workgroups move in while this
             // chunk's persistent launch drains; the deliveries stay in chunk order (running totals, shared scratch)
