@@ -2237,19 +2237,32 @@ __global__ __launch_bounds__(WAVE, PG_WAVES(NB, Id)) void pg_search_kernel(PgDev
     S.t_base = 1;
 #endif
 
-    // reads claimed per atomic: PG_CLAIM, fewer when the launch is small (a 50 000-read flush is ten reads per resident
-    // wave: with claims of eight some waves would search sixteen reads and most eight).
+    // Reads claimed per atomic: a workgroup's share of the launch in the fewest equal claims of at most PG_CLAIM reads.  The host
+    // launches one workgroup per PG_CLAIM reads up to the chip's resident slots, so up to 57 k reads every wave takes exactly one claim
+    // of eight; between that and a few hundred thousand reads the share is 8..64 reads and claims of exactly eight would leave some
+    // waves a whole claim more than others (100 000 reads: 14 per wave = two claims of seven).  Measured, seven waves per SIMD:
+    // 50 000 reads 0.262 ms with claims of two, 0.23 with eight; 100 000: 0.403 -> 0.36; 5000 reads on 633 workgroups 0.106 either way,
+    // and 0.125 on 5008 workgroups of one read each -- a small launch pays for the NUMBER of workgroups.  A wave that looks at the
+    // other parts' counters before claiming from them (the walk over the eight parts at the end of a launch is one atomic per wave
+    // and address) gained nothing.
     // (Claims of ONE read for the last round and a half of a launch, to shorten its tail, were measured and rejected: a claim
     // is a dependent chain atomic -> records -> first window, 2 us that eight reads share -- 262 144 reads 0.94 -> 0.98 ms.)
     // Nothing but `part` and `tried` lives from one claim to the next: the launch's size comes from the kernarg segment again.
     uint32_t part = blockIdx.x % PG_N_XCD, tried = 0;
     while (tried < PG_N_XCD) {
         const uint32_t n = KA(B, n_reads);
-        const uint32_t claim = n >= 24u * gridDim.x ? PG_CLAIM : (n >= 6u * gridDim.x ? 2u : 1u);
+#ifdef PG_FORCE_CLAIM
+        const uint32_t claim = PG_FORCE_CLAIM;
+#else
+        // (a workgroup's share of the launch in the fewest equal claims of at most PG_CLAIM)
+        const uint32_t per_wg = (n + gridDim.x - 1u) / gridDim.x, n_claims = (per_wg + PG_CLAIM - 1u) / PG_CLAIM;
+        const uint32_t claim = per_wg >= 8u * PG_CLAIM ? PG_CLAIM : (per_wg + n_claims - 1u) / n_claims;
+#endif
         const uint32_t per = n / PG_N_XCD;
         const uint32_t lo = part * per, hi = part + 1 == PG_N_XCD ? n : lo + per;
         uint32_t got = 0;
-        if (lane == 0) got = atomicAdd(KA(B, work_ctr) + part * 16u, claim);
+        uint32_t *ctr = KA(B, work_ctr) + part * 16u;
+        if (lane == 0) got = atomicAdd(ctr, claim);
         got = (u32)uni((int)got);
         if (got >= hi - lo) {                             // this part is exhausted
             part = part + 1 == PG_N_XCD ? 0 : part + 1;
