@@ -132,7 +132,7 @@ def issue_model(args, kernel_ms, reads_per_launch):
            "valu_busy_frac_at_3p2_cycles": valu * per_simd * 3.2 / cyc,
            "salu_busy_frac_at_1_per_cu_cycle": salu * reads_per_launch / 256.0 / cyc,
            "ns_per_instruction": kernel_ms * 1e6 / per_simd / (valu + salu),
-           "in_situ_ns_per_extra_instruction": {"salu": 1.18, "valu_fast_rate": 0.83, "valu_slow_rate": 1.15},
+           "in_situ_ns_per_extra_instruction": {"salu": 1.65, "valu_fast_rate": 0.79, "valu_slow_rate": 1.06},
            "source": f"profiles/r04/{PMC_FILE} + profiles/r03/ubench_issue_rates.txt + profiles/r04/issue_calibration.txt, "
                      "256 CUs x 4 SIMDs, 2.4 GHz nominal"}
     if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_ACTIVE_INST_VALU"):

@@ -136,12 +136,13 @@ struct PgSoaOut {
 // fill, where the extra KB of LDS would cost a resident wave per SIMD.
 #define PG_PAIR_CHUNKS(nb) ((nb) <= 3)
 #define PG_WIN_WORDS(nb) (((PG_PAIR_CHUNKS(nb) ? 2u : 1u) * PG_CHUNK + 2u * (64u * (nb))) / 32u + 6u)
-// ... of which this many are STATIC LDS.  For 129..192-base reads (nb = 3) the second chunk's words are dynamic LDS that only
-// launches with -x >= 3 ask for: the static part, 6.3 KB, then fits 24 workgroups per CU (6 waves per SIMD) at the default -x 2,
-// where nothing ever takes two chunks per fill.  The dynamic part starts where the static LDS ends (the window is the last
-// member of the kernel's one static LDS object), so the window stays one array with compile-time addresses.
-// (LDS is handed out in granules of 1280 bytes on gfx950: 24 workgroups per CU need <= 6400 bytes each -- hence + 4 words of
-// slack here, not + 6: a fill writes 78 words and a candidate reads up to word 76 of a one-chunk window)
+// ... of which this many are STATIC LDS.  For reads of 65..192 bases (nb = 2, 3) the second chunk's words are dynamic LDS that only
+// launches with -x >= 3 ask for: the static part then fits 28 (nb = 2: 5120 B) or 24 (nb = 3: 6384 B) workgroups per CU -- seven or
+// six waves per SIMD -- at the default -x 2, where nothing takes two chunks per fill (a cluster window of more than a chunk
+// goes chunk by chunk).  The dynamic part starts where the static LDS ends (the window is the last member of the kernel's one
+// static LDS object), so the window stays one array with compile-time addresses.
+// (LDS is handed out in granules of 1280 bytes on gfx950 -- hence + 4 words of slack here, not + 6: a fill writes
+// (2048 + 128 nb) / 32 + 2 words -- 74 / 78 -- and a candidate reads up to word 4 nb + 63 of a one-chunk window)
 #define PG_WIN_STATIC_WORDS(nb) ((nb) == 3 || (nb) == 2 ? (PG_CHUNK + 2u * (64u * (nb))) / 32u + 4u : PG_WIN_WORDS(nb))
 #define PG_WIN_DYN_BYTES(nb) ((PG_WIN_WORDS(nb) - PG_WIN_STATIC_WORDS(nb)) * 16u)
 

@@ -115,12 +115,14 @@ __device__ __forceinline__ void karg_load3(T &a, T &b, T &c)
 #ifndef PG_N_XCD
 #define PG_N_XCD 8u        // MI355X: 8 accelerator complex dies, 32 CUs and one L2 each
 #endif
-// Register budget the kernel is compiled for, in waves per SIMD (= resident single-wave workgroups per CU / 4).  Six (80 VGPRs)
-// where the LDS lets 24 workgroups in: reads of up to 192 bases with 32-bit candidate ids.  Since the kernel's arguments stopped occupying scalar
-// registers (round 4) the sixth wave pays: 100 bp 6.03 -> 5.60 ms per 2 M reads, -x 5 28.9 -> 27.1; four waves: +13 %; seven
-// (72 VGPRs, spills): +-0.  Longer reads (7.3 KB of LDS and up) stay at five.
-// (LDS comes in granules of 1280 bytes: 24 workgroups per CU = at most five granules = 6400 bytes each; pg_waves<NB, Id>()
-// below, behind the Lds struct, decides by its size)
+// Register budget the kernel is compiled for, in waves per SIMD (= resident single-wave workgroups per CU / 4), decided by the
+// size of the kernel's LDS object -- LDS comes in granules of 1280 bytes:
+//   seven (72 VGPRs)  up to 5120 B = four granules, 28 workgroups per CU: reads of up to 128 bases with 32-bit candidate ids
+//   six   (80 VGPRs)  up to 6400 B = five granules, 24 workgroups: 129..192 bases; 64-bit ids
+//   five  (96 VGPRs)  longer reads (7.6 KB and up)
+// History of the measurement (100 bp, ms per 2 M reads): four waves 6.69, five 6.03, six 5.60 once the kernel's arguments had
+// stopped occupying scalar registers (round 4), seven then 6.02 (50 VGPR spills); with the default-parameter kernels and without
+// machine LICM seven fit 72 VGPRs with 3 spills: 4.97 -> 4.91 (generic kernels 5.35 -> 5.24).
 #ifdef PG_WAVES_PER_EU
 #define PG_WAVES(NB, Id) PG_WAVES_PER_EU
 #else

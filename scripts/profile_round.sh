@@ -95,6 +95,12 @@ if [ -f pindel_amd/libpindel_pg_pad_s.so ]; then
     cat "$out/issue_calibration_raw.txt"
 fi
 
+# where the instructions of a read go: builds that run one component twice (-DPG_DUP=n) or stop early (-DPG_STOP=n), PMC per read
+if [ -f pindel_amd/libpindel_pg_dup3.so ]; then
+    PMC=1 bash scripts/variants.sh plain dup3 dup4 dup5 dup6 dup7 dup8 dup9 stop1 stop2 > "$out/component_instruction_counts_raw.txt" 2>&1
+    grep -E "^==|SALU|VALU" "$out/component_instruction_counts_raw.txt" | paste - - - | head -12
+fi
+
 # Pindel's own flush size and a 4 M-read batch through the host-buffer entry, steady state (six calls each)
 python scripts/host_path_calls.py 50000 4000000 > "$out/host_path_calls.txt" 2>&1
 tail -4 "$out/host_path_calls.txt"
