@@ -40,9 +40,10 @@
 //     counters (every XCD works through a contiguous eighth of the batch: neighbouring reads share cache
 //     lines and reference windows in ONE L2).
 //
-// The kernel is bound by instruction issue (vector + scalar together: an instruction of either kind costs about 1 ns
-// of SIMD time in situ), not by HBM (profiles/r03/ubench_issue_rates.txt,
-// profiles/r03/issue_calibration.txt).  No MFMA: this is bit/byte comparison work, not a contraction.
+// The kernel is bound by instruction issue, not by HBM -- vector and scalar together, the CU's one scalar unit first: in situ a
+// scalar instruction costs 1.65 ns of SIMD time, a vector one 0.8-1.1 (profiles/r03/ubench_issue_rates.txt,
+// profiles/r04/issue_calibration.txt, profiles/r04/component_instruction_counts.txt).  No MFMA: this is bit/byte comparison
+// work, not a contraction.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -1532,7 +1533,7 @@ __device__ __forceinline__ u32 mm_of(const Search &S, int L)
 template <int NB, typename Id>
 __device__ __forceinline__ void evaluate(Search &S, const Acc<NB, Id> &A, Eval<NB, Id> &E, int lane, int qmask = 15)
 {
-    const u32 mm0 = mm_of<NB>(S, S.bps + lane);       // (one LDS read per evaluation; a VGPR per phase otherwise: the sixth wave's budget)
+    const u32 mm0 = mm_of<NB>(S, S.bps + lane);       // (one LDS read per evaluation; a VGPR per phase otherwise: the register budget of six and seven waves per SIMD)
     E.n_runs = 0;
     E.max_len = 0;
     E.id_last = 0;
@@ -1797,7 +1798,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     // ------------------------------------------------------------------------------- close end
     if (do_close) {
         // (the record's words are read again where they are used -- from LDS up to 256-base reads -- instead of eight VGPRs of
-        // wave-uniform data living through the whole read: what the sixth wave per SIMD is paid with)
+        // wave-uniform data living through the whole read: what the sixth and seventh wave per SIMD are paid with)
         const int strand = uni((int)((rec1().y >> 16) & 0xffu));
         const int apos = uni((int)rec0().z);
         const int isz = uni((int)(short)(rec1().x >> 16));
