@@ -33,6 +33,28 @@ def test_header_symbols_exported():
         assert hasattr(lib, sym), sym
 
 
+def test_library_holds_both_kernel_families(tmp_path):
+    """The shipped library carries the search kernels twice: generic (the five search parameters as kernel arguments) and compiled
+    for Pindel's default parameter set (`DEF`).  Read from the code object, no GPU needed."""
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump in this image")
+    binding.build()
+    lib = str(tmp_path / "lib.so")
+    shutil.copy(binding.LIB_PATH, lib)
+    subprocess.run([objdump, "--offloading", lib], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+    cos = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert cos, "no gfx950 code object in the library"
+    syms = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", str(tmp_path / cos[0])], stdout=subprocess.PIPE,
+                          text=True, check=True).stdout             # (the kernels' names in the code object's metadata)
+    for nb in (1, 2, 3, 4, 8):
+        for mode in (1, 2, 3):                   # close end, far end, both
+            assert f"pg_search_kernelILi{nb}ELi3EjLi{mode}ELb0E" in syms, ("generic kernel missing", nb, mode)
+            assert f"pg_search_kernelILi{nb}ELi3EjLi{mode}ELb1E" in syms, ("default-parameter kernel missing", nb, mode)
+
+
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(binding.PgParams) == 56
     assert binding.RUN_DTYPE.itemsize == 12 and binding.POINT_DTYPE.itemsize == 12
