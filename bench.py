@@ -30,9 +30,12 @@ if ROOT not in sys.path:
 
 CHR20_LEN = 62_435_964       # demo/hs_ref_chr20.fa.fai:1
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r04")
+# the round's committed counter files (scripts/profile_round.sh); PMC counters cannot be read from inside this process
+PROFILE_ROUND = next((r for r in ("r05", "r04") if os.path.exists(os.path.join(ROOT, "profiles", r, "hbm_traffic.json"))), "r05")
+PROFILE_DIR = os.path.join(ROOT, "profiles", PROFILE_ROUND)
 TRAFFIC_FILE = "hbm_traffic.json"
 PMC_FILE = "pmc_sq.txt"
+CALIB_FILE = "issue_calibration.txt"
 
 
 def cpu_baseline(chroms, batch, params_kw, budget_s=10.0, bd=None, bd_off=None, thread_points=True):
@@ -100,7 +103,7 @@ def measured_traffic(args, reads_per_launch):
     with open(path) as fh:
         t = json.load(fh)
     per_read = t["fetch_bytes_per_read"] + t["write_bytes_per_read_uncalibrated"]
-    return per_read * reads_per_launch, (f"profiles/r04/{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+    return per_read * reads_per_launch, (f"profiles/{PROFILE_ROUND}/{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                           "separate passes, per read x reads per launch)")
 
 
@@ -133,7 +136,7 @@ def issue_model(args, kernel_ms, reads_per_launch):
            "salu_busy_frac_at_1_per_cu_cycle": salu * reads_per_launch / 256.0 / cyc,
            "ns_per_instruction": kernel_ms * 1e6 / per_simd / (valu + salu),
            "in_situ_ns_per_extra_instruction": {"salu": 1.65, "valu_fast_rate": 0.79, "valu_slow_rate": 1.06},
-           "source": f"profiles/r04/{PMC_FILE} + profiles/r03/ubench_issue_rates.txt + profiles/r04/issue_calibration.txt, "
+           "source": f"profiles/{PROFILE_ROUND}/{PMC_FILE} + profiles/r03/ubench_issue_rates.txt + profiles/r04/issue_calibration.txt, "
                      "256 CUs x 4 SIMDs, 2.4 GHz nominal"}
     if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_ACTIVE_INST_VALU"):
         # active lanes per executed VALU instruction (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU), of 64
@@ -433,6 +436,11 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                # what the memory system actually moved per second (counter traffic / kernel time) and how much of it the
+                # algorithm did not ask for; null when the workload is not the one the committed counter passes ran
+                "hbm_achieved_gbs": traffic / (avg_ms * 1e-3) / 1e9 if traffic and avg_ms > 0 else None,
+                "hbm_achieved_frac": traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic and avg_ms > 0 else None,
+                "traffic_over_algorithmic": traffic / alg_bytes if traffic and alg_bytes else None,
                 "kernel": "pg_search_kernel", "kernel_ms": avg_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "actual_bound": "instruction issue (VALU + scalar), see DESIGN.md section 4",

@@ -96,6 +96,13 @@ def use_library(path):
     LIB_PATH = path
 
 
+def reload_env():
+    """The library reads its PG_* environment switches once per process; tests that change one call this afterwards."""
+    L = lib()
+    L.pg_debug_reload_env.restype = None
+    L.pg_debug_reload_env()
+
+
 def lib():
     """Load the shared library (building it first if the sources are newer)."""
     global _lib

@@ -22,6 +22,8 @@
 #include <chrono>
 #include <condition_variable>
 #include <functional>
+#include <exception>
+#include <pthread.h>
 namespace {
 
 double now_ms()
@@ -29,6 +31,30 @@ double now_ms()
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 const bool g_host_timing = getenv("PG_HOST_TIMING") != nullptr;
+
+// The environment switches of tests and experiments, read ONCE (getenv on the 50 000-read flush path is a linear scan of the
+// environment per call) -- pg_debug_reload_env() re-reads them (tests that change one in mid-process call it).
+PgEnvSwitches g_env;
+std::once_flag g_env_once;
+void load_env()
+{
+    PgEnvSwitches e;
+    const char *c = getenv("PG_HOST_CHUNK");                 // (tests: several chunks on a small batch)
+    e.host_chunk = c ? (uint32_t)std::min<long>(std::max(1, atoi(c)), PG_DELIVER_CHUNK) : 0u;
+    e.no_single_block = getenv("PG_NO_SINGLE_BLOCK") != nullptr;
+    e.tiny_delivery = getenv("PG_TEST_TINY_DELIVERY") != nullptr;
+    e.tiny_pool = getenv("PG_TEST_TINY_POOL") != nullptr;
+    e.force_wide_cells = getenv("PG_FORCE_WIDE_CELLS") != nullptr;
+    e.split_launch = getenv("PG_SPLIT_LAUNCH") != nullptr;
+    e.generic_kernels = getenv("PG_GENERIC_KERNELS") != nullptr;
+    e.lds_pad = getenv("PG_LDS_PAD") ? (uint32_t)atoi(getenv("PG_LDS_PAD")) : 0u;
+    g_env = e;
+}
+const PgEnvSwitches &env()
+{
+    std::call_once(g_env_once, load_env);
+    return g_env;
+}
 
 // Pinned host memory for results (device-to-host copies at PCIe speed, no staging through pageable pages).
 // Pinning is expensive, results are handed out and freed all the time (Pindel flushes a batch every 50 000
@@ -193,6 +219,7 @@ struct pg_ctx {
     uint64_t last_runs = 0;
     std::string err;
     bool counted = false;              // in g_live_ctx (the pinned-memory cache is trimmed with the last context)
+    bool kargs_checked = false;        // the kernels' view of the kernarg segment was checked on this device (pg_debug_kargs_check)
 };
 
 struct pg_device_batch {
@@ -230,15 +257,16 @@ struct pg_device_batch {
 
 struct pg_result {
     uint32_t n = 0;
+    // one-chunk results of the host path arrive in ONE device-to-host copy: this block; the arrays below are views into it.
+    // Declared BEFORE them: members are destroyed in reverse order of declaration, so the views go first and the block is handed
+    // back to the pinned cache (where another thread may take it at once) only after nothing points into it any more.
+    HostBuf<uint8_t> block;
     HostBuf<uint64_t> close_off, far_off;
     HostBuf<pg_run> close_runs, far_runs;
     HostBuf<uint8_t> rc_flag;
     HostBuf<uint32_t> close_last;
     HostBuf<uint16_t> close_max;
     HostBuf<uint32_t> csr32[2];        // staging of the device-built 32-bit offsets
-    // one-chunk results of the host path arrive in ONE device-to-host copy: this block, the arrays above are views into it
-    // (declared last: destroyed first would be wrong -- members are destroyed in reverse order, so the views go first)
-    HostBuf<uint8_t> block;
 };
 
 namespace {
@@ -392,6 +420,14 @@ void free_batch_buffers(pg_device_batch *b)
 // pool that sleeps between calls: spawning sixteen std::threads per pass cost more than the pass (0.25 ms of the 1.5 ms a
 // 4 M-read pg_search_batch spent before its first copy).  One job at a time; a second caller (another context's host
 // thread in pg_search_batch_multi) that finds the pool busy runs its ranges on threads of its own as before.
+//   * re-entry: a range function that calls host_ranges() again on a pool thread (or on the caller's) finds t_in_pool set and
+//     runs its ranges inline (try_lock on a mutex the thread already owns would be undefined behaviour);
+//   * fork(): the child has the pool object but none of its threads; the pool lives behind a pointer and a pthread_atfork
+//     child handler replaces it with a fresh one (the old object is leaked on purpose: joining threads that do not exist in
+//     this process, or destroying mutexes another thread held at the fork, is not defined);
+//   * a range function must not throw across threads: an exception on a worker is caught, the job completes, and the first
+//     one is rethrown on the calling thread.
+thread_local bool t_in_pool = false;
 class HostPool {
 public:
     ~HostPool()
@@ -405,8 +441,10 @@ public:
     }
     bool try_run(size_t n, unsigned nt, const std::function<void(size_t, size_t)> &fn)
     {
+        if (t_in_pool) return false;                            // re-entry from a range function
         std::unique_lock<std::mutex> job(job_mu_, std::try_to_lock);
         if (!job.owns_lock()) return false;
+        struct InPool { InPool() { t_in_pool = true; } ~InPool() { t_in_pool = false; } } in_pool;
         {
             std::lock_guard<std::mutex> lk(mu_);
             while (th_.size() + 1 < nt) {
@@ -417,13 +455,23 @@ public:
             n_ = n;
             nt_ = nt;
             remaining_ = nt - 1;
+            error_ = nullptr;
             gen_++;
         }
         cv_.notify_all();
-        fn((size_t)0, n / nt);                                  // the caller takes the first range
+        std::exception_ptr mine;
+        try {
+            fn((size_t)0, n / nt);                              // the caller takes the first range
+        } catch (...) {
+            mine = std::current_exception();
+        }
         std::unique_lock<std::mutex> lk(mu_);
         done_.wait(lk, [this] { return remaining_ == 0; });
         fn_ = nullptr;
+        std::exception_ptr err = mine ? mine : error_;
+        error_ = nullptr;
+        lk.unlock();
+        if (err) std::rethrow_exception(err);
         return true;
     }
 private:
@@ -443,8 +491,15 @@ private:
                 n = n_;
                 nt = nt_;
             }
-            (*fn)(n * id / nt, n * (id + 1) / nt);
+            std::exception_ptr err;
+            t_in_pool = true;
+            try {
+                (*fn)(n * id / nt, n * (id + 1) / nt);
+            } catch (...) {
+                err = std::current_exception();
+            }
             std::lock_guard<std::mutex> lk(mu_);
+            if (err && !error_) error_ = err;
             if (--remaining_ == 0) done_.notify_one();
         }
     }
@@ -455,8 +510,19 @@ private:
     size_t n_ = 0;
     unsigned nt_ = 0, remaining_ = 0, gen_ = 0;
     bool stop_ = false;
+    std::exception_ptr error_;
 };
-HostPool g_host_pool;
+HostPool *g_host_pool = nullptr;
+std::once_flag g_host_pool_once;
+HostPool &host_pool()
+{
+    std::call_once(g_host_pool_once, [] {
+        g_host_pool = new HostPool();
+        (void)pthread_atfork(nullptr, nullptr, [] { g_host_pool = new HostPool(); t_in_pool = false; });
+        atexit([] { HostPool *p = g_host_pool; g_host_pool = nullptr; delete p; });
+    });
+    return *g_host_pool;
+}
 
 template <class Fn>
 void host_ranges(size_t n, Fn fn)
@@ -467,7 +533,7 @@ void host_ranges(size_t n, Fn fn)
         fn((size_t)0, n);
         return;
     }
-    if (g_host_pool.try_run(n, nt, std::function<void(size_t, size_t)>(fn))) return;
+    if (host_pool().try_run(n, nt, std::function<void(size_t, size_t)>(fn))) return;
     std::vector<std::thread> th;
     for (unsigned t = 0; t < nt; t++) th.emplace_back(fn, n * t / nt, n * (t + 1) / nt);
     for (std::thread &x : th) x.join();
@@ -546,7 +612,7 @@ int validate_and_measure(pg_ctx *ctx, const pg_read_batch *reads, uint32_t *max_
 
 // Runs per list the chunked delivery of search_host has room for (1.04 per read on average; a batch that needs more
 // falls back to the whole-batch download).
-static size_t deliver_cap(size_t n) { return getenv("PG_TEST_TINY_DELIVERY") ? n / 2 + 8 : 2 * n + 4096; }   // (tests: force the fallback)
+static size_t deliver_cap(size_t n) { return env().tiny_delivery ? n / 2 + 8 : 2 * n + 4096; }   // (tests: force the fallback)
 
 // Validates the batch and allocates its device buffers.  copy = true also copies the inputs
 // (synchronously); otherwise the caller streams them in (search_host).  off = read offsets rebased to 0.
@@ -572,7 +638,7 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, HostBuf<uint
     const uint64_t nseq = n ? reads->seq_off[n] - base0 : 0;
     // every read reserves PG_RESERVE slots (one atomic per claim of reads); lists longer than their share allocate more
     b->pool_shard_cap = (uint32_t)std::min<uint64_t>(((PG_RESERVE + 2ull) * n) / PG_POOL_SHARDS + 512ull, 0x7fffffffull / PG_POOL_SHARDS);
-    if (getenv("PG_TEST_TINY_POOL")) b->pool_shard_cap = 1;      // tests: force the overflow/regrow path
+    if (env().tiny_pool) b->pool_shard_cap = 1;      // tests: force the overflow/regrow path
     const size_t n1 = std::max<size_t>(n, 1);
     // (pointer, bytes) of every buffer; the zeroed block (outputs) is contiguous in the arena case
     struct Item { void **p; size_t bytes; };
@@ -606,7 +672,8 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, HostBuf<uint
                 pg_scan_tmp_bytes((uint32_t)n) + 4096;
         // ... and for the chunk-by-chunk delivery of search_host: gathered runs (2 lists), 64-bit offsets (2 lists), scratch
         need += 2 * (deliver_cap(n) * sizeof(pg_run) + 512) + 2 * ((n + 1) * 8 + 512) + PG_DELIVER_CHUNK * 8 + 4096 * 8 +
-                (n / (PG_HOST_CHUNK / 4) + 16) * 64 + 8192 + 8 * n + 4096;      // (+ the summaries of a one-block delivery)
+                (n / std::min<size_t>(PG_HOST_CHUNK / 4, env().host_chunk ? env().host_chunk : PG_HOST_CHUNK) + 16) * 64 +   // 64 B of info per chunk
+                8192 + 8 * n + 4096;                                           // (+ the summaries of a one-block delivery)
         if (need > ctx->arena.cap) {
             if (ctx->arena.base) (void)hipFree(ctx->arena.base);
             ctx->arena.base = nullptr;
@@ -742,7 +809,7 @@ bool small_ids(const pg_ctx *ctx, const pg_device_batch *b)
     // 32-bit candidate ids when every window of this launch has <= 2^24 positions: ranges 128 * 4^x
     // (x <= 8), close windows 3 * InsertSize (a short), BreakDancer windows as attached
     return ctx->prm.max_range_index <= 8 && (long long)b->max_bd_window <= PG_SMALL_MAX_WINDOW &&
-           b->max_bd_cluster <= PG_SMALL_MAX_CLUSTER && !getenv("PG_FORCE_WIDE_CELLS");
+           b->max_bd_cluster <= PG_SMALL_MAX_CLUSTER && !env().force_wide_cells;
 }
 
 // Launches the search for reads [lo, lo + cnt) of the batch on the ctx stream.
@@ -762,6 +829,13 @@ int launch_range(pg_ctx *ctx, pg_device_batch *b, int mode, uint32_t lo, uint32_
     if (set) {
         d.work_ctr += PG_WORK_CTRS * 16 + PG_DIAG_WORDS * 2;
         bytes = PG_WORK_CTRS * 16 * sizeof(uint32_t);
+    }
+    if (!ctx->kargs_checked) {
+        // once per context: the kernels fetch their arguments from the kernarg segment at offsets of their own (KA() in
+        // pg_kernels.hip); a one-wave kernel with the same parameter list compares them with the by-value arguments
+        const int bad = pg_debug_kargs_check(&ref, &prm, &d, b->max_len, b->levels, d.work_ctr + PG_WORK_CTRS * 16, st);
+        if (bad != 0) return fail(ctx, PG_E_DEVICE, "kernel arguments: the kernarg segment is not laid out as the kernels expect (" + std::to_string(bad) + ")");
+        ctx->kargs_checked = true;
     }
     if (!fresh) HIP_TRY(ctx, hipMemsetAsync(d.work_ctr, 0, bytes, st));
     int lrc = pg_launch_search(&ref, &prm, &d, mode, b->max_len, b->levels, small_ids(ctx, b) ? 1 : 0, st);
@@ -926,6 +1000,13 @@ int upload_reference(pg_ctx *ctx)
 
 // ============================================================================== C ABI
 extern "C" {
+
+const PgEnvSwitches *pg_env_switches(void) { return &env(); }
+void pg_debug_reload_env(void)
+{
+    (void)env();
+    load_env();
+}
 
 void pg_default_params(pg_params *p)
 {
@@ -1439,8 +1520,8 @@ static int search_host(pg_ctx *ctx, const pg_read_batch *reads, int mode, pg_res
     const uint32_t n = b->n;
     r = new pg_result();
     r->n = n;
-    const char *chunk_env = getenv("PG_HOST_CHUNK");             // (tests: several chunks on a small batch)
-    const uint32_t chunk = chunk_env ? (uint32_t)std::min<long>(std::max(1, atoi(chunk_env)), PG_DELIVER_CHUNK) : PG_HOST_CHUNK;
+    const bool chunk_env = env().host_chunk != 0u;               // (tests: several chunks on a small batch)
+    const uint32_t chunk = chunk_env ? env().host_chunk : PG_HOST_CHUNK;
     // Chunk boundaries.  A launch of 256 k reads runs at 278 M reads/s, one of 1 M at ~310, one of 10 M at 323 (ramp-up and
     // tail of the launch itself: profiles/r04/kernel_experiments.txt), but the first chunk's copy and the last chunk's
     // delivery + download are exposed: small chunks first (a quarter of the base chunk, doubling), up to 2^20 reads in the
@@ -1460,7 +1541,7 @@ static int search_host(pg_ctx *ctx, const pg_read_batch *reads, int mode, pg_res
     // A batch that is ONE chunk (Pindel's own 50 000-read flushes) gets its whole result in ONE device-to-host copy: offsets,
     // summaries and both run lists are laid out in one device block and one pinned host block (pg_result::block), the
     // result's arrays are views into it -- five copies and their ~10 us of runtime call each otherwise.
-    const bool single = n_chunks == 1 && !getenv("PG_NO_SINGLE_BLOCK");
+    const bool single = n_chunks == 1 && !env().no_single_block;
     const size_t cap = single ? 2 * deliver_cap(n) : deliver_cap(n);       // (single: both lists share one buffer)
     size_t o_coff = 0, o_foff = 0, o_rc = 0, o_last = 0, o_max = 0, o_runs = 0, blk_bytes = 0;
     if (single) {
@@ -1536,7 +1617,7 @@ static int search_host(pg_ctx *ctx, const pg_read_batch *reads, int mode, pg_res
             const size_t o_str = (size_t)((const char *)b->strand - d0), o_pos = (size_t)((const char *)b->pos - d0),
                          o_isz = (size_t)((const char *)b->isz - d0), o_chr = (size_t)((const char *)b->chr - d0), span = o_chr + (size_t)n * 4;
             const bool one_copy = single && b->in_arena && (const char *)b->strand > d0 && o_str < o_pos && o_pos < o_isz && o_isz < o_chr &&
-                                  span <= off.cap_bytes && !getenv("PG_NO_SINGLE_BLOCK");
+                                  span <= off.cap_bytes && !env().no_single_block;
             if (one_copy) {
                 char *h = (char *)off.data();
                 memcpy(h + o_str, reads->anchor_strand, n);

@@ -146,9 +146,26 @@ struct PgSoaOut {
 #define PG_WIN_STATIC_WORDS(nb) ((nb) == 3 || (nb) == 2 ? (PG_CHUNK + 2u * (64u * (nb))) / 32u + 4u : PG_WIN_WORDS(nb))
 #define PG_WIN_DYN_BYTES(nb) ((PG_WIN_WORDS(nb) - PG_WIN_STATIC_WORDS(nb)) * 16u)
 
+// Environment switches of tests and experiments, read once per process by pg_api.cpp (pg_debug_reload_env() re-reads them)
+struct PgEnvSwitches {
+    uint32_t host_chunk;        // PG_HOST_CHUNK: reads per chunk of the host path (0 = the default schedule)
+    uint32_t lds_pad;           // PG_LDS_PAD: extra dynamic LDS per workgroup (lowers occupancy), bytes
+    bool no_single_block;       // PG_NO_SINGLE_BLOCK: no one-copy delivery of one-chunk batches
+    bool tiny_delivery;         // PG_TEST_TINY_DELIVERY: forces the delivery-overflow fallback
+    bool tiny_pool;             // PG_TEST_TINY_POOL: forces the run-pool regrow path
+    bool force_wide_cells;      // PG_FORCE_WIDE_CELLS: 64-bit candidate ids
+    bool split_launch;          // PG_SPLIT_LAUNCH: close end and far end as two launches
+    bool generic_kernels;       // PG_GENERIC_KERNELS: never the default-parameter kernels
+};
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+const struct PgEnvSwitches *pg_env_switches(void);
+void pg_debug_reload_env(void);
+// number of kernel arguments whose value fetched from the kernarg segment at PgKArgs' offsets differs from the by-value one (0)
+int pg_debug_kargs_check(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch *batch, uint32_t max_len, uint32_t levels,
+                         uint32_t *scratch_dev, void *stream);
 // Launches the search kernel for the reads of the batch on `stream`.  small_ids selects the
 // 32-bit candidate ids (see above for when that is valid).
 int pg_launch_search(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch *batch,

@@ -79,11 +79,11 @@ __device__ __forceinline__ T karg_load(int off)
     const auto k = __builtin_amdgcn_kernarg_segment_ptr();
     if (sizeof(T) == 8) {
         unsigned long long v;
-        asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(k), "n"(off));
+        asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v) : "s"(k), "n"(off));   // (early clobber: never the base's registers)
         return KaGlobal<T>::of(v);
     } else {
         unsigned int v;
-        asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(k), "n"(off));
+        asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v) : "s"(k), "n"(off));
         return (T)v;
     }
 }
@@ -379,6 +379,18 @@ struct Search {
 #define PG_T(S, k) do { if (threadIdx.x == 0) { const u64 t_ = __builtin_readcyclecounter(); (S).t_acc[k] += (u32)(t_ - *(S).t_last); *(S).t_last = t_; } } while (0)
 #else
 #define PG_T(S, k) ((void)0)
+#endif
+#ifdef PG_STOP
+    // diagnostics ladder (wrong results): -DPG_STOP=k returns from the read the first time it reaches point k; the PMC difference
+    // between two builds = the instructions of the code between the two points (profiles/r05/everything_else_breakdown.txt)
+    u32 stopped;
+// (every point leaves a marker in the ISA -- s_nop 14, s_nop k & 7, s_nop k >> 3 -- so that the code between two points can be read)
+#define PG_STOP_AT(S, k) do { asm volatile("s_nop 14\n\ts_nop %0\n\ts_nop %1" : : "n"((k) & 7), "n"((k) >> 3)); \
+                              if (PG_STOP == (k) && uni(opaque(1))) { (S).stopped = 1u; return; } } while (0)
+#define PG_STOPPED(S) do { if ((S).stopped) return; } while (0)
+#else
+#define PG_STOP_AT(S, k) ((void)0)
+#define PG_STOPPED(S) ((void)0)
 #endif
 #ifdef PG_DIAG
     u32 dg;              // diagnostics build: fills | seed-filter runs << 8 | candidate passes << 16 | evaluations << 24
@@ -721,6 +733,7 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
         }
     }
     if (lng) S.hdrB[lane] = make_uint2((u32)id, meta);
+    PG_STOP_AT(const_cast<Search &>(S), (MIXED && R.on) ? 28 : 17);
     PG_SYNC();
     // ---- tier A
     if (nA > 0) {
@@ -741,6 +754,7 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
     // ---- tier B (with rings: left to the caller, ring by ring)
     if (!(MIXED && R.on)) fold_tier_b<NB, Id>(S, Q, A, longm, lane);
     PG_SYNC();
+    PG_STOP_AT(const_cast<Search &>(S), (MIXED && R.on) ? 29 : 18);
 }
 
 // Stages bases [lo, hi) (hi - lo <= PG_CHUNK + 128 NB) of a chromosome into LDS: word i of the window
@@ -1395,6 +1409,7 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
                 PG_SYNC();
                 PG_T(S, S.t_base);
                 fold_candidates<NB, Id, MIXED>(S, Q, A, wb, origin, region, n, lane, Rings{ false, 0, 0, 0, 0 }, nullptr);
+                PG_STOPPED(S);
                 PG_T(S, S.t_base + 1);
                 slot -= n;
                 end -= n;
@@ -1415,6 +1430,7 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
             stage_window<NB>(ref, S, wo, wb, se + 64 * NB, opaque(lane));
 #endif
         }
+        PG_STOP_AT(S, 13);
         const int pbase = cs + 32 * lane;
         const u32 rmask = (low32_lane(ne - pbase) & ~low32_lane(ns - pbase)) & ~(low32_lane(xe - pbase) & ~low32_lane(xs - pbase));
         const bool cached = use_cache && k == 0 && cache_valid != 0u;
@@ -1438,6 +1454,7 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
             }
             if (use_cache && k == 0) { cacheF = mF; cacheB = mB; }
         }
+        PG_STOP_AT(S, 14);
         mF &= rmask;
         mB &= rmask;
         if (use_cache && k == 0) cache_valid = 1u;
@@ -1446,6 +1463,7 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
         const u32 incl = wave_scan(cnt);
         const int total = (int)read_lane(incl, 63);
         int slot = (int)(incl - cnt);
+        PG_STOP_AT(S, 15);
         for (int base = 0; base < total; base += WAVE) {
             PG_SYNC();
             const int top = base + WAVE;
@@ -1473,7 +1491,9 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
             }
 #endif
             PG_T(S, S.t_base);
+            PG_STOP_AT(S, 16);
             fold_candidates<NB, Id, MIXED>(S, Q, A, wb, origin, region, n, lane, Rings{ false, 0, 0, 0, 0 }, nullptr);
+            PG_STOPPED(S);
             PG_T(S, S.t_base + 1);
         }
     }
@@ -1736,6 +1756,9 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
 #endif
     S.cap_state = 255;
     S.sf = 0u;
+#ifdef PG_STOP
+    S.stopped = 0u;
+#endif
     // the read's packed record (rid is wave-uniform)
     auto rec0 = [&]() -> uint4 {
         if (PG_REC_LDS(NB)) return S.rec[2 * opaque(slot)];
@@ -1761,6 +1784,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
         S.mm_j[0] = uni((int)mm_of<NB>(S, j0));
         S.mm_j[1] = uni((int)mm_of<NB>(S, j1));
     }
+    PG_STOP_AT(S, 10);
     // The record is the read's first memory round trip; its bases and the window of the first close-end attempt are
     // the second: both are requested before either is used (the scan below finds the window resident).
     const u64 planes_of_read = request_planes<NB>(B, rid, lane);
@@ -1827,6 +1851,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
             u32 co0 = 0u, co1 = 0u;                       // ... and of the other one (swapped at attempts 1 and 3)
             u32 vo = 0u;
             int ps = 0, pe = 0, nsurv_eval = 0;
+            PG_STOP_AT(S, 11);
             for (int att = 0; att < 4; att++) {
                 const int Rg = att >> 1;
 #ifdef PG_TIMING
@@ -1867,8 +1892,11 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                 // one call site: attempt 0 on its own grid unless the R = 1 window fits a chunk, the retries on the grid
                 // of the R = 1 window
                 const bool own_grid = att == 0 && !shared_grid;
+                PG_STOP_AT(S, 12);
                 scan_range<NB, NS, Id>(ref, S, Q, A, chr_wo, own_grid ? s1 : w1s, s1, e1, own_grid ? e1 : w1e, ps, pe, w1s, 0u,
                                    opaque(lane), (att == 1 || att == 2 ? 1u : 0u) | shared_grid, cr0, cr1, vr);
+                PG_STOPPED(S);
+                PG_STOP_AT(S, 19);
                 ps = s1;
                 pe = e1;
                 if (S.nsurv != nsurv_eval) {
@@ -1889,6 +1917,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                     }
 #endif
                     evaluate<NB, Id>(S, A, E, opaque(lane));
+                    PG_STOP_AT(S, 20);
                     close_max = uni(E.max_len);
                     if (uni(E.n_runs) > 0) {
                         u64 kept[NB];
@@ -1907,6 +1936,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                         const u64 idl = (u64)E.id_last;
                         const int pl = w1s + (int)(u32)(idl & ((1ull << IdFmt<Id>::RB) - 1ull));
                         close_last = ((idl >> IdFmt<Id>::RB) & 1ull) ? (u32)(pl - close_max + 1) : (u32)(pl + close_max - 1);
+                        PG_STOP_AT(S, 21);
                         break;
                     }
                 }
@@ -1928,6 +1958,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     PG_T(S, S.t_base + 2);
     S.t_base = 7;
 #endif
+    PG_STOP_AT(S, 22);
     int n_far = 0, far_max = 0;
     u32 far_base = 0;
     // "if (CurrentBase == 'N' || MaxLenCloseEnd() == 0) return;" (farend_searcher.cpp:60-66)
@@ -2006,6 +2037,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                     far_bases += (e > s ? e - s : 0) + 2 * len;
                     scan_range<NB, NS, Id>(ref, S, Q, A, chr_word_off_of(ref, S, uni(bw.chr_id)), s, s, e, e, 0, 0, st,
                                        (u32)w, opaque(lane), false, unused0, unused1, unused_valid);
+                    PG_STOPPED(S);
                 }
                 if (S.nsurv > 0) far_update(0, bd, 15);
                 done = far_max + close_max >= len;           // goodFarEndFound (pindel.cpp:480-483)
@@ -2052,13 +2084,16 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                         rs[r] = uni(rs[r]);
                         re[r] = uni(re[r]);
                     }
+                    PG_STOP_AT(S, 23);
                     if (rs[R] < re[R]) {
                         const int wb = g0 - 64 * NB;
                         const int se = emax < g0 + (int)PG_CHUNK ? emax : g0 + (int)PG_CHUNK;
                         if (!(chr_wo == S.win_wo && S.wbase == wb && se + 64 * NB <= S.win_hi))
                             stage_window<NB>(ref, S, chr_wo, wb, se + 64 * NB, lane);
+                        PG_STOP_AT(S, 24);
                         u32 mF = 0u, mB = 0u;
                         seed_filter<NB, NS, true>(S, Q, false, false, lane, mF, mB);
+                        PG_STOP_AT(S, 25);
 #if defined(PG_DUP) && PG_DUP == 8
                         {
                             u32 dF, dB;
@@ -2077,6 +2112,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                         const u32 cnt = (u32)(__popc(mF) + __popc(mB));
                         const u32 incl = wave_scan(cnt);
                         const int total = (int)read_lane(incl, 63);
+                        PG_STOP_AT(S, 26);
                         if (total <= WAVE) {
                             r_first = R + 1;
                             ps = rs[R];
@@ -2099,6 +2135,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                                 S.nsurv += total;
                                 S.nsurv_total += (u32)total;
                                 PG_SYNC();
+                                PG_STOP_AT(S, 27);
                                 int ring_n[3];
                                 PG_T(S, 7);
 #if defined(PG_DUP) && PG_DUP == 9
@@ -2112,6 +2149,8 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
 #endif
                                 fold_candidates<NB, Id, true>(S, Q, A, wb, origin, 0u, total, lane,
                                                               Rings{ true, rs[0], re[0], rs[1], re[1] }, ring_n);
+                                PG_STOPPED(S);
+                                PG_STOP_AT(S, 30);
                                 PG_T(S, 8);
                                 for (int r = 0; r <= R; r++) {
                                     if (uni(ring_n[r]) > 0) {       // (no new candidate: the evaluation would repeat the previous one)
@@ -2139,6 +2178,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                             }
                         }
                     }
+                    PG_STOP_AT(S, 31);
                 }
 #endif
                 int span = 64 << (2 * r_first);
@@ -2148,6 +2188,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                     if (s < e) {
                         scan_range<NB, NS, Id>(ref, S, Q, A, chr_wo, g0, s, e, emax, ps, pe, origin, 0u, opaque(lane), true,
                                            cacheF, cacheB, cache_valid);
+                        PG_STOPPED(S);
                         if (ps < pe) {
                             ps = s < ps ? s : ps;
                             pe = e > pe ? e : pe;
@@ -2168,6 +2209,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
             alg += (u32)(3 * far_bases + 96 * n_far);
         }
     }
+    PG_STOP_AT(S, 32);
     PG_T(S, 9);
     alg = (alg + 4u) >> 3;
     if (lane == 0) {
@@ -2302,13 +2344,50 @@ __global__ __launch_bounds__(WAVE, PG_WAVES(NB, Id)) void pg_search_kernel(PgDev
 #endif
 }
 
+// Self-check of KA(): a kernel with pg_search_kernel's parameter list compares what KA() / KAP() fetch from the kernarg segment at
+// PgKArgs' offsets with the by-value arguments the compiler passes (one launch per context, pg_debug_kargs_check); a mismatch --
+// a changed parameter list, an ABI that lays the segment out differently -- is reported instead of searched with.
+static_assert(offsetof(PgKArgs, ref) == 0 && offsetof(PgKArgs, prm) == sizeof(PgDevRef) && alignof(PgDevRef) == 8 && alignof(PgDevParams) == 4 &&
+              offsetof(PgKArgs, B) == ((sizeof(PgDevRef) + sizeof(PgDevParams) + 7) & ~(size_t)7) &&
+              offsetof(PgKArgs, max_len) == offsetof(PgKArgs, B) + sizeof(PgDevBatch) && offsetof(PgKArgs, levels) == offsetof(PgKArgs, max_len) + 4,
+              "PgKArgs mirrors the kernarg segment of pg_search_kernel(PgDevRef, PgDevParams, PgDevBatch, uint32_t, uint32_t)");
+__global__ void pg_kargs_check_kernel(PgDevRef ref, PgDevParams prm, PgDevBatch B, uint32_t max_len, uint32_t levels)
+{
+    u32 bad = 0u;
+#define PG_CHK(obj, m) bad += (u64)KA(obj, m) != (u64)obj.m ? 1u : 0u
+    PG_CHK(ref, lo); PG_CHK(ref, hi); PG_CHK(ref, nn); PG_CHK(ref, chr_word_off); PG_CHK(ref, chr_size); PG_CHK(ref, n_chr);
+    PG_CHK(prm, max_range_index); PG_CHK(prm, add_mm); PG_CHK(prm, min_perfect); PG_CHK(prm, min_close); PG_CHK(prm, spacer);
+    PG_CHK(B, n_reads); PG_CHK(B, first_read); PG_CHK(B, in); PG_CHK(B, out); PG_CHK(B, seq); PG_CHK(B, planes); PG_CHK(B, plane_blocks);
+    PG_CHK(B, bd); PG_CHK(B, pool); PG_CHK(B, pool_shard_cap); PG_CHK(B, pool_used); PG_CHK(B, work_ctr);
+#undef PG_CHK
+    {
+        const u32 *glo, *ghi, *gnn;
+        karg_load3<(int)offsetof(PgKArgs, ref.lo)>(glo, ghi, gnn);
+        bad += (glo != ref.lo ? 1u : 0u) + (ghi != ref.hi ? 1u : 0u) + (gnn != ref.nn ? 1u : 0u);
+    }
+    bad += karg_load<uint32_t>((int)offsetof(PgKArgs, max_len)) != max_len ? 1u : 0u;
+    bad += karg_load<uint32_t>((int)offsetof(PgKArgs, levels)) != levels ? 1u : 0u;
+    if (threadIdx.x == 0) *B.work_ctr = bad;      // (B.work_ctr: the caller's scratch word)
+}
+extern "C" int pg_debug_kargs_check(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch *batch, uint32_t max_len, uint32_t levels,
+                                    uint32_t *scratch_dev, void *stream)
+{
+    PgDevBatch b = *batch;
+    b.work_ctr = scratch_dev;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(pg_kargs_check_kernel, dim3(1), dim3(WAVE), 0, st, *ref, *prm, b, max_len, levels);
+    uint32_t bad = ~0u;
+    if (hipMemcpyAsync(&bad, scratch_dev, sizeof bad, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
+    return (int)bad;
+}
+
 // ---------------------------------------------------------------------------------
 template <int NB, int NS, typename Id, bool DEF>
 static void launch_modes(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch *batch, int mode,
                          uint32_t max_len, uint32_t levels, hipStream_t st, unsigned lds_pad, dim3 grid, dim3 block)
 {
     // close end + far end in one launch; PG_SPLIT_LAUNCH=1 runs the two seams as separate launches
-    const bool fused = getenv("PG_SPLIT_LAUNCH") == nullptr;
+    const bool fused = !pg_env_switches()->split_launch;
     if (mode == PG_MODE_BOTH && fused) {
         hipLaunchKernelGGL((pg_search_kernel<NB, NS, Id, PG_MODE_BOTH, DEF>), grid, block, lds_pad, st,
                            *ref, *prm, *batch, max_len, levels);
@@ -2347,7 +2426,7 @@ static void launch_ns(const PgDevRef *ref, const PgDevParams *prm, const PgDevBa
     if (PG_WIN_DYN_BYTES(NB) != 0u && prm->max_range_index >= 3) lds_pad += PG_WIN_DYN_BYTES(NB);   // two chunks per fill need their LDS
     // Pindel's default parameters have kernels of their own (see PRM): up to 16 mismatch levels, 32-bit candidate ids
     constexpr bool HAS_DEF = NS <= 4 && sizeof(Id) == 4;
-    const bool def = HAS_DEF && getenv("PG_GENERIC_KERNELS") == nullptr && prm->max_range_index == PG_DEF_MAX_RANGE_INDEX &&
+    const bool def = HAS_DEF && !pg_env_switches()->generic_kernels && prm->max_range_index == PG_DEF_MAX_RANGE_INDEX &&
                      prm->add_mm == PG_DEF_ADD_MM && prm->min_perfect == PG_DEF_MIN_PERFECT && prm->min_close == PG_DEF_MIN_CLOSE &&
                      prm->spacer == PG_DEF_SPACER;
     if constexpr (HAS_DEF) {
@@ -2676,7 +2755,7 @@ extern "C" int pg_launch_search(const PgDevRef *ref, const PgDevParams *prm, con
     if (batch->n_reads == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     // experiment knob: extra dynamic LDS per workgroup (lowers occupancy), bytes
-    static const unsigned lds_pad = getenv("PG_LDS_PAD") ? (unsigned)atoi(getenv("PG_LDS_PAD")) : 0u;
+    const unsigned lds_pad = pg_env_switches()->lds_pad;
     // 64-base blocks per read: 1/2/3/4/8 with 32-bit candidate ids (the common case), 2/4/8 with 64-bit ids
     const int nb = max_len <= 128 ? 2 : (max_len <= 256 ? 4 : 8);
 #ifdef PG_ONLY_BENCH

@@ -69,7 +69,21 @@ def random_params(rng, wide=False):
     return kw
 
 
-def one_iteration(seed, n_reads=1500, verbose=True):
+def one_iteration(seed, n_reads=1500, verbose=True, generic=False):
+    """generic=True forces the generic kernel family (PG_GENERIC_KERNELS=1) for this iteration; otherwise the launch picks the
+    default-parameter kernels whenever the parameters equal Pindel's defaults."""
+    if generic:
+        old = os.environ.get("PG_GENERIC_KERNELS")
+        os.environ["PG_GENERIC_KERNELS"] = "1"
+        binding.reload_env()
+        try:
+            return one_iteration(seed, n_reads, verbose)
+        finally:
+            if old is None:
+                del os.environ["PG_GENERIC_KERNELS"]
+            else:
+                os.environ["PG_GENERIC_KERNELS"] = old
+            binding.reload_env()
     rng = np.random.default_rng(seed)
     length = int(rng.integers(150_000, 400_000))
     ref = nasty_reference(rng, length)
@@ -153,7 +167,11 @@ def one_iteration(seed, n_reads=1500, verbose=True):
 if __name__ == "__main__":
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    quiet = os.environ.get("FUZZ_QUIET") is not None          # one summary line per call (the committed fuzz log)
+    both = os.environ.get("FUZZ_BOTH_FAMILIES") is not None   # default-parameter seeds also through the generic kernels
     for s in range(first, first + iters):
-        if not one_iteration(s):
+        if not one_iteration(s, verbose=not quiet):
             sys.exit(1)
-    print("all", iters, "iterations bit-exact")
+        if both and not one_iteration(s, verbose=False, generic=True):
+            sys.exit(1)
+    print("seeds", first, "..", first + iters - 1, ":", iters, "iterations bit-exact" + (" (both kernel families)" if both else ""))

@@ -10,9 +10,9 @@ pytestmark = pytest.mark.gpu
 # 61026: a close-end window (R = 1) that starts exactly where the innermost far-end chunk starts -- the chunk
 # must be re-staged to its full extent before the filter masks of all nested ranges are computed
 # 5002 / 5015 / 5027: -x 3 / 4, the state-dependent bound of the seed filter (a DPP shift under a diverged EXEC mask
-# once made it too tight); 1011 / 8018 / 200203: more than 64 survivors in the first of two paired chunks of a wide
+# once made it too tight; 5011 / 5026 failed with them in round 2); 1011 / 8018 / 200203: more than 64 survivors in the first of two paired chunks of a wide
 # far-end window (the rest of the first half must be queued before the second half is filtered)
-@pytest.mark.parametrize("seed", [1000, 1006, 1011, 1015, 1020, 1029, 1038, 2024, 61026, 5002, 5015, 5027, 8018, 200203])
+@pytest.mark.parametrize("seed", [1000, 1006, 1011, 1015, 1020, 1029, 1038, 2024, 61026, 5002, 5011, 5015, 5026, 5027, 8018, 200203])
 def test_fuzz_seed(seed):
     assert one_iteration(seed, verbose=False)
 
@@ -38,3 +38,13 @@ def test_fuzz_block_wide(block):
 def test_fuzz_block_default_parameters(block):
     for seed in range(300000 + 10 * block, 300010 + 10 * block):
         assert one_iteration(seed, verbose=False), seed
+
+
+# ... and 30 more default-parameter seeds through BOTH kernel families on the same inputs and the same oracle: the kernels compiled for
+# Pindel's default parameter set (what the launch picks) and, forced with PG_GENERIC_KERNELS=1, the generic ones that every other
+# parameter set runs
+@pytest.mark.parametrize("block", range(3))
+def test_fuzz_block_both_kernel_families(block):
+    for seed in range(300100 + 10 * block, 300110 + 10 * block):
+        assert one_iteration(seed, verbose=False), seed
+        assert one_iteration(seed, verbose=False, generic=True), (seed, "generic kernels")

@@ -239,30 +239,30 @@ def test_long_reads_and_wide_close_windows(engine_factory, small_ref):
     compare_result(gpu, orc, batch.n)
 
 
-def test_pool_overflow_is_retried_on_the_gpu(engine_factory, small_ref, monkeypatch):
+def test_pool_overflow_is_retried_on_the_gpu(engine_factory, small_ref, pg_env):
     """A pool that is far too small makes the launch repeat with a regrown pool; results unchanged."""
     eng = engine_factory()
     eng.load_reference(small_ref)
     batch = synth.make_reads(small_ref[0][1], 5000, seed=14)
     orc = run_oracle({}, small_ref, batch)
-    monkeypatch.setenv("PG_TEST_TINY_POOL", "1")
+    pg_env.set("PG_TEST_TINY_POOL", "1")
     gpu = eng.search_batch(batch)
     compare_result(gpu, orc, batch.n)
 
 
-def test_delivery_overflow_falls_back_to_the_whole_batch_download(engine_factory, small_ref, monkeypatch):
+def test_delivery_overflow_falls_back_to_the_whole_batch_download(engine_factory, small_ref, pg_env):
     """The chunk-by-chunk delivery of pg_search_batch has room for three runs per read and list; a batch that needs more
     is downloaded the whole-batch way instead (forced here with room for half a run per read)."""
     eng = engine_factory()
     eng.load_reference(small_ref)
     batch = synth.make_reads(small_ref[0][1], 5000, seed=15)
     orc = run_oracle({}, small_ref, batch)
-    monkeypatch.setenv("PG_TEST_TINY_DELIVERY", "1")
+    pg_env.set("PG_TEST_TINY_DELIVERY", "1")
     compare_result(eng.search_batch(batch), orc, batch.n)
     compare_result(eng.close_end_batch(batch), orc, batch.n, check_far=False)
 
 
-def test_one_block_delivery_equals_chunked_delivery(engine_factory, small_ref, monkeypatch):
+def test_one_block_delivery_equals_chunked_delivery(engine_factory, small_ref, pg_env):
     """A batch of one chunk (Pindel's own flush size) comes back in ONE device-to-host copy, the result's arrays being views
     into one pinned block; the same batch through the copy-per-array path and through seven small chunks gives the same
     result, and the views behave as results do (pg_far_end_batch extends a close result in place)."""
@@ -274,31 +274,31 @@ def test_one_block_delivery_equals_chunked_delivery(engine_factory, small_ref, m
     close = eng.close_end_batch(batch)
     compare_result(close, orc, batch.n, check_far=False)
     compare_result(eng.far_end_batch(batch, close), orc, batch.n)
-    monkeypatch.setenv("PG_NO_SINGLE_BLOCK", "1")
+    pg_env.set("PG_NO_SINGLE_BLOCK", "1")
     compare_result(eng.search_batch(batch), orc, batch.n)
-    monkeypatch.delenv("PG_NO_SINGLE_BLOCK")
-    monkeypatch.setenv("PG_HOST_CHUNK", "1000")
+    pg_env.unset("PG_NO_SINGLE_BLOCK")
+    pg_env.set("PG_HOST_CHUNK", "1000")
     compare_result(eng.search_batch(batch), orc, batch.n)
     close = eng.close_end_batch(batch)
     compare_result(eng.far_end_batch(batch, close), orc, batch.n)
 
 
-def test_wide_cells_and_split_launches(engine_factory, small_ref, monkeypatch):
+def test_wide_cells_and_split_launches(engine_factory, small_ref, pg_env):
     """The 64-bit candidate ids and the two-launch form (close kernel, then far kernel) on a default
     workload give the same result as the default (32-bit ids, one fused launch)."""
     eng = engine_factory()
     eng.load_reference(small_ref)
     batch = synth.make_reads(small_ref[0][1], 3000, seed=15)
     orc = run_oracle({}, small_ref, batch)
-    monkeypatch.setenv("PG_FORCE_WIDE_CELLS", "1")
+    pg_env.set("PG_FORCE_WIDE_CELLS", "1")
     compare_result(eng.search_batch(batch), orc, batch.n)
-    monkeypatch.delenv("PG_FORCE_WIDE_CELLS")
-    monkeypatch.setenv("PG_SPLIT_LAUNCH", "1")
+    pg_env.unset("PG_FORCE_WIDE_CELLS")
+    pg_env.set("PG_SPLIT_LAUNCH", "1")
     compare_result(eng.search_batch(batch), orc, batch.n)
 
 
 @pytest.mark.parametrize("read_len", [100, 150, 250])
-def test_generic_kernels_on_the_default_parameters(engine_factory, small_ref, monkeypatch, read_len):
+def test_generic_kernels_on_the_default_parameters(engine_factory, small_ref, pg_env, read_len):
     """Pindel's default parameter set runs kernels compiled with the five parameters as constants (pg_kernels.hip: PRM);
     PG_GENERIC_KERNELS=1 sends the same launch through the kernels every other parameter set uses.  Both equal the oracle,
     fused and as the two seams."""
@@ -308,7 +308,7 @@ def test_generic_kernels_on_the_default_parameters(engine_factory, small_ref, mo
     orc = run_oracle({}, small_ref, batch)
     for generic in (False, True):
         if generic:
-            monkeypatch.setenv("PG_GENERIC_KERNELS", "1")
+            pg_env.set("PG_GENERIC_KERNELS", "1")
         compare_result(eng.search_batch(batch), orc, batch.n)
         close = eng.close_end_batch(batch)
         compare_result(close, orc, batch.n, check_far=False)

@@ -6,12 +6,16 @@ sequences and "has a far end", it must reproduce the gold file.
 
 Result: 7 of the 8 gold LI events byte for byte (798 read lines); the eighth (LI 6) keeps 2 of its 8 '-' reads.  The six
 others -- @130387/1 (twice, anchor 130237), @130388/1 (three times), @130388/2 -- get a close end at AbsLoc 229500 and a
-13/14-base far end at 230000 from the Pindel-text input, so they are not LI material; in the gold run (BAM input, not in
-the snapshot) their last close-end point was 230644 like their neighbours'.  That points at the input route rather than
-the search: SURVEY.md section 8c ran the reference BINARY ITSELF on this text input and found _D/_SI/_TD/_INV identical
-to gold and _LI different "in 8 lines" (cause not investigated there); this restatement differs in 7 (one header, six
-reads) -- consistent with the same cause, though the survey's diff is not in the snapshot to compare line by line.
-The test asserts exactly that difference and nothing else.
+13/14-base far end at 230000 from the Pindel-text input, so they are not LI material.  What the GOLD run had for them is read
+off the gold file's own bytes (`_gold_close_end_of_the_excluded_reads`): SortOutputLI prints a '-' read indented by
+ReportLength + LengthStr - ReadLength under a reference line whose column ReportLength is the event's '-' position
+(src/reporter.cpp:2095-2130), so the indentation IS UP_Close.back().LengthStr (12 and 11 bases), the header's '-' field
+(130645) IS UP_Close.back().AbsLoc - spacer + 1, i.e. AbsLoc 230644 like their two neighbours that stay, and the read's last
+LengthStr bases lie on the upper-case reference bases printed above them (two mismatches in twelve).  The gold run (BAM input, not in the snapshot) thus
+found a 12/11-base close end at 230644 where the text route finds one at 229500 plus a far end: the input route, not the
+search (the same reads' neighbours come out byte for byte).  SURVEY.md section 8c ran the reference BINARY ITSELF on this text
+input and found _D/_SI/_TD/_INV identical to gold and _LI different "in 8 lines": one changed header (two lines of diff
+output) + six removed read lines = 8 -- exactly the difference this test asserts, and nothing else.
 """
 import gzip
 import os
@@ -36,6 +40,34 @@ def _records(reads_txt):
         d, chrom, pos, ms, isz, tag = lines[i + 2].split()
         recs.append((lines[i], lines[i + 1], d, chrom, int(pos), int(ms), int(isz), tag))
     return recs
+
+
+def _gold_close_end_of_the_excluded_reads():
+    """(AbsLoc, [LengthStr per read]) of UP_Close.back() of the six reads in the GOLD run, from the gold _LI bytes alone."""
+    gold = gzip.open(os.path.join(gu.GOLD, "simulated_test.out_LI.gz")).read().split(b"\n")
+    k = next(i for i, l in enumerate(gold) if l.startswith(b"6\tLI\t"))
+    minus_field = int(gold[k].split(b"\t")[5])                     # "... + 4 <TAB> 130645 <TAB> - 8 ..."
+    assert gold[k].split(b"\t")[6] == b"- 8"
+    sep = next(i for i in range(k, len(gold)) if gold[i].startswith(b"-----"))
+    ref_line = gold[sep + 1]
+    report_length = len(ref_line) // 2
+    assert ref_line[:report_length].islower() and ref_line[report_length:].isupper()
+    lens, stay = [], []
+    for line in gold[sep + 2:]:
+        if line.startswith(b"####"):
+            break
+        f = line.split(b"\t")
+        seq = f[0].rstrip(b"-")                                       # (no tab before MatchedD: reporter.cpp:2124)
+        indent = len(seq) - len(seq.lstrip(b" "))
+        read = seq.strip(b" ")
+        length_str = indent - report_length + len(read)               # indentation = ReportLength + LengthStr - ReadLength
+        # the read's last LengthStr bases lie on the upper-case half of the reference line: columns ReportLength ...
+        # (a close end may carry mismatches: two in these twelve bases)
+        tail, under = read[len(read) - length_str:], ref_line[report_length:report_length + length_str]
+        assert len(tail) == len(under) == length_str and sum(a != b for a, b in zip(tail, under)) <= 2
+        (lens if (f[4].decode(), int(f[1])) in NOT_LI_ON_THE_TEXT_ROUTE else stay).append(length_str)
+    assert len(lens) == 6 and len(stay) == 2
+    return minus_field - 1 + li.SPACER, lens, stay
 
 
 def _expected_on_the_text_route():
@@ -86,8 +118,13 @@ def _check(text, odd, reads):
     assert len(got) == len(want)
     for k, (a, b) in enumerate(zip(got, want)):
         assert a == b, f"_LI line {k + 1}:\n got  {a[:160]!r}\n gold {b[:160]!r}"
-    # the six reads that are in gold's LI 6 and not in ours: a far end keeps them out (see the module docstring)
+    # the six reads that are in gold's LI 6 and not in ours: a far end keeps them out (see the module docstring); in the gold run
+    # -- read off the gold bytes -- their last close-end point was AbsLoc 230644 with 12 / 11 bases, like the two that stay
     assert len(odd) == 6 and all(x.has_far and x.close_abs == 229500 for x in odd)
+    gold_abs, gold_lens, stay_lens = _gold_close_end_of_the_excluded_reads()
+    assert gold_abs == 230644 and sorted(gold_lens) == [11, 11, 11, 11, 12, 12] and sorted(stay_lens) == [12, 12]
+    kept = [x for x in reads if (x.name, x.pos) in {("@130387/1", 130337), ("@130387/2", 130337)} and x.strand == "-" and not x.has_far]
+    assert kept and all(x.close_abs == gold_abs for x in kept)       # the neighbours: the same close end as in gold, from this search
     assert sum(1 for l in got if l.count(b"\t") == 5 or (l.count(b"\t") == 4 and l.split(b"\t")[0].endswith((b"-", b"+")))) == 814
 
 
