@@ -152,7 +152,7 @@ def pack_roofline(batch, pack_ms):
     lens = batch.lengths()
     ml = int(lens.max()) if batch.n else 1
     blocks = 1 if ml <= 64 else 2 if ml <= 128 else 3 if ml <= 192 else 4 if ml <= 256 else 8
-    nbytes = float(lens.sum()) + batch.n * (8 + 11 + 64 * blocks + 32)
+    nbytes = float(lens.sum()) + batch.n * (8 + 11 + 64 * blocks + 64)     # offsets + SoA fields in; bit planes + the 64-byte record out
     achieved = nbytes / (pack_ms * 1e-3) / 1e9 if pack_ms > 0 else 0.0
     return {"bound": "hbm", "kernel": "pg_pack_kernel", "kernel_ms": pack_ms, "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes, "traffic": None}
@@ -367,7 +367,7 @@ def main():
     # records the search kernel reads) runs once at upload, before the timed region; its own duration on this batch, HIP
     # events on the ctx's stream, goes on the record beside `value` (config.pack_ms_per_step, config.value_incl_pack,
     # roofline.pack).  Bytes per read: len + 8 (offset) + 11 (strand, position, insert size, chromosome) in, 64 x blocks
-    # (planes) + 32 (record) out.
+    # (planes) + 64 (record) out.
     pack_ms = min(eng.repack(dbatch) for _ in range(5))
     if bins is not None:
         eng.search_device(dbatch)                 # the whole batch once, for the accounting below (same reads)

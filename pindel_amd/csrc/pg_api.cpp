@@ -645,7 +645,7 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, HostBuf<uint
     const Item items[] = {
         { (void **)&b->seq, (size_t)nseq + 16 }, { (void **)&b->seq_off, (n + 1) * 8 },
         { (void **)&b->strand, n1 }, { (void **)&b->pos, n1 * 4 }, { (void **)&b->isz, n1 * 2 }, { (void **)&b->chr, n1 * 4 },
-        { (void **)&b->in_rec, n1 * sizeof(PgInRec) },
+        { (void **)&b->in_rec, (n1 + PG_IN_PAD) * sizeof(PgInRec) },    // (+ the records the kernel's prefetch may touch behind the last read)
         { (void **)&b->planes, n1 * 64 * pg_plane_blocks(max_len) },
         { (void **)&b->pool, (size_t)b->pool_shard_cap * PG_POOL_SHARDS * sizeof(pg_run) },
         // ---- zero-initialised from here
@@ -731,7 +731,11 @@ PgSoaIn soa_in(const pg_ctx *ctx, const pg_device_batch *b)
     a.bd_off = b->bd_off;
     a.mm = ctx->d_mm;
     a.thr = ctx->d_thr;
+    a.chr_word_off = ctx->d_word_off;
+    a.chr_size = ctx->d_chr_size;
     a.spacer = ctx->prm.spacer;
+    a.add_mm = ctx->prm.additional_mismatch;
+    a.min_close = ctx->prm.min_close;
     return a;
 }
 
@@ -801,6 +805,7 @@ PgDevBatch dev_batch(const pg_device_batch *b)
     d.pool_shard_cap = b->pool_shard_cap;
     d.pool_used = b->pool_used;
     d.work_ctr = b->pool_used + PG_POOL_SHARDS * 16;
+    d.claim = PG_CLAIM_DEFAULT;        // (pg_launch_search sets it from the launch's grid)
     return d;
 }
 

@@ -35,21 +35,44 @@ struct PgDevParams {
 
 enum PgMode { PG_MODE_CLOSE = 1, PG_MODE_FAR = 2, PG_MODE_BOTH = 3 };
 
-// Packed per-read records (32 bytes each, one scalar load / two vector stores per read in the search
-// kernel).  pg_pack_reads builds the input records on the device from the SoA arrays of the C ABI;
+// Packed per-read records.  pg_pack_reads builds the input records on the device from the SoA arrays of the C ABI;
 // pg_unpack_results scatters the output records back into SoA arrays for the CSR scan / download.
+//
+// The input record is 64 bytes = one line of the scalar data cache: the search kernel fetches it with scalar loads straight
+// into SGPRs, and it holds everything about a read that is a function of (read, parameters) alone, worked out ONCE by the pack
+// kernel -- a streaming kernel with every lane busy -- instead of by every wave's scalar unit at the start of every read (round 5:
+// profiles/r05/everything_else_breakdown.txt; the CU's one scalar unit is the search kernel's tightest pipe):
+//   * the close end's windows: GetCloseEndInner's (pindel.cpp:2250-2326) R = 1 window is [w1s, w1s + 3 isz), its R = 0 window
+//     [w1s + isz, w1s + 2 isz) whichever the anchor's strand (w1s = anchor - isz for '+', anchor - 2 isz for '-'); whether the
+//     R = 1 window fits one LDS chunk (all four attempts on one grid); the first window fill;
+//   * the word offset and size of the anchor's chromosome (no table look-up, no fallback path);
+//   * T = g_maxMismatch[len] + ADDITIONAL_MISMATCH + 1 mismatch levels, CheckMismatches' threshold, the seed filter's two
+//     depths J (plain / wide windows) with their base masks bits [1, J) and relevance bounds min(T - 1, g_maxMismatch[J] + ADD);
+//   * is the first consumed base of either orientation one of ACGT (farend_searcher.cpp:60-66; searcher.cpp:160).
+#define PG_RF_CLOSE_OK 1u       // the close end is searched: len - 1 >= g_MinClose and MatchedD is '+' or '-'
+#define PG_RF_PLUS 2u           // MatchedD == '+'
+#define PG_RF_SHARED_GRID 4u    // 0 < 3 InsertSize <= PG_CHUNK
+#define PG_RF_FIRST_OK_FWD 8u   // read[0] is one of ACGT (orientation 0: left to right)
+#define PG_RF_FIRST_OK_REV 16u  // read[len - 1] is (orientation 1: from the last base)
 struct PgInRec {
-    uint64_t seq_off;       // offset of the read's bases in PgDevBatch::seq
-    int32_t  apos;          // anchor position + spacer (AbsLoc of MatchedRelPos)
+    // dwords 0 .. 11: fetched at the start of a read
+    int32_t  w1s;           // AbsLoc where the close end's R = 1 window starts
+    int32_t  isz;           // InsertSize
+    int32_t  stage_s, stage_e;   // the first window fill covers positions [stage_s, stage_e) (+ overhangs); 0, 0: none
+    uint32_t chr_wo_lo, chr_wo_hi;   // index of the word holding AbsLoc 0 of the anchor's chromosome in the reference planes
+    uint32_t lenf;          // read length | PG_RF_* << 16
+    uint32_t lvl;           // CheckMismatches' threshold (smallest n with (float)n >= (float)(len * u)) | g_maxMismatch[len] << 16 | T << 24
+    uint32_t depth;         // J plain | J wide << 8 | bound plain << 16 | bound wide << 24
+    uint32_t jmask0, jmask1;     // bits [1, J plain), [1, J wide)
     int32_t  chr;           // chromosome of the anchor
-    uint16_t len;           // read length (<= PG_MAX_READ_LEN)
-    int16_t  isz;           // InsertSize
-    uint16_t thr;           // CheckMismatches: smallest n with (float)n >= (float)(len * u)
-    uint8_t  strand;        // MatchedD
-    uint8_t  M;             // g_maxMismatch[len]
+    // dwords 12 .. 15: fetched at the start of the far end
+    uint32_t chr_size;      // getCompSize() of that chromosome
     uint32_t bd_cnt;        // BreakDancer windows of this read ...
     uint32_t bd_off;        // ... starting at PgDevBatch::bd[bd_off]
+    uint32_t pad;
 };
+#define PG_CLAIM_DEFAULT 8u  // reads a workgroup of the persistent launch claims per atomic, at most
+#define PG_IN_PAD 8u        // records allocated behind the last one (the kernel prefetches the next read's record)
 struct PgOutRec {
     uint32_t close_off, close_cnt, far_off, far_cnt;   // runs in the pool
     uint32_t close_last;    // getLastAbsLocCloseEnd()
@@ -80,6 +103,7 @@ struct PgDevBatch {
     uint32_t pool_shard_cap;       // runs per shard
     uint32_t *pool_used;           // [PG_POOL_SHARDS * 16]; cursor > pool_shard_cap means overflow (retry bigger)
     uint32_t *work_ctr;            // [PG_WORK_CTRS * 16] reads claimed per XCD part (zeroed before every launch)
+    uint32_t claim;                // reads per claim (set by pg_launch_search: a workgroup's share in the fewest equal claims <= PG_CLAIM)
 };
 
 // SoA views for the pack / unpack kernels
@@ -99,8 +123,29 @@ struct PgSoaIn {
     const uint64_t *bd_off;        // nullable
     const uint32_t *mm;            // [512] g_maxMismatch
     const uint16_t *thr;           // [512]
+    const uint64_t *chr_word_off;  // [n_chr] as PgDevRef
+    const uint32_t *chr_size;      // [n_chr]
     uint32_t spacer;
+    int32_t add_mm;                // ADDITIONAL_MISMATCH
+    int32_t min_close;             // g_MinClose
 };
+// consumed bases the seed filter inspects for a read of `len` bases with T mismatch levels (wide: the chunks of wide far-end
+// windows, where a survivor costs a whole candidate pass for a handful of candidates: two more)
+#ifndef PG_SEED_J
+#define PG_SEED_J(T) (2 * (T) + 4)
+#endif
+#ifndef PG_SEED_J_WIDE
+#define PG_SEED_J_WIDE 2
+#endif
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline int pg_seed_depth(int len, int T, int wide)
+{
+    int J = len - 1 < 32 ? len - 1 : 32;
+    const int jt = PG_SEED_J(T) + (wide ? PG_SEED_J_WIDE : 0);
+    return J > jt ? jt : J;
+}
 struct PgSoaOut {
     uint8_t *rc_flag;
     uint32_t *close_last;

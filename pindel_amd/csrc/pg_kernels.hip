@@ -52,6 +52,8 @@
 
 typedef unsigned long long u64;
 typedef unsigned int u32;
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));       // (scalar-load destinations)
+typedef u32 u32x8 __attribute__((ext_vector_type(8)));
 
 // KERNEL ARGUMENTS ON DEMAND.  The kernel's by-value arguments (reference planes, parameters, batch: ~45 dwords of pointers
 // and sizes) are used a handful of times per read, but as ordinary arguments they sit in scalar registers from the first
@@ -133,8 +135,6 @@ __device__ __forceinline__ void karg_load3(T &a, T &b, T &c)
 #define PG_CLAIM 8u         // reads claimed per atomic
 #endif
 #define PG_BIG 0xffffu      // "no candidate" level
-// reads of up to 256 bases: the records of a claim are fetched at once into LDS (longer reads have no LDS to spare)
-#define PG_REC_LDS(nb) ((nb) <= 4)
 #define PG_CHR_TAB 24       // chromosomes whose word offset / size are kept in LDS (a read's first dependent load otherwise)
 #define PG_MM_IN_WIN(nb) ((nb) <= 4)
 
@@ -342,7 +342,6 @@ struct Lds {
     uint8_t mm_tab[PG_MM_IN_WIN(NB) ? 4 : 64 * NB + 64];
     uint2 chr_tab[PG_CHR_TAB];                // word offset and size of the first PG_CHR_TAB chromosomes (size 0: not in the table --
                                               // its word offset does not fit 32 bits)
-    uint4 rec[PG_REC_LDS(NB) ? 2 * PG_CLAIM : 0];   // the packed records of the claimed reads (one coalesced load per claim)
 #ifdef PG_TIMING
     u64 t_last;
     u32 t_acc[12];
@@ -364,8 +363,9 @@ struct Search {
     void *accB;
     const uint8_t *mm_tab;
     const uint2 *chr_tab;
-    int mm_j[2];         // g_maxMismatch[J] for the two filter depths J of this read (plain, wide): once per read
-    const uint4 *rec;    // PG_REC_LDS: the claim's records in LDS    // LDS copy of PgDevParams::mm_bp
+    // the seed filter's two depths of this read (plain, wide windows), from the read's record: `depth` = J plain | J wide << 8 |
+    // bound plain << 16 | bound wide << 24 (bound = min(T - 1, g_maxMismatch[J] + ADD)), jmask = bits [1, J)
+    u32 depth, jmask[2];
     // what the LDS window currently holds: bases [win_lo, win_hi) of the chromosome whose AbsLoc 0 is
     // at word index win_wo; the first staged base is wbase = win_lo (any alignment)
     long long win_wo;
@@ -760,8 +760,12 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
 // Stages bases [lo, hi) (hi - lo <= PG_CHUNK + 128 NB) of a chromosome into LDS: word i of the window
 // holds bases [lo + 32 i, lo + 32 i + 32) whatever the alignment of lo (funnel shift of two HBM words), as
 // the code planes (lo, hi, N) that both the candidate pass and the seed filter read.
+// next_rec (first fill of a read only): the NEXT read's record is touched with a one-dword scalar load issued beside the window's
+// HBM loads and waited for with them -- its 64-byte line is then in the scalar cache (or at least in L2) when the next read
+// starts with it.  (Anywhere else an outstanding scalar load would stall the next LDS wait: lgkmcnt counts both.)
 template <int NB>
-__device__ __forceinline__ void stage_window(const PgDevRef &ref, Search &S, long long wo, int lo, int hi, int lane)
+__device__ __forceinline__ void stage_window(const PgDevRef &ref, Search &S, long long wo, int lo, int hi, int lane,
+                                             const PgInRec *next_rec = nullptr)
 {
     const int nw = ((hi - lo + 31) >> 5) + 2;
     const u32 sh = (u32)(lo & 31);
@@ -780,6 +784,15 @@ __device__ __forceinline__ void stage_window(const PgDevRef &ref, Search &S, lon
             const bool two = j < nw;
             const u32 oi = 4u * (u32)i, oj = 4u * (u32)(two ? j : i);
             u64 a, b, c, d, e, f;
+            if (next_rec) {
+                u32 touched;
+                asm volatile("global_load_dwordx2 %[a], %[oi], %[glo]\n\tglobal_load_dwordx2 %[b], %[oi], %[ghi]\n\tglobal_load_dwordx2 %[c], %[oi], %[gnn]\n\t"
+                             "global_load_dwordx2 %[d], %[oj], %[glo]\n\tglobal_load_dwordx2 %[e], %[oj], %[ghi]\n\tglobal_load_dwordx2 %[f], %[oj], %[gnn]\n\t"
+                             "s_load_dword %[t], %[nr], 0x0\n\t"
+                             "s_waitcnt vmcnt(0) lgkmcnt(0)"
+                             : [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [d] "=&v"(d), [e] "=&v"(e), [f] "=&v"(f), [t] "=&s"(touched)
+                             : [oi] "v"(oi), [oj] "v"(oj), [glo] "s"(glo), [ghi] "s"(ghi), [gnn] "s"(gnn), [nr] "s"(next_rec) : "memory");
+            } else
             asm volatile("global_load_dwordx2 %0, %6, %8\n\tglobal_load_dwordx2 %1, %6, %9\n\tglobal_load_dwordx2 %2, %6, %10\n\t"
                          "global_load_dwordx2 %3, %7, %8\n\tglobal_load_dwordx2 %4, %7, %9\n\tglobal_load_dwordx2 %5, %7, %10\n\t"
                          "s_waitcnt vmcnt(0)"
@@ -806,19 +819,7 @@ __device__ __forceinline__ u32 bits32(int lo, int hi)      // bits [lo,hi), clam
     return low32(hi) & ~low32(lo);
 }
 
-#ifndef PG_SEED_J
-#define PG_SEED_J(T) (2 * (T) + 4)     // consumed bases the seed filter looks at
-#endif
-#ifndef PG_SEED_J_WIDE
-#define PG_SEED_J_WIDE 2
-#endif
-// consumed bases the seed filter inspects for a read of `len` bases with T levels
-__device__ __forceinline__ int seed_depth(int len, int T, bool wide)
-{
-    int J = len - 1 < 32 ? len - 1 : 32;
-    const int jt = PG_SEED_J(T) + (wide ? PG_SEED_J_WIDE : 0);
-    return J > jt ? jt : J;
-}
+// (consumed bases the seed filter inspects: pg_seed_depth, pg_device.h -- the pack kernel puts them into the read's record)
 
 // positions whose bit-sliced mismatch count (c[NS-1] .. c0, ov = overflowed) is <= thr (wave-uniform, >= 0).
 // "count <= constant" is a fixed boolean function of the slices: the low three slices against thr & 7 are ONE v_bitop3
@@ -1024,46 +1025,6 @@ struct Counter {
                 : PG_CTR5, [ta] "=&s"(ta), [tb] "=&s"(tb), [tc] "=&s"(tc), [ma] "=&v"(ma), [mb] "=&v"(mb), [mc] "=&v"(mc),
                   [s0] "=&v"(s0), [s1] "=&v"(s1), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES, [ja] "s"(ja), [jb] "s"(jb), [jc] "s"(jc) : "scc");
     }
-    // --- base(s) whose shift is known already (a second window word of the same lane: see seed_filter_pair)
-    __device__ __forceinline__ void shift1(u32 lo, u32 hi, u32 ja)
-    {
-        u32 ma, k0, k1;
-        if (NS == 3)
-            asm(PG_SHIFT("ma", "ja") PG_ADD1 PG_UP3 : PG_CTR3, [ma] "=&v"(ma), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES, [ja] "s"(ja));
-        else if (NS == 4)
-            asm(PG_SHIFT("ma", "ja") PG_ADD1 PG_UP4 : PG_CTR4, [ma] "=&v"(ma), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES, [ja] "s"(ja));
-        else
-            asm(PG_SHIFT("ma", "ja") PG_ADD1 PG_UP5 : PG_CTR5, [ma] "=&v"(ma), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES, [ja] "s"(ja));
-    }
-    __device__ __forceinline__ void shift2(u32 lo, u32 hi, u32 ja, u32 jb)
-    {
-        u32 ma, mb, s0, k0, k1;
-        if (NS == 3)
-            asm(PG_SHIFT("ma", "ja") PG_SHIFT("mb", "jb") PG_ADD2 PG_UP3
-                : PG_CTR3, [ma] "=&v"(ma), [mb] "=&v"(mb), [s0] "=&v"(s0), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES, [ja] "s"(ja), [jb] "s"(jb));
-        else if (NS == 4)
-            asm(PG_SHIFT("ma", "ja") PG_SHIFT("mb", "jb") PG_ADD2 PG_UP4
-                : PG_CTR4, [ma] "=&v"(ma), [mb] "=&v"(mb), [s0] "=&v"(s0), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES, [ja] "s"(ja), [jb] "s"(jb));
-        else
-            asm(PG_SHIFT("ma", "ja") PG_SHIFT("mb", "jb") PG_ADD2 PG_UP5
-                : PG_CTR5, [ma] "=&v"(ma), [mb] "=&v"(mb), [s0] "=&v"(s0), [k0] "=&v"(k0), [k1] "=&v"(k1) : PG_PLANES, [ja] "s"(ja), [jb] "s"(jb));
-    }
-    __device__ __forceinline__ void shift3(u32 lo, u32 hi, u32 ja, u32 jb, u32 jc)
-    {
-        u32 ma, mb, mc, s0, s1, k0, k1;
-        if (NS == 3)
-            asm(PG_SHIFT("ma", "ja") PG_SHIFT("mb", "jb") PG_SHIFT("mc", "jc") PG_ADD3 PG_UP3
-                : PG_CTR3, [ma] "=&v"(ma), [mb] "=&v"(mb), [mc] "=&v"(mc), [s0] "=&v"(s0), [s1] "=&v"(s1), [k0] "=&v"(k0), [k1] "=&v"(k1)
-                : PG_PLANES, [ja] "s"(ja), [jb] "s"(jb), [jc] "s"(jc));
-        else if (NS == 4)
-            asm(PG_SHIFT("ma", "ja") PG_SHIFT("mb", "jb") PG_SHIFT("mc", "jc") PG_ADD3 PG_UP4
-                : PG_CTR4, [ma] "=&v"(ma), [mb] "=&v"(mb), [mc] "=&v"(mc), [s0] "=&v"(s0), [s1] "=&v"(s1), [k0] "=&v"(k0), [k1] "=&v"(k1)
-                : PG_PLANES, [ja] "s"(ja), [jb] "s"(jb), [jc] "s"(jc));
-        else
-            asm(PG_SHIFT("ma", "ja") PG_SHIFT("mb", "jb") PG_SHIFT("mc", "jc") PG_ADD3 PG_UP5
-                : PG_CTR5, [ma] "=&v"(ma), [mb] "=&v"(mb), [mc] "=&v"(mc), [s0] "=&v"(s0), [s1] "=&v"(s1), [k0] "=&v"(k0), [k1] "=&v"(k1)
-                : PG_PLANES, [ja] "s"(ja), [jb] "s"(jb), [jc] "s"(jc));
-    }
 };
 
 // Every base of the (wave-uniform) set pm goes into the counter(s).  Kind F: the base at bit j reads the pair
@@ -1098,13 +1059,13 @@ __device__ __forceinline__ void add_bases(bool group, u32 pm, Counter<NS> &C, u3
 // both masks (mF, mB).  Otherwise the mask of the one kind (kindB) comes back in mF.
 template <int NB, int NS, bool DUAL>
 __device__ __forceinline__ void seed_filter_run(const Search &S, const Query<NB> &Q, bool kindB, int lane,
-                                                int J, int jb, int cap0, u32 &mF, u32 &mB)
+                                                u32 jmask, u32 g0mask, int cap0, u32 &mF, u32 &mB)
 {
+    // jmask = the inspected bases, bits [1, J); g0mask = those before the first evaluated length, bits [1, min(bps, J))
     u32 lo = (u32)uni((int)(u32)q_lo<NB>(Q, 0)), hi = (u32)uni((int)(u32)q_hi<NB>(Q, 0));
     const u32 nn = (u32)uni((int)(u32)q_nn<NB>(Q, 0)), oo = (u32)uni((int)(u32)q_oo<NB>(Q, 0));
     if (DUAL ? Q.cF() : (kindB ? Q.cB() : Q.cF())) { lo = ~lo; hi = ~hi; }
     const u32 acgt = ~(nn | oo);
-    const u32 jmask = bits32(1, J), g0mask = bits32(1, jb);
     // read symbols A C G T N (in the orientation of the single kind / of kind F); bases [1, jb) first,
     // snapshot, then bases [jb, J)
     const u32 sym[5] = { ~lo & ~hi & acgt, lo & ~hi & acgt, ~lo & hi & acgt, lo & hi & acgt, nn };
@@ -1192,11 +1153,11 @@ __device__ __forceinline__ void seed_filter(const Search &S, const Query<NB> &Q,
     }
 #endif
     // bases inspected: two more in the chunks of wide far-end windows, where survivors cost a whole pass of
-    // fold_candidates for a handful of candidates (measured: -4 % time at -x 5, +2 % if used everywhere)
-    const int J = seed_depth(S.len, T, wide);
-    const int jb = S.bps < J ? S.bps : J;
-    int cap0 = S.mm_j[wide ? 1 : 0] + S.add_mm;                    // min(T-1, g_maxMismatch[J] + ADD)
-    if (cap0 > T - 1) cap0 = T - 1;
+    // fold_candidates for a handful of candidates (measured: -4 % time at -x 5, +2 % if used everywhere).  Depths, base masks and
+    // bounds come with the read's record (pg_pack_kernel): bits [1, J), and of those the ones below the first evaluated length
+    const u32 jmask = S.jmask[wide ? 1 : 0];
+    const u32 g0mask = jmask & low32(S.bps);
+    int cap0 = (int)((S.depth >> (wide ? 24 : 16)) & 0xffu);      // min(T - 1, g_maxMismatch[J] + ADD)
     // ... and, once candidates have been folded, min with the state's bound: a seed whose level at bps exceeds
     // (lowest level present at L) + ADD for every L in [bps, J] cannot be the lowest there nor within ADD of it
     // (levels only grow with L); later lengths are covered by the "alive after J bases" test
@@ -1205,110 +1166,7 @@ __device__ __forceinline__ void seed_filter(const Search &S, const Query<NB> &Q,
     // five up to 32 (-e 0.05 on 300-base reads).  NS is a parameter of the launch (the largest T of the batch, `levels`):
     // with all three counter widths behind a run-time switch at every call site the headline kernel was 246 KB of code
     // with 219 SGPR spills and scratch; one width: 100 KB, 200, none.
-    seed_filter_run<NB, NS, DUAL>(S, Q, kindB, lane, J, jb, cap0, mF, mB);
-}
-
-// WIDE FAR-END WINDOWS: two window words per lane (-DPG_PAIR_FILTER; an experiment that is NOT in the shipped build: results
-// identical, -x 5 1.5 % faster, but its four counters cost the fused kernel 17 VGPR spills and scratch, and the default
-// -x 2 path 0.8 % -- profiles/r04/kernel_experiments.txt).  The chunks of a wide window are taken two per LDS fill; lane l filters
-// words 2 l and 2 l + 1 -- 64 positions of each kind -- in ONE walk over the read's bases: the scalar bookkeeping (which base
-// comes next for this symbol, its shift, the mirrored shift: ~110 scalar instructions per run, as many as the vector work
-// of one counter) is paid once for the four counters instead of once per chunk.
-template <int NS>
-__device__ __forceinline__ void add_bases_pair(bool group, u32 pm, Counter<NS> &Fa, u32 fa_lo, u32 fa_hi, Counter<NS> &Ba, u32 ba_lo, u32 ba_hi,
-                                               Counter<NS> &Fb, u32 fb_lo, u32 fb_hi, Counter<NS> &Bb, u32 bb_lo, u32 bb_hi)
-{
-    u32 ja, jb, jc;
-    if (group) {
-        int n = __popc(pm);
-        while (n >= 3) {
-            Fa.take3(pm, fa_lo, fa_hi, ja, jb, jc);
-            Fb.shift3(fb_lo, fb_hi, ja, jb, jc);
-            const u32 ta = 32u - ja, tb = 32u - jb, tc = 32u - jc;
-            Ba.shift3(ba_lo, ba_hi, ta, tb, tc);
-            Bb.shift3(bb_lo, bb_hi, ta, tb, tc);
-            n -= 3;
-        }
-        if (n == 2) {
-            Fa.take2(pm, fa_lo, fa_hi, ja, jb);
-            Fb.shift2(fb_lo, fb_hi, ja, jb);
-            const u32 ta = 32u - ja, tb = 32u - jb;
-            Ba.shift2(ba_lo, ba_hi, ta, tb);
-            Bb.shift2(bb_lo, bb_hi, ta, tb);
-        }
-    }
-    while (pm != 0u) {
-        Fa.take1(pm, fa_lo, fa_hi, ja);
-        Fb.shift1(fb_lo, fb_hi, ja);
-        const u32 ta = 32u - ja;
-        Ba.shift1(ba_lo, ba_hi, ta);
-        Bb.shift1(bb_lo, bb_hi, ta);
-    }
-}
-
-// one-hot plane X (0..3 = A C G T, 4 = not N) of a window word given as code planes
-__device__ __forceinline__ u32 onehot(const uint4 &p, int X)
-{
-    switch (X) {
-    case 0: return ~(p.x | p.y | p.z);
-    case 1: return p.x & ~(p.y | p.z);
-    case 2: return p.y & ~(p.x | p.z);
-    case 3: return p.x & p.y & ~p.z;
-    default: return ~p.z;
-    }
-}
-
-// both kinds of the window words 2 `lane` and 2 `lane` + 1 of the LDS window (a chunk pair = 128 words): as two calls of
-// seed_filter<NB, NS, true>(.., wide = true, word, ..), bit for bit.  Adjacent words, not words 64 apart: the four counters
-// then read four window words (previous, own two, next) instead of six, which is what keeps them in registers.
-template <int NB, int NS>
-__device__ __forceinline__ void seed_filter_pair(const Search &S, const Query<NB> &Q, int lane, u32 &mFa, u32 &mBa, u32 &mFb, u32 &mBb)
-{
-    const int T = S.T;
-    PG_DG(const_cast<Search &>(S), 8);
-    PG_DG(const_cast<Search &>(S), 8);
-    const int J = seed_depth(S.len, T, true);
-    const int jb = S.bps < J ? S.bps : J;
-    int cap0 = S.mm_j[1] + S.add_mm;
-    if (cap0 > T - 1) cap0 = T - 1;
-    if (cap0 > S.cap_state) cap0 = S.cap_state;
-    u32 lo = (u32)uni((int)(u32)q_lo<NB>(Q, 0)), hi = (u32)uni((int)(u32)q_hi<NB>(Q, 0));
-    const u32 nn = (u32)uni((int)(u32)q_nn<NB>(Q, 0)), oo = (u32)uni((int)(u32)q_oo<NB>(Q, 0));
-    if (Q.cF()) { lo = ~lo; hi = ~hi; }
-    const u32 acgt = ~(nn | oo);
-    const u32 jmask = bits32(1, J), g0mask = bits32(1, jb);
-    const u32 sym[5] = { ~lo & ~hi & acgt, lo & ~hi & acgt, ~lo & hi & acgt, lo & hi & acgt, nn };
-    const int a = 2 * NB + 2 * lane;
-    const uint4 wm = S.win[a - 1], w0 = S.win[a], w1 = S.win[a + 1], w2 = S.win[a + 2];      // code planes
-    const int o_pre = __popc(oo & g0mask), o_all = __popc(oo & jmask);
-    Counter<NS> Fa, Ba, Fb, Bb;
-    Fa.reset();
-    Ba.reset();
-    Fb.reset();
-    Bb.reset();
-    u32 snFa = 0u, snBa = 0u, snFb = 0u, snBb = 0u;
-#pragma unroll
-    for (int it = 0; it < 10; it++) {
-        const int X = it >= 5 ? it - 5 : it;
-        const int X2 = X < 4 ? 3 - X : X;                              // the complementary symbol (kind B)
-        if (it == 5) {
-            Fa.template le<true>(Ba, cap0 - o_pre, snFa, snBa);
-            Fb.template le<true>(Bb, cap0 - o_pre, snFb, snBb);
-        }
-        const u32 pm = sym[X] & (it >= 5 ? (jmask & ~g0mask) : g0mask);
-        if (pm == 0u) continue;                                        // uniform
-        const u32 x1 = onehot(w1, X), y0 = onehot(w0, X2);
-        add_bases_pair<NS>(X < 4, pm, Fa, onehot(w0, X), x1, Ba, onehot(wm, X2), y0, Fb, x1, onehot(w2, X), Bb, y0, onehot(w1, X2));
-    }
-    u32 fFa, fBa, fFb, fBb;
-    Fa.template le<true>(Ba, T - 1 - o_all, fFa, fBa);
-    Fb.template le<true>(Bb, T - 1 - o_all, fFb, fBb);
-    // the seed: the position's own base equals the first read base / its complement (kind B)
-    const u32 l0 = (lo & 1u) ? ~0u : 0u, h0 = (hi & 1u) ? ~0u : 0u;
-    mFa = ~((w0.x ^ l0) | (w0.y ^ h0) | w0.z) & (snFa | fFa);
-    mBa = ~((w0.x ^ ~l0) | (w0.y ^ ~h0) | w0.z) & (snBa | fBa);
-    mFb = ~((w1.x ^ l0) | (w1.y ^ h0) | w1.z) & (snFb | fFb);
-    mBb = ~((w1.x ^ ~l0) | (w1.y ^ ~h0) | w1.z) & (snBb | fBb);
+    seed_filter_run<NB, NS, DUAL>(S, Q, kindB, lane, jmask, g0mask, cap0, mF, mB);
 }
 
 // Scan the positions of [s, e) outside [xs, xe) (wo = word index of AbsLoc 0 of the chromosome).
@@ -1355,7 +1213,6 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
             // the rest after the last half
             int h = 0, end = 0, slot = 0;
             u32 mF = 0u, mB = 0u, pos0 = 0u;
-            u32 pF1 = 0u, pB1 = 0u;                           // the second half's masks until the first half's survivors are queued
             for (;;) {
                 while (mF != 0u && slot < WAVE) {
                     const int bit = __ffs((int)mF) - 1;
@@ -1372,17 +1229,7 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
                 int n;
                 if (end >= WAVE) n = WAVE;
                 else if (h < nh) {                            // every survivor so far is queued: the next half
-#ifdef PG_PAIR_FILTER
-                    const int word = nh == 2 ? 2 * lane + h : lane;   // (a pair: the lane's two words are adjacent)
-#else
                     const int word = 64 * h + lane;
-#endif
-#ifdef PG_PAIR_FILTER
-                    if (nh == 2) {                            // both halves in one walk over the read's bases (seed_filter_pair)
-                        if (h == 0) seed_filter_pair<NB, NS>(S, Q, lane, mF, mB, pF1, pB1);
-                        else { mF = pF1; mB = pB1; }
-                    } else
-#endif
                     seed_filter<NB, NS, true>(S, Q, false, true, word, mF, mB);
 #if defined(PG_DUP) && PG_DUP == 3
                     u32 dF, dB;
@@ -1584,7 +1431,7 @@ __device__ __forceinline__ void evaluate(Search &S, const Acc<NB, Id> &A, Eval<N
     if (S.want_cap()) {
         // max over L in [bps, J] of the lowest level present (none present: no bound), + ADD; J as in seed_filter
         // for the chunks of wide windows (the only ones filtered after an evaluation)
-        const int J = seed_depth(S.len, S.T, true);
+        const int J = (int)((S.depth >> 8) & 0xffu);
         u32 v = (S.bps + lane <= J) ? t1 : 0u;
         // (each shift is taken once, outside the select: a DPP read under a diverged EXEC mask sees 0 in the
         // lanes that are switched off)
@@ -1736,6 +1583,15 @@ __device__ __forceinline__ bool first_base_ok(const Query<NB> &Q)
     return (x & 1u) == 0u;
 }
 
+// Address of a read's record for the scalar loads.  Both halves go through readfirstlane (free when the compiler already holds
+// them in scalar registers): left to itself it may do the 64-bit address arithmetic next to the planes' per-lane addresses on the
+// vector unit, and an "s" operand is then printed as a VGPR pair.
+__device__ __forceinline__ const PgInRec *rec_ptr(const PgInRec *in, uint32_t rid)
+{
+    const u64 a = (u64)(uintptr_t)in + ((u64)rid << 6);
+    return (const PgInRec *)(uintptr_t)((u64)(u32)uni((int)(u32)a) | ((u64)(u32)uni((int)(u32)(a >> 32)) << 32));
+}
+
 // One read: close end, then far end.
 //   close end   attempts (R0,seq) (R0,RC) (R1,RC) (R1,seq) until one yields points    pindel.cpp:2537-2575
 //   far end     BreakDancer cluster (if the read has one), then the ranges
@@ -1759,51 +1615,35 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
 #ifdef PG_STOP
     S.stopped = 0u;
 #endif
-    // the read's packed record (rid is wave-uniform)
-    auto rec0 = [&]() -> uint4 {
-        if (PG_REC_LDS(NB)) return S.rec[2 * opaque(slot)];
-        return ((const uint4 *)(B.in + rid))[0];          // (reads over 256 bases only; as an ordinary argument: the compiler makes this a scalar load)
-    };
-    auto rec1 = [&]() -> uint4 {
-        if (PG_REC_LDS(NB)) return S.rec[2 * opaque(slot) + 1];
-        return ((const uint4 *)(B.in + rid))[1];
-    };
-    const uint4 r0 = rec0(), r1 = rec1();
-    const int len = uni((int)(r1.x & 0xffffu));
-    const int chr = uni((int)r0.w);
-    const long long chr_wo = chr_word_off_of(ref, S, chr);
+    // The read's packed record (pg_device.h: everything that depends on the read and the parameters alone, worked out by the pack
+    // kernel), by scalar loads straight into SGPRs: dwords 0 .. 11 now, 12 .. 15 at the start of the far end.  (rid is wave-uniform.)
+    // The read's bit planes are requested first (they need nothing but the read's index) and arrive while the record is
+    // waited for; the window of the first close-end attempt follows (the scan below finds it resident).
+    const u64 planes_of_read = request_planes<NB>(B, rid, lane);
+    const PgInRec *rp = rec_ptr(KA(B, in), rid);
+    u32x8 ra;
+    u32x4 rb;
+    // (load and wait in ONE statement: between two statements the compiler may spill or reuse the destination registers -- it
+    // does not know that a scalar load is still in flight -- and the late data then lands on whatever lives there)
+    asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(ra), "=&s"(rb) : "s"(rp));
+    const int len = (int)(ra[6] & 0xffffu);
+    const u32 flags = ra[6] >> 16;                          // PG_RF_*
+    const int chr = (int)rb[3];
+    const long long chr_wo = (long long)((u64)ra[4] | ((u64)ra[5] << 32));
     S.len = len;
-    S.M = uni((int)(r1.y >> 24));
+    S.thr = (int)(ra[7] & 0xffffu);
+    S.M = (int)((ra[7] >> 16) & 0xffu);
+    S.T = (int)(ra[7] >> 24);
     S.add_mm = PRM(add_mm, PG_DEF_ADD_MM);
     S.min_perfect = PRM(min_perfect, PG_DEF_MIN_PERFECT);
-    S.T = uni(S.M + S.add_mm + 1);
-    S.thr = uni((int)(r1.y & 0xffffu));
-    // g_maxMismatch at the two filter depths (<= M: the breakpoints from index M on lie beyond the read)
-    {
-        const int j0 = seed_depth(len, S.T, false), j1 = seed_depth(len, S.T, true);
-        S.mm_j[0] = uni((int)mm_of<NB>(S, j0));
-        S.mm_j[1] = uni((int)mm_of<NB>(S, j1));
-    }
+    S.depth = rb[0];
+    S.jmask[0] = rb[1];
+    S.jmask[1] = rb[2];
     PG_STOP_AT(S, 10);
-    // The record is the read's first memory round trip; its bases and the window of the first close-end attempt are
-    // the second: both are requested before either is used (the scan below finds the window resident).
-    const u64 planes_of_read = request_planes<NB>(B, rid, lane);
-    if (mode & PG_MODE_CLOSE) {
-        const int strand0 = uni((int)((r1.y >> 16) & 0xffu));
-        if (len - 1 >= PRM(min_close, PG_DEF_MIN_CLOSE) && (strand0 == '+' || strand0 == '-')) {
-            const int apos0 = uni((int)r0.z), isz0 = uni((int)(short)(r1.x >> 16));
-            int s1 = strand0 == '+' ? apos0 : apos0 - isz0, e1 = s1 + isz0;           // attempt 0: R = 0
-#ifndef PG_NO_SHARED_CLOSE_GRID
-            if (isz0 > 0 && 3 * isz0 <= (int)PG_CHUNK) {                              // ... on the grid of the R = 1 window (below)
-                s1 -= isz0;
-                e1 += isz0;
-            }
-#endif
-            if (s1 < e1) {
-                const int se = e1 < s1 + (int)PG_CHUNK ? e1 : s1 + (int)PG_CHUNK;
-                stage_window<NB>(ref, S, chr_wo, s1 - 64 * NB, se + 64 * NB, lane);
-            }
-        }
+    if ((mode & PG_MODE_CLOSE) && (flags & PG_RF_CLOSE_OK)) {
+        // attempt 0's window -- the whole R = 1 window when that fits one chunk (PG_RF_SHARED_GRID): every attempt then runs on its grid
+        const int ss = (int)ra[2], se = (int)ra[3];
+        if (ss < se) stage_window<NB>(ref, S, chr_wo, ss - 64 * NB, se + 64 * NB, lane, rp + 1);
     }
     store_planes<NB>(B, planes_of_read, lane, qplanes);
 
@@ -1821,13 +1661,10 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
 
     // ------------------------------------------------------------------------------- close end
     if (do_close) {
-        // (the record's words are read again where they are used -- from LDS up to 256-base reads -- instead of eight VGPRs of
-        // wave-uniform data living through the whole read: what the sixth and seventh wave per SIMD are paid with)
-        const int strand = uni((int)((rec1().y >> 16) & 0xffu));
-        const int apos = uni((int)rec0().z);
-        const int isz = uni((int)(short)(rec1().x >> 16));
         int close_bases = 0;
-        if (len - 1 >= PRM(min_close, PG_DEF_MIN_CLOSE) && (strand == '+' || strand == '-')) {
+        if (flags & PG_RF_CLOSE_OK) {                     // len - 1 >= g_MinClose, MatchedD '+' or '-' (pindel.cpp:2258, 2271, 2298)
+            const int w1s = (int)ra[0], isz = (int)ra[1];
+            const u32 plus = flags & PG_RF_PLUS;
             S.bps = PRM(min_close, PG_DEF_MIN_CLOSE);
             // Min_Perfect_Match_Around_BP >= the first evaluated length: CheckMismatches' length test can fail, no short-lived tier
             S.sf = S.min_perfect >= S.bps ? 4u : (S.bps + 16 <= 32 ? 2u : 0u);
@@ -1836,16 +1673,13 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
             // attempt 1 on the chunk grid is anchored at the R = 1 window, which is staged once; attempts 1 and 2
             // use the same orientation of the read, so the seed-filter masks of the first chunk are computed
             // once for both and attempt 2 only adds the flanks to attempt 1's state (the reduction is additive).
-            const int w1s = strand == '+' ? apos - isz : apos - 2 * isz, w1e = w1s + 3 * isz;
+            // (whichever the strand, R = 1 is [w1s, w1s + 3 isz) and R = 0 its middle third: the record carries w1s)
+            const int w1e = w1s + 3 * isz;
             // When the R = 1 window fits one chunk (3 InsertSize <= 2048, the usual case), attempt 0 runs on that grid too:
             // the stage above already brought the whole R = 1 window (one pass of the fill loop either way), and
             // attempts 0 and 3 -- same orientation, nested windows -- share their seed-filter masks the way attempts 1
             // and 2 do: a read without a close end costs two filter runs and one fill instead of three and two.
-#ifndef PG_NO_SHARED_CLOSE_GRID
-            const u32 shared_grid = isz > 0 && 3 * isz <= (int)PG_CHUNK ? 1u : 0u;
-#else
-            const u32 shared_grid = 0u;
-#endif
+            const u32 shared_grid = (flags / PG_RF_SHARED_GRID) & 1u;       // isz > 0 && 3 isz <= PG_CHUNK
             u32 cr0 = 0u, cr1 = 0u;                       // cached masks of the orientation in hand ...
             u32 vr = 0u;
             u32 co0 = 0u, co1 = 0u;                       // ... and of the other one (swapped at attempts 1 and 3)
@@ -1863,18 +1697,14 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                 // '-' anchor: CurrentReadSeq = cur, grown right to left     (pindel.cpp:2298-2319)
                 Query<NB> Q;
                 Q.qp = qplanes + (!flipped ? 4 * NB : 0);
-                int s1, e1;
-                if (strand == '+') {
+                if (plus) {
                     Q.cF_ = !flipped; Q.cB_ = false; Q.allowF_ = true; Q.allowB_ = false;
-                    s1 = apos - Rg * isz;
-                    e1 = s1 + (2 * Rg + 1) * isz;
                 } else {
                     Q.cB_ = flipped; Q.cF_ = false; Q.allowF_ = false; Q.allowB_ = true;
-                    e1 = apos + Rg * isz;
-                    s1 = e1 - (2 * Rg + 1) * isz;
                 }
+                const int s1 = Rg ? w1s : w1s + isz, e1 = Rg ? w1e : w1s + 2 * isz;
                 // (points: CheckLeft_Close FORWARD / ANTISENSE, CheckRight_Close BACKWARD / SENSE: emit_runs' arguments)
-                Q.first_ok_ = first_base_ok<NB>(Q);
+                Q.first_ok_ = (flags & (flipped ? PG_RF_FIRST_OK_FWD : PG_RF_FIRST_OK_REV)) != 0u;   // (orientation 1 unless flipped)
                 close_bases = e1 > s1 ? e1 - s1 : 0;
                 if (att != 2) {           // attempt 2 continues attempt 1's reduction
                     A.reset();
@@ -1974,9 +1804,13 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
         Q.qp = qplanes + (flipped ? 4 * NB : 0);
         Q.cF_ = flipped; Q.cB_ = !flipped;                // (points: FORWARD / SENSE, BACKWARD / ANTISENSE)
         Q.allowF_ = Q.allowB_ = true;
-        Q.first_ok_ = first_base_ok<NB>(Q);
+        Q.first_ok_ = (flags & (flipped ? PG_RF_FIRST_OK_REV : PG_RF_FIRST_OK_FWD)) != 0u;       // (orientation 1 if flipped)
         if (Q.first_ok_) {
-            const int chr_size = chr_size_of(ref, S, chr);
+            // the rest of the record (chromosome size, window cluster); its address again rather than two scalar registers
+            // held through the close end
+            u32x4 rc;
+            asm volatile("s_load_dwordx4 %0, %1, 0x30\n\ts_waitcnt lgkmcnt(0)" : "=&s"(rc) : "s"(rec_ptr(KA(B, in), rid)));
+            const int chr_size = (int)rc[0];
             int far_bases = 0;
             // a search window's result replaces UP_Far if its MaxLen is >= (NewUPFarIsBetter, farend_searcher.cpp:30-44)
             auto far_update = [&](int origin, const pg_window *bdw, int qmask) {
@@ -2022,10 +1856,9 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
             bool done = false;
             // BreakDancer / read-pair cluster of this read first (pindel.cpp:1006-1018)
             const pg_window *bd_all = KA(B, bd);
-            const uint4 rbd = rec1();
-            if (bd_all && uni((int)rbd.z) != 0) {
-                const int nbd = uni((int)rbd.z);
-                const pg_window *bd = bd_all + uni((int)rbd.w);
+            if (bd_all && rc[1] != 0u) {
+                const int nbd = (int)rc[1];
+                const pg_window *bd = bd_all + rc[2];
                 A.reset();
                 S.cap_state = 255;
                 S.nsurv = 0;
@@ -2269,7 +2102,6 @@ __global__ __launch_bounds__(WAVE, PG_WAVES(NB, Id)) void pg_search_kernel(PgDev
     S.accB = lds.accB;
     S.mm_tab = lds.mm_tab;
     S.chr_tab = lds.chr_tab;
-    S.rec = lds.rec;
     u64 *qplanes = lds.qp;                        // [0]: forward, [1]: reversed consumption order
     if (lane < 8 * NB) qplanes[lane] = 0ull;      // (blocks beyond the batch's plane layout are never written)
 #ifdef PG_TIMING
@@ -2299,15 +2131,15 @@ __global__ __launch_bounds__(WAVE, PG_WAVES(NB, Id)) void pg_search_kernel(PgDev
 #ifdef PG_FORCE_CLAIM
         const uint32_t claim = PG_FORCE_CLAIM;
 #else
-        // (a workgroup's share of the launch in the fewest equal claims of at most PG_CLAIM)
-        const uint32_t per_wg = (n + gridDim.x - 1u) / gridDim.x, n_claims = (per_wg + PG_CLAIM - 1u) / PG_CLAIM;
-        const uint32_t claim = per_wg >= 8u * PG_CLAIM ? PG_CLAIM : (per_wg + n_claims - 1u) / n_claims;
+        const uint32_t claim = KA(B, claim);              // (pg_launch_search: the share of a workgroup in the fewest equal claims <= PG_CLAIM)
 #endif
         const uint32_t per = n / PG_N_XCD;
         const uint32_t lo = part * per, hi = part + 1 == PG_N_XCD ? n : lo + per;
+        // (the single-lane atomics by hand: the compiler wraps an atomicAdd in its wave-reduction form -- exec juggling, mbcnt,
+        // bcnt, a multiply -- some 25 instructions each)
         uint32_t got = 0;
         uint32_t *ctr = KA(B, work_ctr) + part * 16u;
-        if (lane == 0) got = atomicAdd(ctr, claim);
+        if (lane == 0) asm volatile("global_atomic_add %0, %1, %2, %3 sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(got) : "v"(0u), "v"(claim), "s"(ctr) : "memory");
         got = (u32)uni((int)got);
         if (got >= hi - lo) {                             // this part is exhausted
             part = part + 1 == PG_N_XCD ? 0 : part + 1;
@@ -2315,18 +2147,13 @@ __global__ __launch_bounds__(WAVE, PG_WAVES(NB, Id)) void pg_search_kernel(PgDev
             continue;
         }
         const uint32_t first = lo + got, end = hi - first < claim ? hi : first + claim;
-        if (PG_REC_LDS(NB)) {
-            PG_SYNC();
-            if ((uint32_t)lane < 8u * (end - first))
-                ((u32 *)lds.rec)[lane] = ((const u32 *)(KA(B, in) + KA(B, first_read) + first))[lane];
-            PG_SYNC();
-        }
         PG_T(S, 11);
-        // run-pool slots of the claim's reads: one atomic per claim (its round trip overlaps the record load above)
+        // run-pool slots of the claim's reads: one atomic per claim
         u32 res = 0u;
         {
             const u32 shard = blockIdx.x & (PG_POOL_SHARDS - 1u);
-            if (lane == 0) res = atomicAdd(KA(B, pool_used) + shard * 16u, claim * PG_RESERVE);
+            uint32_t *cur = KA(B, pool_used) + shard * 16u;
+            if (lane == 0) asm volatile("global_atomic_add %0, %1, %2, %3 sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(res) : "v"(0u), "v"(claim * PG_RESERVE), "s"(cur) : "memory");
             res = (u32)uni((int)res);
             const u32 res_fits = (u64)res + (u64)(claim * PG_RESERVE) <= (u64)KA(B, pool_shard_cap) ? 1u : 0u;
             res += shard * KA(B, pool_shard_cap);
@@ -2358,7 +2185,7 @@ __global__ void pg_kargs_check_kernel(PgDevRef ref, PgDevParams prm, PgDevBatch 
     PG_CHK(ref, lo); PG_CHK(ref, hi); PG_CHK(ref, nn); PG_CHK(ref, chr_word_off); PG_CHK(ref, chr_size); PG_CHK(ref, n_chr);
     PG_CHK(prm, max_range_index); PG_CHK(prm, add_mm); PG_CHK(prm, min_perfect); PG_CHK(prm, min_close); PG_CHK(prm, spacer);
     PG_CHK(B, n_reads); PG_CHK(B, first_read); PG_CHK(B, in); PG_CHK(B, out); PG_CHK(B, seq); PG_CHK(B, planes); PG_CHK(B, plane_blocks);
-    PG_CHK(B, bd); PG_CHK(B, pool); PG_CHK(B, pool_shard_cap); PG_CHK(B, pool_used); PG_CHK(B, work_ctr);
+    PG_CHK(B, bd); PG_CHK(B, pool); PG_CHK(B, pool_shard_cap); PG_CHK(B, pool_used); PG_CHK(B, work_ctr); PG_CHK(B, claim);
 #undef PG_CHK
     {
         const u32 *glo, *ghi, *gnn;
@@ -2423,6 +2250,15 @@ static void launch_ns(const PgDevRef *ref, const PgDevParams *prm, const PgDevBa
     const uint32_t chunks = (batch->n_reads + PG_CLAIM - 1) / PG_CLAIM + PG_N_XCD;
     const uint32_t want = (uint32_t)n_cu * 4u * (uint32_t)PG_WAVES(NB, Id);
     dim3 grid(chunks < want ? chunks : want), block(WAVE);
+    // Reads claimed per atomic: a workgroup's share of the launch in the fewest equal claims of at most PG_CLAIM reads (the kernel
+    // used to divide twice per claim for this: ~50 instructions)
+    PgDevBatch with_claim = *batch;
+    {
+        const uint32_t per_wg = (batch->n_reads + grid.x - 1u) / grid.x, n_claims = (per_wg + PG_CLAIM - 1u) / PG_CLAIM;
+        with_claim.claim = per_wg >= 8u * PG_CLAIM ? PG_CLAIM : (per_wg + n_claims - 1u) / n_claims;
+        if (with_claim.claim == 0u) with_claim.claim = 1u;
+    }
+    batch = &with_claim;
     if (PG_WIN_DYN_BYTES(NB) != 0u && prm->max_range_index >= 3) lds_pad += PG_WIN_DYN_BYTES(NB);   // two chunks per fill need their LDS
     // Pindel's default parameters have kernels of their own (see PRM): up to 16 mismatch levels, 32-bit candidate ids
     constexpr bool HAS_DEF = NS <= 4 && sizeof(Id) == 4;
@@ -2493,9 +2329,11 @@ __device__ __forceinline__ u32 swar_bits(u32 m)               // the four 0x80 f
 #ifndef PG_PACK_GRID
 #define PG_PACK_GRID 65536u
 #endif
-static_assert(sizeof(PgInRec) == 32 && offsetof(PgInRec, apos) == 8 && offsetof(PgInRec, chr) == 12 && offsetof(PgInRec, len) == 16 &&
-              offsetof(PgInRec, isz) == 18 && offsetof(PgInRec, thr) == 20 && offsetof(PgInRec, strand) == 22 && offsetof(PgInRec, M) == 23 &&
-              offsetof(PgInRec, bd_cnt) == 24 && offsetof(PgInRec, bd_off) == 28, "pg_pack_kernel writes PgInRec as two uint4");
+static_assert(sizeof(PgInRec) == 64 && offsetof(PgInRec, w1s) == 0 && offsetof(PgInRec, isz) == 4 && offsetof(PgInRec, stage_s) == 8 &&
+              offsetof(PgInRec, stage_e) == 12 && offsetof(PgInRec, chr_wo_lo) == 16 && offsetof(PgInRec, lenf) == 24 && offsetof(PgInRec, lvl) == 28 &&
+              offsetof(PgInRec, depth) == 32 && offsetof(PgInRec, jmask0) == 36 && offsetof(PgInRec, jmask1) == 40 && offsetof(PgInRec, chr) == 44 &&
+              offsetof(PgInRec, chr_size) == 48 && offsetof(PgInRec, bd_cnt) == 52 && offsetof(PgInRec, bd_off) == 56,
+              "pg_pack_kernel writes PgInRec as four uint4; search_read reads it as dwords 0..7, 8..11, 12..15");
 struct PgDw3 { u32 x, y, z; };
 template <int PB>
 __global__ __launch_bounds__(256) void pg_pack_kernel(PgSoaIn a, PgInRec *in, uint32_t lo, uint32_t cnt)
@@ -2512,7 +2350,8 @@ __global__ __launch_bounds__(256) void pg_pack_kernel(PgSoaIn a, PgInRec *in, ui
     for (u32 g = blockIdx.x * 4u + (threadIdx.x >> 6); g < n_blocks; g += n_waves) {
         const u32 r0 = g << 6;
         const u32 nb = cnt - r0 < 64u ? cnt - r0 : 64u;
-        // ---- phase A: lane = read
+        // ---- phase A: lane = read.  The whole 64-byte record from one lane (the wave writes 4 KB contiguous): everything the search
+        // kernel would otherwise derive per read on its scalar unit (PgInRec, pg_device.h)
         u32 so_lo = 0u, so_hi = 0u, len = 0u;
         if (lane < nb) {
             const u32 ii = lo + r0 + lane;
@@ -2522,23 +2361,64 @@ __global__ __launch_bounds__(256) void pg_pack_kernel(PgSoaIn a, PgInRec *in, ui
             so_hi = o.y;
             len = o.z - o.x;                           // (a read is shorter than 2^32 bases: the low words suffice)
             const u32 lc = len < 512u ? len : 511u;
-            uint4 r_lo, r_hi;
-            r_lo.x = so_lo;
-            r_lo.y = so_hi;
-            r_lo.z = (u32)(a.pos[ii] + (int32_t)a.spacer);
-            r_lo.w = (u32)a.chr[ii];
-            r_hi.x = (len & 0xffffu) | ((u32)(uint16_t)a.isz[ii] << 16);
-            r_hi.y = (u32)a.thr[lc] | ((u32)a.strand[ii] << 16) | ((a.mm[lc] & 0xffu) << 24);
-            r_hi.z = r_hi.w = 0u;
+            const int isz = (int)a.isz[ii];
+            const int apos = a.pos[ii] + (int32_t)a.spacer;
+            const u32 strand = a.strand[ii];
+            const int chr = a.chr[ii];
+            const u64 wo = a.chr_word_off[chr];
+            const u32 M = a.mm[lc] & 0xffu, T = M + (u32)a.add_mm + 1u;
+            const int J0 = pg_seed_depth((int)len, (int)T, 0), J1 = pg_seed_depth((int)len, (int)T, 1);
+            // relevance bound of a seed: min(T - 1, g_maxMismatch[J] + ADD)  (J >= 0; a one-base read has J = 0)
+            const u32 b0 = min(T - 1u, (a.mm[J0 < 0 ? 0 : J0] & 0xffu) + (u32)a.add_mm), b1 = min(T - 1u, (a.mm[J1 < 0 ? 0 : J1] & 0xffu) + (u32)a.add_mm);
+            const u32 jm0 = J0 > 1 ? ((J0 >= 32 ? 0xffffffffu : (1u << J0) - 1u) & ~1u) : 0u, jm1 = J1 > 1 ? ((J1 >= 32 ? 0xffffffffu : (1u << J1) - 1u) & ~1u) : 0u;
+            u32 flags = 0u;
+            const bool plus = strand == (u32)'+';
+            if ((int)len - 1 >= a.min_close && (plus || strand == (u32)'-')) flags |= PG_RF_CLOSE_OK;
+            if (plus) flags |= PG_RF_PLUS;
+            const bool shared = isz > 0 && 3 * isz <= (int)PG_CHUNK;
+            if (shared) flags |= PG_RF_SHARED_GRID;
+            if (len) {
+                const u64 at = (u64)so_lo | ((u64)so_hi << 32);
+                const u32 c0 = a.seq[at], c1 = a.seq[at + len - 1u];
+                if (c0 == 'A' || c0 == 'C' || c0 == 'G' || c0 == 'T') flags |= PG_RF_FIRST_OK_FWD;
+                if (c1 == 'A' || c1 == 'C' || c1 == 'G' || c1 == 'T') flags |= PG_RF_FIRST_OK_REV;
+            }
+            const int w1s = plus ? apos - isz : apos - 2 * isz;
+            // the first window fill: attempt 0's window (R = 0), or the whole R = 1 window when that fits one chunk
+            int ss = 0, se = 0;
+            if (flags & PG_RF_CLOSE_OK) {
+                const int s1 = shared ? w1s : w1s + isz, e1 = shared ? w1s + 3 * isz : w1s + 2 * isz;
+                if (s1 < e1) {
+                    ss = s1;
+                    se = e1 < s1 + (int)PG_CHUNK ? e1 : s1 + (int)PG_CHUNK;
+                }
+            }
+            uint4 q0, q1, q2, q3;
+            q0.x = (u32)w1s;
+            q0.y = (u32)isz;
+            q0.z = (u32)ss;
+            q0.w = (u32)se;
+            q1.x = (u32)wo;
+            q1.y = (u32)(wo >> 32);
+            q1.z = (len & 0xffffu) | (flags << 16);
+            q1.w = (u32)a.thr[lc] | (M << 16) | (T << 24);
+            q2.x = (u32)(J0 < 0 ? 0 : J0) | ((u32)(J1 < 0 ? 0 : J1) << 8) | (b0 << 16) | (b1 << 24);
+            q2.y = jm0;
+            q2.z = jm1;
+            q2.w = (u32)chr;
+            q3.x = a.chr_size[chr];
+            q3.y = q3.z = q3.w = 0u;
             if (a.bd_off) {
                 uint4 w;
                 __builtin_memcpy(&w, __builtin_assume_aligned(a.bd_off + ii, 8), 16);
-                r_hi.w = w.x;
-                r_hi.z = w.z - w.x;
+                q3.z = w.x;
+                q3.y = w.z - w.x;
             }
             uint4 *dst = (uint4 *)(in + ii);
-            dst[0] = r_lo;
-            dst[1] = r_hi;
+            dst[0] = q0;
+            dst[1] = q1;
+            dst[2] = q2;
+            dst[3] = q3;
         }
         // ---- phase B: 8 PB lanes = one read
         for (u32 s = 0; s < STEPS; s += U) {
