@@ -1881,7 +1881,11 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                 // did not cover are scanned.  Chunk grid: the innermost 2048 positions are one chunk (one LDS
                 // fill and one seed-filter pass serve the ranges up to 1024).
                 const int center = (int)close_last;
+#ifdef PG_DEF_X_RUNTIME      // (experiment: -x a launch argument of the default-parameter kernels too)
+                const int k_mri = KA(prm, max_range_index);
+#else
                 const int k_mri = PRM(max_range_index, PG_DEF_MAX_RANGE_INDEX);
+#endif
                 const u32 k_spacer = PRM(spacer, PG_DEF_SPACER);
                 const int maxspan = 64 << (2 * k_mri);
                 const int origin = center - maxspan;
@@ -2262,7 +2266,11 @@ static void launch_ns(const PgDevRef *ref, const PgDevParams *prm, const PgDevBa
     if (PG_WIN_DYN_BYTES(NB) != 0u && prm->max_range_index >= 3) lds_pad += PG_WIN_DYN_BYTES(NB);   // two chunks per fill need their LDS
     // Pindel's default parameters have kernels of their own (see PRM): up to 16 mismatch levels, 32-bit candidate ids
     constexpr bool HAS_DEF = NS <= 4 && sizeof(Id) == 4;
+#ifdef PG_DEF_X_RUNTIME
+    const bool def = HAS_DEF && !pg_env_switches()->generic_kernels &&
+#else
     const bool def = HAS_DEF && !pg_env_switches()->generic_kernels && prm->max_range_index == PG_DEF_MAX_RANGE_INDEX &&
+#endif
                      prm->add_mm == PG_DEF_ADD_MM && prm->min_perfect == PG_DEF_MIN_PERFECT && prm->min_close == PG_DEF_MIN_CLOSE &&
                      prm->spacer == PG_DEF_SPACER;
     if constexpr (HAS_DEF) {
