@@ -219,6 +219,7 @@ struct pg_ctx {
     uint64_t last_runs = 0;
     std::string err;
     bool counted = false;              // in g_live_ctx (the pinned-memory cache is trimmed with the last context)
+    uint32_t ref_epoch = 0;            // counts reference (re)loads: a device batch's records hold chromosome offsets and sizes
     bool kargs_checked = false;        // the kernels' view of the kernarg segment was checked on this device (pg_debug_kargs_check)
 };
 
@@ -242,6 +243,7 @@ struct pg_device_batch {
     uint32_t *close_off = nullptr, *close_cnt = nullptr, *far_off = nullptr, *far_cnt = nullptr;
     uint32_t *alg = nullptr;
     PgInRec *in_rec = nullptr;         // packed per-read records the kernel reads / writes (pg_device.h)
+    uint32_t ref_epoch = 0;            // pg_ctx::ref_epoch when the records were packed (a reload of the reference: pack again)
     uint64_t *planes = nullptr;        // the reads as bit planes (PgDevBatch::planes)
     PgOutRec *out_rec = nullptr;
     bool unpacked = true;              // the SoA output arrays reflect out_rec
@@ -345,6 +347,7 @@ void make_tables(pg_ctx *ctx)
 
 void free_reference(pg_ctx *ctx)
 {
+    ctx->ref_epoch++;
     if (ctx->d_lo) (void)hipFree(ctx->d_lo);
     if (ctx->d_hi) (void)hipFree(ctx->d_hi);
     if (ctx->d_nn) (void)hipFree(ctx->d_nn);
@@ -758,6 +761,7 @@ PgSoaOut soa_out(const pg_device_batch *b)
 int pack_reads(pg_ctx *ctx, pg_device_batch *b, uint32_t lo, uint32_t cnt, hipStream_t st = nullptr)
 {
     const PgSoaIn a = soa_in(ctx, b);
+    b->ref_epoch = ctx->ref_epoch;
     int rc = pg_pack_reads(&a, b->in_rec, lo, cnt, st ? st : ctx->stream);
     if (rc) return fail(ctx, PG_E_DEVICE, std::string("pack kernel: ") + hipGetErrorString((hipError_t)rc));
     return PG_OK;
@@ -867,6 +871,10 @@ int read_cursors(pg_ctx *ctx, pg_device_batch *b, uint32_t *worst, uint64_t *tot
 int run_search(pg_ctx *ctx, pg_device_batch *b, int mode)
 {
     if (ctx->names.empty()) return fail(ctx, PG_E_NO_REFERENCE, "no reference loaded");
+    // (a batch is validated and its records are packed against the reference loaded at upload time: chromosome offsets and sizes,
+    // window bounds; a reference loaded later makes them stale)
+    if (b->ref_epoch != ctx->ref_epoch && b->n)
+        return fail(ctx, PG_E_INVALID, "the reference was (re)loaded after this batch was uploaded: upload the batch again");
     for (int attempt = 0; attempt < 8; attempt++) {
         HIP_TRY(ctx, hipMemsetAsync(b->pool_used, 0, PG_POOL_SHARDS * 16 * sizeof(uint32_t), ctx->stream));
         HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));

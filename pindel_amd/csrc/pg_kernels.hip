@@ -1576,13 +1576,6 @@ __device__ __forceinline__ u32 pool_alloc(const PgDevBatch &B, int n, int lane, 
     return shard * KA(B, pool_shard_cap) + off;
 }
 
-template <int NB>
-__device__ __forceinline__ bool first_base_ok(const Query<NB> &Q)
-{
-    const u32 x = (u32)uni((int)(u32)(q_nn<NB>(Q, 0) | q_oo<NB>(Q, 0)));
-    return (x & 1u) == 0u;
-}
-
 // Address of a read's record for the scalar loads.  Both halves go through readfirstlane (free when the compiler already holds
 // them in scalar registers): left to itself it may do the 64-bit address arithmetic next to the planes' per-lane addresses on the
 // vector unit, and an "s" operand is then printed as a VGPR pair.
@@ -2118,7 +2111,8 @@ __global__ __launch_bounds__(WAVE, PG_WAVES(NB, Id)) void pg_search_kernel(PgDev
     S.t_base = 1;
 #endif
 
-    // Reads claimed per atomic: a workgroup's share of the launch in the fewest equal claims of at most PG_CLAIM reads.  The host
+    // Reads claimed per atomic (PgDevBatch::claim, worked out by pg_launch_search): a workgroup's share of the launch in the fewest
+    // equal claims of at most PG_CLAIM reads.  The host
     // launches one workgroup per PG_CLAIM reads up to the chip's resident slots, so up to 57 k reads every wave takes exactly one claim
     // of eight; between that and a few hundred thousand reads the share is 8..64 reads and claims of exactly eight would leave some
     // waves a whole claim more than others (100 000 reads: 14 per wave = two claims of seven).  Measured, seven waves per SIMD:
