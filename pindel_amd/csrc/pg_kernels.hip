@@ -129,13 +129,18 @@ __device__ __forceinline__ void karg_load3(T &a, T &b, T &c)
 #ifdef PG_WAVES_PER_EU
 #define PG_WAVES(NB, Id) PG_WAVES_PER_EU
 #else
-#define PG_WAVES(NB, Id) (sizeof(Lds<NB, Id>) <= 5120 ? 7 : (sizeof(Lds<NB, Id>) <= 6400 ? 6 : 5))
+#define PG_WAVES(NB, Id) (sizeof(Lds<NB, Id>) <= 5120 ? 7 : (sizeof(Lds<NB, Id>) <= 6400 ? 6 : (sizeof(Lds<NB, Id>) <= 7680 ? 5 : 4)))
 #endif
 #ifndef PG_CLAIM
 #define PG_CLAIM 8u         // reads claimed per atomic
 #endif
 #define PG_BIG 0xffffu      // "no candidate" level
-#define PG_CHR_TAB 24       // chromosomes whose word offset / size are kept in LDS (a read's first dependent load otherwise)
+#define PG_CHR_TAB 24       // chromosomes whose word offset / size are kept in LDS (window clusters on other chromosomes)
+// Candidates per pass.  Reads over 256 bases (NB = 8) take 32: the tier B entries (PASS x NB mismatch words) and the queue are
+// what decides between three and four waves per SIMD there -- 10 208 B of LDS is eight 1280-byte granules, sixteen workgroups per
+// CU -- and a pass rarely holds more than a dozen candidates anyway.
+#define PG_PASS(nb) ((nb) == 8 ? 32 : 64)
+#define PG_CHR_TAB_N(nb) ((nb) == 8 ? 0 : PG_CHR_TAB)
 #define PG_MM_IN_WIN(nb) ((nb) <= 4)
 
 // Lane masks.  ballot64 of ONE compare is that compare's result register; of a compound condition the compiler first builds the
@@ -330,17 +335,17 @@ template <> struct AccB<u64> {
 template <int NB, typename Id>
 struct Lds {
     uint4 bufA[68];                           // tier A entries {mis0 lo, sne0 lo, id lo, meta}; scratch for the quarter merge
-    uint2 bufB[64 * NB];                      // tier B entries: the mismatch bitmap, NB x {mis lo, mis hi} per candidate
+    uint2 bufB[PG_PASS(NB) * NB];             // tier B entries: the mismatch bitmap, NB x {mis lo, mis hi} per candidate
     uint2 hdrB[64];                           // ... and their {id lo, meta}
     u64 ringB[3 * NB];                        // fused far-end ranges: the long-lived candidates of a pass per ring and round
     typename AccB<Id>::T accB[NB > 1 ? 64 * (NB - 1) : 1];   // reduction state of the rounds >= 1 (AccB)
     u64 qp[2 * 4 * NB];                       // the read's bit planes, two orientations
-    uint16_t queue[64];                       // survivors of the prefilter for one candidate pass: (window position << 1) | kind
+    uint16_t queue[PG_PASS(NB)];              // survivors of the prefilter for one candidate pass: (window position << 1) | kind
     // g_maxMismatch[L] for every length a lane can own (filled once per workgroup).  Up to 256-base reads the table
     // lives in the fourth dword of the window entries (four lengths per dword; the fills write three dwords): the LDS
     // it would take costs a resident workgroup per CU at NB = 3 and 4.
     uint8_t mm_tab[PG_MM_IN_WIN(NB) ? 4 : 64 * NB + 64];
-    uint2 chr_tab[PG_CHR_TAB];                // word offset and size of the first PG_CHR_TAB chromosomes (size 0: not in the table --
+    uint2 chr_tab[PG_CHR_TAB_N(NB)];          // word offset and size of the first PG_CHR_TAB chromosomes (size 0: not in the table --
                                               // its word offset does not fit 32 bits)
 #ifdef PG_TIMING
     u64 t_last;
@@ -460,18 +465,20 @@ __device__ __forceinline__ int max_mismatch_at(const u32 *mm_bp, int L)
 }
 
 // word offset / size of a chromosome: from LDS for the first PG_CHR_TAB ones (c is wave-uniform)
+template <int NB>
 __device__ __forceinline__ long long chr_word_off_of(const PgDevRef &ref, const Search &S, int c)
 {
-    if (c < PG_CHR_TAB) {
+    if (c < PG_CHR_TAB_N(NB)) {
         const uint2 e = S.chr_tab[c];
         if (uni((int)e.y) != 0) return (long long)(u64)(u32)uni((int)e.x);
     }
     const u64 w = KA(ref, chr_word_off)[c];
     return (long long)((u64)(u32)uni((int)(u32)w) | ((u64)(u32)uni((int)(u32)(w >> 32)) << 32));
 }
+template <int NB>
 __device__ __forceinline__ int chr_size_of(const PgDevRef &ref, const Search &S, int c)
 {
-    if (c < PG_CHR_TAB) {
+    if (c < PG_CHR_TAB_N(NB)) {
         const int sz = uni((int)S.chr_tab[c].y);
         if (sz != 0) return sz;
     }
@@ -1214,20 +1221,20 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
             int h = 0, end = 0, slot = 0;
             u32 mF = 0u, mB = 0u, pos0 = 0u;
             for (;;) {
-                while (mF != 0u && slot < WAVE) {
+                while (mF != 0u && slot < PG_PASS(NB)) {
                     const int bit = __ffs((int)mF) - 1;
                     mF &= mF - 1u;
                     S.queue[slot] = (uint16_t)((pos0 + (u32)bit) << 1);
                     slot++;
                 }
-                while (mF == 0u && mB != 0u && slot < WAVE) {
+                while (mF == 0u && mB != 0u && slot < PG_PASS(NB)) {
                     const int bit = __ffs((int)mB) - 1;
                     mB &= mB - 1u;
                     S.queue[slot] = (uint16_t)(((pos0 + (u32)bit) << 1) | 1u);
                     slot++;
                 }
                 int n;
-                if (end >= WAVE) n = WAVE;
+                if (end >= PG_PASS(NB)) n = PG_PASS(NB);
                 else if (h < nh) {                            // every survivor so far is queued: the next half
                     const int word = 64 * h + lane;
                     seed_filter<NB, NS, true>(S, Q, false, true, word, mF, mB);
@@ -1311,9 +1318,9 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
         const int total = (int)read_lane(incl, 63);
         int slot = (int)(incl - cnt);
         PG_STOP_AT(S, 15);
-        for (int base = 0; base < total; base += WAVE) {
+        for (int base = 0; base < total; base += PG_PASS(NB)) {
             PG_SYNC();
-            const int top = base + WAVE;
+            const int top = base + PG_PASS(NB);
             while (mF != 0u && slot < top) {
                 const int bit = __ffs((int)mF) - 1;
                 mF &= mF - 1u;
@@ -1326,7 +1333,7 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
                 S.queue[slot - base] = (uint16_t)(((u32)(64 * NB + 32 * lane + bit) << 1) | 1u);
                 slot++;
             }
-            const int n = total - base < WAVE ? total - base : WAVE;
+            const int n = total - base < PG_PASS(NB) ? total - base : PG_PASS(NB);
             S.nsurv += n;
             S.nsurv_total += (u32)n;
             PG_SYNC();
@@ -1858,10 +1865,10 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                 for (int w = 0; w < nbd; w++) {
                     const pg_window bw = bd[w];
                     const int st = bw.start < 0 ? bw.end - 1 : bw.start;
-                    const int csz = chr_size_of(ref, S, uni(bw.chr_id));
+                    const int csz = chr_size_of<NB>(ref, S, uni(bw.chr_id));
                     const int s = st < 0 ? 0 : st, e = bw.end > csz ? csz : bw.end;
                     far_bases += (e > s ? e - s : 0) + 2 * len;
-                    scan_range<NB, NS, Id>(ref, S, Q, A, chr_word_off_of(ref, S, uni(bw.chr_id)), s, s, e, e, 0, 0, st,
+                    scan_range<NB, NS, Id>(ref, S, Q, A, chr_word_off_of<NB>(ref, S, uni(bw.chr_id)), s, s, e, e, 0, 0, st,
                                        (u32)w, opaque(lane), false, unused0, unused1, unused_valid);
                     PG_STOPPED(S);
                 }
@@ -1943,7 +1950,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                         const u32 incl = wave_scan(cnt);
                         const int total = (int)read_lane(incl, 63);
                         PG_STOP_AT(S, 26);
-                        if (total <= WAVE) {
+                        if (total <= PG_PASS(NB)) {
                             r_first = R + 1;
                             ps = rs[R];
                             pe = re[R];
@@ -2084,7 +2091,7 @@ __global__ __launch_bounds__(WAVE, PG_WAVES(NB, Id)) void pg_search_kernel(PgDev
         }
     } else
         for (int L = lane; L < 64 * NB + 64; L += WAVE) lds.mm_tab[L] = (uint8_t)max_mismatch_at(prm.mm_bp, L);
-    if (lane < PG_CHR_TAB && lane < ref.n_chr) {
+    if (lane < PG_CHR_TAB_N(NB) && lane < ref.n_chr) {
         const u64 wo = ref.chr_word_off[lane];
         lds.chr_tab[lane] = make_uint2((u32)wo, (wo >> 32) == 0ull ? ref.chr_size[lane] : 0u);
     }
