@@ -136,11 +136,11 @@ __device__ __forceinline__ void karg_load3(T &a, T &b, T &c)
 #endif
 #define PG_BIG 0xffffu      // "no candidate" level
 #define PG_CHR_TAB 24       // chromosomes whose word offset / size are kept in LDS (window clusters on other chromosomes)
-// Candidates per pass.  Reads over 256 bases (NB = 8) take 32: the tier B entries (PASS x NB mismatch words) and the queue are
-// what decides between three and four waves per SIMD there -- 10 208 B of LDS is eight 1280-byte granules, sixteen workgroups per
-// CU -- and a pass rarely holds more than a dozen candidates anyway.
-#define PG_PASS(nb) ((nb) == 8 ? 32 : 64)
-#define PG_CHR_TAB_N(nb) ((nb) == 8 ? 0 : PG_CHR_TAB)
+// Candidates per pass.  Reads over 192 bases (NB = 4, 8) take 32: the tier B entries (PASS x NB mismatch words), the queue and the
+// chromosome table are what decides between five and six (NB = 4: 7.2 -> 6.0 KB) and between three and four waves per SIMD (NB = 8:
+// 12.5 -> 10.2 KB = eight 1280-byte granules, sixteen workgroups per CU) -- and a pass rarely holds more than a dozen candidates.
+#define PG_PASS(nb) ((nb) >= 4 ? 32 : 64)
+#define PG_CHR_TAB_N(nb) ((nb) >= 4 ? 0 : PG_CHR_TAB)
 #define PG_MM_IN_WIN(nb) ((nb) <= 4)
 
 // Lane masks.  ballot64 of ONE compare is that compare's result register; of a compound condition the compiler first builds the
@@ -1865,10 +1865,11 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                 for (int w = 0; w < nbd; w++) {
                     const pg_window bw = bd[w];
                     const int st = bw.start < 0 ? bw.end - 1 : bw.start;
-                    const int csz = chr_size_of<NB>(ref, S, uni(bw.chr_id));
+                    const bool own_chr = uni(bw.chr_id) == chr;          // (the usual case: the record's offset and size)
+                    const int csz = own_chr ? chr_size : chr_size_of<NB>(ref, S, uni(bw.chr_id));
                     const int s = st < 0 ? 0 : st, e = bw.end > csz ? csz : bw.end;
                     far_bases += (e > s ? e - s : 0) + 2 * len;
-                    scan_range<NB, NS, Id>(ref, S, Q, A, chr_word_off_of<NB>(ref, S, uni(bw.chr_id)), s, s, e, e, 0, 0, st,
+                    scan_range<NB, NS, Id>(ref, S, Q, A, own_chr ? chr_wo : chr_word_off_of<NB>(ref, S, uni(bw.chr_id)), s, s, e, e, 0, 0, st,
                                        (u32)w, opaque(lane), false, unused0, unused1, unused_valid);
                     PG_STOPPED(S);
                 }
