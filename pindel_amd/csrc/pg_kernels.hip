@@ -136,11 +136,12 @@ __device__ __forceinline__ void karg_load3(T &a, T &b, T &c)
 #endif
 #define PG_BIG 0xffffu      // "no candidate" level
 #define PG_CHR_TAB 24       // chromosomes whose word offset / size are kept in LDS (window clusters on other chromosomes)
-// Candidates per pass.  Reads over 192 bases (NB = 4, 8) take 32: the tier B entries (PASS x NB mismatch words), the queue and the
-// chromosome table are what decides between five and six (NB = 4: 7.2 -> 6.0 KB) and between three and four waves per SIMD (NB = 8:
-// 12.5 -> 10.2 KB = eight 1280-byte granules, sixteen workgroups per CU) -- and a pass rarely holds more than a dozen candidates.
-#define PG_PASS(nb) ((nb) >= 4 ? 32 : 64)
-#define PG_CHR_TAB_N(nb) ((nb) >= 4 ? 0 : PG_CHR_TAB)
+// Candidates per pass.  Reads over 128 bases (NB >= 3) take 32: the tier B entries (PASS x NB mismatch words), the queue and the
+// chromosome table are what decides between six and seven (NB = 3: 6032 -> 5008 B), five and six (NB = 4: 7.2 -> 6.0 KB) and three
+// and four waves per SIMD (NB = 8: 12.5 -> 10.2 KB = eight 1280-byte granules, sixteen workgroups per CU) -- and a pass rarely
+// holds more than a dozen candidates (more than 32 survivors in the innermost far-end chunk: the ranges one by one, as for 64).
+#define PG_PASS(nb) ((nb) >= 3 ? 32 : 64)
+#define PG_CHR_TAB_N(nb) ((nb) >= 3 ? 0 : PG_CHR_TAB)
 #define PG_MM_IN_WIN(nb) ((nb) <= 4)
 
 // Lane masks.  ballot64 of ONE compare is that compare's result register; of a compound condition the compiler first builds the
