@@ -394,9 +394,15 @@ struct Search {
 #define PG_STOP_AT(S, k) do { asm volatile("s_nop 14\n\ts_nop %0\n\ts_nop %1" : : "n"((k) & 7), "n"((k) >> 3)); \
                               if (PG_STOP == (k) && uni(opaque(1))) { (S).stopped = 1u; return; } } while (0)
 #define PG_STOPPED(S) do { if ((S).stopped) return; } while (0)
+// (inside a lambda that returns a value)
+#define PG_STOP_AT_V(S, k, v) do { asm volatile("s_nop 14\n\ts_nop %0\n\ts_nop %1" : : "n"((k) & 7), "n"((k) >> 3)); \
+                                 if (PG_STOP == (k) && uni(opaque(1))) { (S).stopped = 1u; return (v); } } while (0)
+#define PG_STOPPED_V(S, v) do { if ((S).stopped) return (v); } while (0)
 #else
 #define PG_STOP_AT(S, k) ((void)0)
 #define PG_STOPPED(S) ((void)0)
+#define PG_STOP_AT_V(S, k, v) ((void)0)
+#define PG_STOPPED_V(S, v) ((void)0)
 #endif
 #ifdef PG_DIAG
     u32 dg;              // diagnostics build: fills | seed-filter runs << 8 | candidate passes << 16 | evaluations << 24
@@ -1687,7 +1693,10 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
             u32 vo = 0u;
             int ps = 0, pe = 0, nsurv_eval = 0;
             PG_STOP_AT(S, 11);
-            for (int att = 0; att < 4; att++) {
+            // The attempts as one body instantiated twice: attempt 0 -- where four reads in five stop -- with the attempt number a
+            // compile-time constant (no orientation swap, no continued state, R = 0 folded into the window arithmetic: -44 vector and
+            // -20 scalar instructions per read, -1.1 %), attempts 1..3 as a loop.  Returns true when the attempt found points.
+            auto attempt = [&](const int att) __attribute__((always_inline)) -> bool {
                 const int Rg = att >> 1;
 #ifdef PG_TIMING
                 PG_T(S, S.t_base + 2);
@@ -1723,11 +1732,11 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                 // one call site: attempt 0 on its own grid unless the R = 1 window fits a chunk, the retries on the grid
                 // of the R = 1 window
                 const bool own_grid = att == 0 && !shared_grid;
-                PG_STOP_AT(S, 12);
+                PG_STOP_AT_V(S, 12, true);
                 scan_range<NB, NS, Id>(ref, S, Q, A, chr_wo, own_grid ? s1 : w1s, s1, e1, own_grid ? e1 : w1e, ps, pe, w1s, 0u,
                                    opaque(lane), (att == 1 || att == 2 ? 1u : 0u) | shared_grid, cr0, cr1, vr);
-                PG_STOPPED(S);
-                PG_STOP_AT(S, 19);
+                PG_STOPPED_V(S, true);
+                PG_STOP_AT_V(S, 19, true);
                 ps = s1;
                 pe = e1;
                 if (S.nsurv != nsurv_eval) {
@@ -1748,7 +1757,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                     }
 #endif
                     evaluate<NB, Id>(S, A, E, opaque(lane));
-                    PG_STOP_AT(S, 20);
+                    PG_STOP_AT_V(S, 20, true);
                     close_max = uni(E.max_len);
                     if (uni(E.n_runs) > 0) {
                         u64 kept[NB];
@@ -1767,11 +1776,16 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                         const u64 idl = (u64)E.id_last;
                         const int pl = w1s + (int)(u32)(idl & ((1ull << IdFmt<Id>::RB) - 1ull));
                         close_last = ((idl >> IdFmt<Id>::RB) & 1ull) ? (u32)(pl - close_max + 1) : (u32)(pl + close_max - 1);
-                        PG_STOP_AT(S, 21);
-                        break;
+                        PG_STOP_AT_V(S, 21, true);
+                        return true;
                     }
                 }
-            }
+                return false;
+            };
+            if (!attempt(0))
+                for (int att = 1; att < 4; att++)
+                    if (attempt(att)) break;
+            PG_STOPPED(S);
         }
         if (n_close == 0) { flipped = 0; close_max = 0; }       // back to the original orientation
         alg = (u32)(8 * len + 3 * (close_bases + 2 * len) + 96 * n_close);   // x 8: the read once, 3 bits per base, 12 bytes per run
