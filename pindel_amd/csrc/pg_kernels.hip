@@ -206,6 +206,12 @@ __device__ __forceinline__ int opaque(int v)
     asm volatile("" : "+v"(v));
     return v;
 }
+// The lane's index, recomputed (v_mbcnt: two instructions) where a fresh copy is wanted: the compiler otherwise keeps threadIdx.x in
+// one VGPR for the whole kernel and, short of registers, parks it in scratch and reloads it at the start of every read.
+__device__ __forceinline__ int lane_now()
+{
+    return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (u32)opaque(0)));
+}
 __device__ __forceinline__ u64 low_bits(int n)            // clamped to [0,64]
 {
     return n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1ull));
@@ -1590,13 +1596,18 @@ __device__ __forceinline__ u32 pool_alloc(const PgDevBatch &B, int n, int lane, 
     return shard * KA(B, pool_shard_cap) + off;
 }
 
-// Address of a read's record for the scalar loads.  Both halves go through readfirstlane (free when the compiler already holds
-// them in scalar registers): left to itself it may do the 64-bit address arithmetic next to the planes' per-lane addresses on the
-// vector unit, and an "s" operand is then printed as a VGPR pair.
-__device__ __forceinline__ const PgInRec *rec_ptr(const PgInRec *in, uint32_t rid)
+// Address of a read's input / output record: base + index * 2^SHIFT, done on the scalar unit by hand.  Left to itself the compiler
+// does this 64-bit arithmetic next to the per-lane addresses on the vector unit, keeps the zero-extended read index in a VGPR pair
+// for the whole read -- and spills it to scratch (the round's only VGPR spills: 8 bytes of scratch written and read per read).
+template <int SHIFT, typename T>
+__device__ __forceinline__ T *record_ptr(T *base, uint32_t rid)
 {
-    const u64 a = (u64)(uintptr_t)in + ((u64)rid << 6);
-    return (const PgInRec *)(uintptr_t)((u64)(u32)uni((int)(u32)a) | ((u64)(u32)uni((int)(u32)(a >> 32)) << 32));
+    const u64 b = (u64)(uintptr_t)base;
+    const u32 blo = (u32)uni((int)(u32)b), bhi = (u32)uni((int)(u32)(b >> 32)), r = (u32)uni((int)rid);
+    u32 lo, hi;
+    asm("s_lshl_b32 %0, %4, %5\n\ts_lshr_b32 %1, %4, %6\n\ts_add_u32 %0, %0, %2\n\ts_addc_u32 %1, %1, %3"
+        : "=&s"(lo), "=&s"(hi) : "s"(blo), "s"(bhi), "s"(r), "n"(SHIFT), "n"(32 - SHIFT) : "scc");
+    return KaGlobal<T *>::of((u64)lo | ((u64)hi << 32));
 }
 
 // One read: close end, then far end.
@@ -1627,7 +1638,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     // The read's bit planes are requested first (they need nothing but the read's index) and arrive while the record is
     // waited for; the window of the first close-end attempt follows (the scan below finds it resident).
     const u64 planes_of_read = request_planes<NB>(B, rid, lane);
-    const PgInRec *rp = rec_ptr(KA(B, in), rid);
+    const PgInRec *rp = record_ptr<6>(KA(B, in), rid);
     u32x8 ra;
     u32x4 rb;
     // (load and wait in ONE statement: between two statements the compiler may spill or reuse the destination registers -- it
@@ -1695,8 +1706,9 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
             PG_STOP_AT(S, 11);
             // The attempts as one body instantiated twice: attempt 0 -- where four reads in five stop -- with the attempt number a
             // compile-time constant (no orientation swap, no continued state, R = 0 folded into the window arithmetic: -44 vector and
-            // -20 scalar instructions per read, -1.1 %), attempts 1..3 as a loop.  Returns true when the attempt found points.
-            auto attempt = [&](const int att) __attribute__((always_inline)) -> bool {
+            // -20 scalar instructions per read, -1.1 %) and, for that instance, the anchor's strand too (the candidate kind: another
+            // -11 / -6, -0.6 %); attempts 1..3 as a loop.  Returns true when the attempt found points.
+            auto attempt = [&](const int att, const bool plus_k) __attribute__((always_inline)) -> bool {
                 const int Rg = att >> 1;
 #ifdef PG_TIMING
                 PG_T(S, S.t_base + 2);
@@ -1707,7 +1719,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                 // '-' anchor: CurrentReadSeq = cur, grown right to left     (pindel.cpp:2298-2319)
                 Query<NB> Q;
                 Q.qp = qplanes + (!flipped ? 4 * NB : 0);
-                if (plus) {
+                if (plus_k) {
                     Q.cF_ = !flipped; Q.cB_ = false; Q.allowF_ = true; Q.allowB_ = false;
                 } else {
                     Q.cB_ = flipped; Q.cF_ = false; Q.allowF_ = false; Q.allowB_ = true;
@@ -1782,16 +1794,16 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                 }
                 return false;
             };
-            if (!attempt(0))
+            if (!(plus ? attempt(0, true) : attempt(0, false)))
                 for (int att = 1; att < 4; att++)
-                    if (attempt(att)) break;
+                    if (attempt(att, plus != 0u)) break;
             PG_STOPPED(S);
         }
         if (n_close == 0) { flipped = 0; close_max = 0; }       // back to the original orientation
         alg = (u32)(8 * len + 3 * (close_bases + 2 * len) + 96 * n_close);   // x 8: the read once, 3 bits per base, 12 bytes per run
     } else {
         // far-end launch: the close-end summary of the earlier launch
-        const uint4 o1 = ((const uint4 *)(KA(B, out) + rid))[1];
+        const uint4 o1 = ((const uint4 *)record_ptr<5>(KA(B, out), rid))[1];
         close_last = (u32)uni((int)o1.x);
         close_max = uni((int)(o1.y & 0xffffu));
         flipped = uni((int)((o1.y >> 16) & 0xffu));
@@ -1824,7 +1836,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
             // the rest of the record (chromosome size, window cluster); its address again rather than two scalar registers
             // held through the close end
             u32x4 rc;
-            asm volatile("s_load_dwordx4 %0, %1, 0x30\n\ts_waitcnt lgkmcnt(0)" : "=&s"(rc) : "s"(rec_ptr(KA(B, in), rid)));
+            asm volatile("s_load_dwordx4 %0, %1, 0x30\n\ts_waitcnt lgkmcnt(0)" : "=&s"(rc) : "s"(record_ptr<6>(KA(B, in), rid)));
             const int chr_size = (int)rc[0];
             int far_bases = 0;
             // a search window's result replaces UP_Far if its MaxLen is >= (NewUPFarIsBetter, farend_searcher.cpp:30-44)
@@ -2066,7 +2078,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     PG_T(S, 9);
     alg = (alg + 4u) >> 3;
     if (lane == 0) {
-        uint4 *op = (uint4 *)(KA(B, out) + rid);
+        uint4 *op = (uint4 *)record_ptr<5>(KA(B, out), rid);
         if (do_close) {
             op[0] = make_uint4(close_base, (u32)n_close, far_base, (u32)n_far);
 #ifdef PG_DIAG
@@ -2179,7 +2191,7 @@ __global__ __launch_bounds__(WAVE, PG_WAVES(NB, Id)) void pg_search_kernel(PgDev
             const u32 res_fits = (u64)res + (u64)(claim * PG_RESERVE) <= (u64)KA(B, pool_shard_cap) ? 1u : 0u;
             res += shard * KA(B, pool_shard_cap);
             for (uint32_t i = first; i < end; i++)
-                search_read<NB, NS, Id, mode, DEF>(ref, prm, B, S, qplanes, KA(B, first_read) + i, (int)(i - first), opaque(lane),
+                search_read<NB, NS, Id, mode, DEF>(ref, prm, B, S, qplanes, KA(B, first_read) + i, (int)(i - first), lane_now(),
                                           res + (i - first) * PG_RESERVE, res_fits);
             PG_T(S, 10);
         }
@@ -2354,6 +2366,7 @@ __device__ __forceinline__ u32 swar_bits(u32 m)               // the four 0x80 f
 #ifndef PG_PACK_GRID
 #define PG_PACK_GRID 65536u
 #endif
+static_assert(sizeof(PgOutRec) == 32, "record_ptr<5>");
 static_assert(sizeof(PgInRec) == 64 && offsetof(PgInRec, w1s) == 0 && offsetof(PgInRec, isz) == 4 && offsetof(PgInRec, stage_s) == 8 &&
               offsetof(PgInRec, stage_e) == 12 && offsetof(PgInRec, chr_wo_lo) == 16 && offsetof(PgInRec, lenf) == 24 && offsetof(PgInRec, lvl) == 28 &&
               offsetof(PgInRec, depth) == 32 && offsetof(PgInRec, jmask0) == 36 && offsetof(PgInRec, jmask1) == 40 && offsetof(PgInRec, chr) == 44 &&
