@@ -496,6 +496,17 @@ def test_rejections_are_loud(engine_factory, small_ref, tmp_path):
     noisy.load_reference(small_ref)
     assert code(lambda: noisy.search_batch(synth.make_reads(small_ref[0][1], 20, seed=23, read_len=450))) == E_UNSUPPORTED
     noisy.search_batch(synth.make_reads(small_ref[0][1], 20, seed=23, read_len=100)).free()
+    # a device batch is bound to the reference loaded when it was uploaded (its records hold chromosome offsets and sizes)
+    stale = engine_factory()
+    stale.load_reference(small_ref)
+    sdb = stale.upload(batch)
+    stale.search_device(sdb)
+    stale.load_reference(small_ref)
+    assert code(lambda: stale.search_device(sdb)) == E_INVALID
+    stale.free_device_batch(sdb)
+    sdb = stale.upload(batch)                    # uploaded again: fine
+    stale.search_device(sdb)
+    stale.free_device_batch(sdb)
     # BreakDancer windows: an unknown chromosome, offsets that go backwards
     db = eng.upload(batch)
     off = np.zeros(batch.n + 1, dtype=np.uint64)
