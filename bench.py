@@ -35,7 +35,8 @@ PROFILE_ROUND = next((r for r in ("r05", "r04") if os.path.exists(os.path.join(R
 PROFILE_DIR = os.path.join(ROOT, "profiles", PROFILE_ROUND)
 TRAFFIC_FILE = "hbm_traffic.json"
 PMC_FILE = "pmc_sq.txt"
-CALIB_FILE = "issue_calibration.txt"
+CALIB_FILE = "profiles/r04/issue_calibration.txt"      # (the in-situ cost per extra instruction was measured once, in round 4)
+UBENCH_FILE = "profiles/r03/ubench_issue_rates.txt"
 
 
 def cpu_baseline(chroms, batch, params_kw, budget_s=10.0, bd=None, bd_off=None, thread_points=True):
@@ -115,7 +116,7 @@ def issue_model(args, kernel_ms, reads_per_launch):
     DPP, lane reads: 44 % of this kernel's VALU instructions statically) every 3.2 cycles, the CU's one scalar unit
     1.0-1.35 ops per cycle.  Both VALU bounds are given; the truth lies between them.  `ns_per_instruction` = SIMD time
     per read / (VALU + SALU instructions per read); `in_situ_ns_per_extra_instruction` = what 128 more instructions
-    per seed-filter run were measured to cost inside this kernel (profiles/r04/issue_calibration.txt)."""
+    per seed-filter run were measured to cost inside this kernel (CALIB_FILE)."""
     path = os.path.join(PROFILE_DIR, PMC_FILE)
     if not default_workload(args) or not os.path.exists(path) or kernel_ms <= 0:
         return None
@@ -136,7 +137,7 @@ def issue_model(args, kernel_ms, reads_per_launch):
            "salu_busy_frac_at_1_per_cu_cycle": salu * reads_per_launch / 256.0 / cyc,
            "ns_per_instruction": kernel_ms * 1e6 / per_simd / (valu + salu),
            "in_situ_ns_per_extra_instruction": {"salu": 1.65, "valu_fast_rate": 0.79, "valu_slow_rate": 1.06},
-           "source": f"profiles/{PROFILE_ROUND}/{PMC_FILE} + profiles/r03/ubench_issue_rates.txt + profiles/r04/issue_calibration.txt, "
+           "source": f"profiles/{PROFILE_ROUND}/{PMC_FILE} (instruction counts) + {UBENCH_FILE} (issue rates) + {CALIB_FILE} (in-situ costs), "
                      "256 CUs x 4 SIMDs, 2.4 GHz nominal"}
     if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_ACTIVE_INST_VALU"):
         # active lanes per executed VALU instruction (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU), of 64
@@ -152,7 +153,7 @@ def pack_roofline(batch, pack_ms):
     lens = batch.lengths()
     ml = int(lens.max()) if batch.n else 1
     blocks = 1 if ml <= 64 else 2 if ml <= 128 else 3 if ml <= 192 else 4 if ml <= 256 else 8
-    nbytes = float(lens.sum()) + batch.n * (8 + 11 + 64 * blocks + 64)     # offsets + SoA fields in; bit planes + the 64-byte record out
+    nbytes = float(lens.sum()) + batch.n * (8 + 11 + 64 * blocks + 128)    # offsets + SoA fields in; bit planes + the 128-byte record out
     achieved = nbytes / (pack_ms * 1e-3) / 1e9 if pack_ms > 0 else 0.0
     return {"bound": "hbm", "kernel": "pg_pack_kernel", "kernel_ms": pack_ms, "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes, "traffic": None}
@@ -253,6 +254,21 @@ def build_workload(args, rank, world, dev):
             bd["chr_id"], bd["start"], bd["end"] = 0, centre - 300, centre + 300
             desc = (f"BASELINE configs[1]-shaped (deletions only, synthetic BreakDancer window hints): {args.reads} x "
                     f"{args.read_len} bp reads on a chr20-shaped reference ({args.chr_len} bp)")
+        elif args.workload == "wgs-real":
+            # the retry path's workload (round-5 verdict, item 2): 75 % of the reads are "no event" -- unmappable junk or plain
+            # reference reads, neither of which keeps a close end (GetCloseEnd walks (R0,seq) (R0,RC) (R1,RC) (R1,seq)) -- the
+            # rest split reads of every type; 150 bp, in coordinate order like a sorted BAM
+            if args.read_len == 100:
+                args.read_len = 150
+            batch = synth.make_reads(ref, args.reads, read_len=args.read_len, seed=read_seed, device=dev,
+                                     mix=(0.10, 0.05, 0.05, 0.05, 0.75))
+            order = np.argsort(batch.anchor_pos, kind="stable")
+            L = args.read_len
+            batch = type(batch)(seq=batch.seq.reshape(batch.n, L)[order].reshape(-1), seq_off=batch.seq_off,
+                                anchor_strand=batch.anchor_strand[order], anchor_pos=batch.anchor_pos[order],
+                                insert_size=batch.insert_size[order], chr_id=batch.chr_id[order])
+            desc = (f"WGS-like read mix (75 % of the reads without a close end: all four attempts), {args.reads} x {args.read_len} bp "
+                    f"reads in coordinate order on a chr20-shaped reference ({args.chr_len} bp)")
         else:
             batch = synth.make_reads(ref, args.reads, read_len=args.read_len, seed=read_seed, device=dev)
             kind = "BASELINE configs[2]" if args.workload == "sv10m" else "repeat-rich variant of configs[2] (45 % repeats)"
@@ -282,12 +298,14 @@ def main():
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive pg_search_batch sample")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--genome-scale", type=float, default=1.0, help="grch38-150: scale every chromosome (tests)")
-    ap.add_argument("--workload", choices=["sv10m", "colo-bd", "grch38-150", "repeat-rich", "wgs-bins"], default="sv10m",
+    ap.add_argument("--workload", choices=["sv10m", "colo-bd", "grch38-150", "repeat-rich", "wgs-bins", "wgs-real"], default="sv10m",
                     help="sv10m = BASELINE configs[2] (default); colo-bd = configs[1]-shaped; grch38-150 = configs[3]-shaped "
                          "(one rank's 12.5 M x 150 bp on a 3.1 Gbp 24-chromosome reference); repeat-rich = configs[2] on a "
                          "reference that is 45 % diverged repeat copies; wgs-bins = configs[4]-shaped: 150-bp reads in "
                          "coordinate order on the GRCh38-shaped reference, searched 5-Mbp bin by bin (one launch per bin, "
-                         "0.65 M reads per bin = 30x WGS with 400 M one-end-anchored reads), as main()'s loop does")
+                         "0.65 M reads per bin = 30x WGS with 400 M one-end-anchored reads), as main()'s loop does; wgs-real = the "
+                         "read mix INTEGRATION.md expects of a real WGS run: three reads in four find no close end and walk all "
+                         "four attempts (150 bp, coordinate order, chr20-shaped reference)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -332,14 +350,23 @@ def main():
     if bd is not None:
         eng.set_windows(dbatch, bd, bd_off)
 
+    # One step = what the device does for one batch whose raw inputs (ASCII bases, offsets, anchor fields) are resident in HBM:
+    # the PACK stage (pg_pack_kernel: bit planes + packed records, the form the search kernel reads -- part of every call of the
+    # ABI, so part of `value` since round 6) and the SEARCH (pg_search_kernel).  Both synchronous; HIP-event times of each.
+    pack_ms_steps = []
+
     def one_step():
         if bins is None:
+            pk = eng.repack(dbatch)
             eng.search_device(dbatch)    # synchronous: returns when the kernel finished
+            pack_ms_steps.append(pk)
             return eng.last_stats()[0]
-        ms = 0.0
+        ms = pk = 0.0
         for h in bins:                   # one launch per 5-Mbp bin
+            pk += eng.repack(h)
             eng.search_device(h)
             ms += eng.last_stats()[0]
+        pack_ms_steps.append(pk)
         return ms
 
     def barrier():
@@ -350,6 +377,7 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
+    pack_ms_steps.clear()
     barrier()
     t0 = time.perf_counter()
     kernel_ms = []
@@ -362,13 +390,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- outside the timed region: accounting, result digests, the pack stage, the host-buffer seam, the CPU baseline
+    # ---- outside the timed region: accounting, result digests, the host-buffer seam, the CPU baseline
     # The pack stage (pg_pack_kernel: ASCII bases as src/reader.cpp:852-856 hands them over -> the bit planes + packed
-    # records the search kernel reads) runs once at upload, before the timed region; its own duration on this batch, HIP
-    # events on the ctx's stream, goes on the record beside `value` (config.pack_ms_per_step, config.value_incl_pack,
+    # records the search kernel reads) is timed inside every step (HIP events on the ctx's stream: config.pack_ms_per_step,
     # roofline.pack).  Bytes per read: len + 8 (offset) + 11 (strand, position, insert size, chromosome) in, 64 x blocks
-    # (planes) + 64 (record) out.
-    pack_ms = min(eng.repack(dbatch) for _ in range(5))
+    # (planes) + 128 (record + symbol programs) out.
+    pack_ms = sum(pack_ms_steps) / max(len(pack_ms_steps), 1)      # inside the timed steps (HIP events around pg_pack_kernel)
     if bins is not None:
         eng.search_device(dbatch)                 # the whole batch once, for the accounting below (same reads)
     alg_bytes = eng.algorithmic_bytes(dbatch)     # per launch
@@ -430,8 +457,11 @@ def main():
                 "candidates_per_read": n_cand / max(batch.n, 1),    # seed-filter survivors that went through the full comparison
                 "result_sha256": shard.digest_hex(digests),
                 "host_path_reads_per_s": host_path,
+                # `value` covers pack + search; the search alone (rounds 1-5's `value`: inputs already packed) for comparison
+                "step": "pg_pack_kernel + pg_search_kernel on raw inputs resident in HBM",
                 "pack_ms_per_step": pack_ms,
-                "value_incl_pack": units * args.steps / (elapsed + args.steps * pack_ms * 1e-3),
+                "search_ms_per_step": avg_ms,
+                "value_search_only": units * args.steps / max(elapsed - args.steps * pack_ms * 1e-3, 1e-9),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

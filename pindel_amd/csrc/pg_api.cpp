@@ -33,7 +33,9 @@ double now_ms()
 const bool g_host_timing = getenv("PG_HOST_TIMING") != nullptr;
 
 // The environment switches of tests and experiments, read ONCE (getenv on the 50 000-read flush path is a linear scan of the
-// environment per call) -- pg_debug_reload_env() re-reads them (tests that change one in mid-process call it).
+// environment per call) -- pg_debug_reload_env() re-reads them (tests that change one in mid-process call it).  g_env is a plain
+// object read without synchronisation by every caller's thread and by the host pool's workers: pg_debug_reload_env() is a TEST
+// hook and must only be called while no pg_* call is in flight on any thread (pindel_pg.h says so; the tests do).
 PgEnvSwitches g_env;
 std::once_flag g_env_once;
 void load_env()
@@ -536,10 +538,26 @@ void host_ranges(size_t n, Fn fn)
         fn((size_t)0, n);
         return;
     }
+    if (t_in_pool) {                                            // re-entry from a range function: inline, no nt x nt fan-out
+        fn((size_t)0, n);
+        return;
+    }
     if (host_pool().try_run(n, nt, std::function<void(size_t, size_t)>(fn))) return;
+    // the pool is busy with another caller's job: threads of this call's own, exceptions carried back like the pool's
     std::vector<std::thread> th;
-    for (unsigned t = 0; t < nt; t++) th.emplace_back(fn, n * t / nt, n * (t + 1) / nt);
+    std::mutex err_mu;
+    std::exception_ptr err;
+    for (unsigned t = 0; t < nt; t++)
+        th.emplace_back([&, t] {
+            try {
+                fn(n * t / nt, n * (t + 1) / nt);
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(err_mu);
+                if (!err) err = std::current_exception();
+            }
+        });
     for (std::thread &x : th) x.join();
+    if (err) std::rethrow_exception(err);
 }
 
 // max_isz (nullable): largest insert size of the batch
@@ -633,6 +651,9 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, HostBuf<uint
     if (rc) return rc;
     pg_device_batch *b = new pg_device_batch();
     b->n = reads->n_reads;
+    // the batch is bound to the reference it was VALIDATED against (anchor windows, chromosome ids): stamped here and nowhere else --
+    // a repack or a new set of windows after a reload of the reference is refused, not re-stamped (stale_batch)
+    b->ref_epoch = ctx->ref_epoch;
     b->max_len = max_len;
     b->levels = levels;
     b->max_isz = max_isz;
@@ -648,7 +669,10 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, HostBuf<uint
     const Item items[] = {
         { (void **)&b->seq, (size_t)nseq + 16 }, { (void **)&b->seq_off, (n + 1) * 8 },
         { (void **)&b->strand, n1 }, { (void **)&b->pos, n1 * 4 }, { (void **)&b->isz, n1 * 2 }, { (void **)&b->chr, n1 * 4 },
-        { (void **)&b->in_rec, (n1 + PG_IN_PAD) * sizeof(PgInRec) },    // (+ the records the kernel's prefetch may touch behind the last read)
+        // INVARIANT: every allocation of in_rec carries PG_IN_PAD records behind the last read -- search_read touches `rp + 1` with a
+        // scalar load whose value is discarded (the next read's record into the scalar cache); this is the only place in_rec is
+        // allocated, and a launch over a sub-range [lo, lo + cnt) of the batch touches at most record lo + cnt, which exists.
+        { (void **)&b->in_rec, (n1 + PG_IN_PAD) * sizeof(PgInRec) },
         { (void **)&b->planes, n1 * 64 * pg_plane_blocks(max_len) },
         { (void **)&b->pool, (size_t)b->pool_shard_cap * PG_POOL_SHARDS * sizeof(pg_run) },
         // ---- zero-initialised from here
@@ -757,11 +781,19 @@ PgSoaOut soa_out(const pg_device_batch *b)
     return a;
 }
 
+// A device batch whose reference has been replaced since it was validated: its chromosome ids, anchor windows and (once packed)
+// word offsets belong to the old reference.
+int stale_batch(pg_ctx *ctx, const pg_device_batch *b)
+{
+    if (b->ref_epoch != ctx->ref_epoch && b->n)
+        return fail(ctx, PG_E_INVALID, "the reference was (re)loaded after this batch was uploaded: upload the batch again");
+    return PG_OK;
+}
+
 // Builds the packed records of reads [lo, lo + cnt) from the SoA inputs (on the ctx stream).
 int pack_reads(pg_ctx *ctx, pg_device_batch *b, uint32_t lo, uint32_t cnt, hipStream_t st = nullptr)
 {
     const PgSoaIn a = soa_in(ctx, b);
-    b->ref_epoch = ctx->ref_epoch;
     int rc = pg_pack_reads(&a, b->in_rec, lo, cnt, st ? st : ctx->stream);
     if (rc) return fail(ctx, PG_E_DEVICE, std::string("pack kernel: ") + hipGetErrorString((hipError_t)rc));
     return PG_OK;
@@ -873,8 +905,7 @@ int run_search(pg_ctx *ctx, pg_device_batch *b, int mode)
     if (ctx->names.empty()) return fail(ctx, PG_E_NO_REFERENCE, "no reference loaded");
     // (a batch is validated and its records are packed against the reference loaded at upload time: chromosome offsets and sizes,
     // window bounds; a reference loaded later makes them stale)
-    if (b->ref_epoch != ctx->ref_epoch && b->n)
-        return fail(ctx, PG_E_INVALID, "the reference was (re)loaded after this batch was uploaded: upload the batch again");
+    if (int rc = stale_batch(ctx, b)) return rc;
     for (int attempt = 0; attempt < 8; attempt++) {
         HIP_TRY(ctx, hipMemsetAsync(b->pool_used, 0, PG_POOL_SHARDS * 16 * sizeof(uint32_t), ctx->stream));
         HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
@@ -1386,6 +1417,7 @@ int pg_device_batch_repack(pg_ctx *ctx, pg_device_batch *b, double *pack_ms)
 {
     use_device(ctx);
     if (!ctx || !b) return PG_E_INVALID;
+    if (int stale = stale_batch(ctx, b)) return stale;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     int rc = b->n ? pack_reads(ctx, b, 0, b->n) : PG_OK;
     if (rc) return rc;
@@ -1854,6 +1886,7 @@ int pg_search_batch_multi(pg_ctx *const *ctxs, int32_t n_ctx, const pg_read_batc
 static int attach_windows(pg_ctx *ctx, pg_device_batch *b, const pg_windows *bd_hints)
 {
     const size_t n = b->n;
+    if (int stale = stale_batch(ctx, b)) return stale;
     if (b->bd_off) { (void)hipFree(b->bd_off); b->bd_off = nullptr; }
     if (b->bd) { (void)hipFree(b->bd); b->bd = nullptr; }
     b->max_bd_window = 0;

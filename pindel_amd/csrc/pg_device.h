@@ -38,7 +38,7 @@ enum PgMode { PG_MODE_CLOSE = 1, PG_MODE_FAR = 2, PG_MODE_BOTH = 3 };
 // Packed per-read records.  pg_pack_reads builds the input records on the device from the SoA arrays of the C ABI;
 // pg_unpack_results scatters the output records back into SoA arrays for the CSR scan / download.
 //
-// The input record is 64 bytes = one line of the scalar data cache: the search kernel fetches it with scalar loads straight
+// The input record is 128 bytes = two lines of the scalar data cache (the second: the seed filter's symbol programs): the search kernel fetches it with scalar loads straight
 // into SGPRs, and it holds everything about a read that is a function of (read, parameters) alone, worked out ONCE by the pack
 // kernel -- a streaming kernel with every lane busy -- instead of by every wave's scalar unit at the start of every read (round 5:
 // profiles/r05/everything_else_breakdown.txt; the CU's one scalar unit is the search kernel's tightest pipe):
@@ -54,6 +54,16 @@ enum PgMode { PG_MODE_CLOSE = 1, PG_MODE_FAR = 2, PG_MODE_BOTH = 3 };
 #define PG_RF_SHARED_GRID 4u    // 0 < 3 InsertSize <= PG_CHUNK
 #define PG_RF_FIRST_OK_FWD 8u   // read[0] is one of ACGT (orientation 0: left to right)
 #define PG_RF_FIRST_OK_REV 16u  // read[len - 1] is (orientation 1: from the last base)
+// The seed filter in READ ORDER (round 6, pg_kernels.hip "seed_filter_ro"): the consumed bases 1 .. 3 G in groups of three, the one-hot
+// plane of a base's symbol picked by VGPR index (s_set_gpr_idx): the symbols come as a PROGRAM, one dword per group -- byte k =
+// 0x30 | symbol of base 3 g + 1 + k (A 0, C 1, G 2, T 3, N 4; the 0x3 nibble is the index mode's operand enables when a 16-bit field
+// is moved into M0, and biases the index by 48), byte 3 = 0x30 (| symbol of base 0 in group 0: the seed).  prog[0] = the read left
+// to right as it is, prog[1] = the read from its last base, COMPLEMENTED: the only two (orientation, complement) pairs any search
+// consumes (kind F reads them as they are; kind B reads the complement, and its planes are laid out in complement order).
+#define PG_RO_GROUPS_MAX 8
+#define PG_RO_GROUPS_MIN 4
+#define PG_RO_OK 0x80000000u     // PgInRec::ro: this read may take the read-order filter (<= 8 mismatch levels, >= 4 groups, ACGTN only
+                                 // among the bases a program covers, g_MinClose >= 8)
 struct PgInRec {
     // dwords 0 .. 11: fetched at the start of a read
     int32_t  w1s;           // AbsLoc where the close end's R = 1 window starts
@@ -63,13 +73,17 @@ struct PgInRec {
     uint32_t lenf;          // read length | PG_RF_* << 16
     uint32_t lvl;           // CheckMismatches' threshold (smallest n with (float)n >= (float)(len * u)) | g_maxMismatch[len] << 16 | T << 24
     uint32_t depth;         // J plain | J wide << 8 | bound plain << 16 | bound wide << 24
-    uint32_t jmask0, jmask1;     // bits [1, J plain), [1, J wide)
+    uint32_t jmask0;        // bits [1, J plain)
+    uint32_t ro;            // read-order filter: groups plain | groups wide << 4 | bound plain << 8 | bound wide << 16 | PG_RO_OK
+                            // (bound = min(T - 1, g_maxMismatch[3 G + 1] + ADD): the depth the groups reach)
     int32_t  chr;           // chromosome of the anchor
     // dwords 12 .. 15: fetched at the start of the far end
     uint32_t chr_size;      // getCompSize() of that chromosome
     uint32_t bd_cnt;        // BreakDancer windows of this read ...
     uint32_t bd_off;        // ... starting at PgDevBatch::bd[bd_off]
-    uint32_t pad;
+    uint32_t jmask1;        // bits [1, J wide)
+    // dwords 16 .. 31: fetched by a seed-filter run (one orientation)
+    uint32_t prog[2][PG_RO_GROUPS_MAX];
 };
 #define PG_CLAIM_DEFAULT 8u  // reads a workgroup of the persistent launch claims per atomic, at most
 #define PG_IN_PAD 8u        // records allocated behind the last one (the kernel prefetches the next read's record)
@@ -146,6 +160,18 @@ static inline int pg_seed_depth(int len, int T, int wide)
     const int jt = PG_SEED_J(T) + (wide ? PG_SEED_J_WIDE : 0);
     return J > jt ? jt : J;
 }
+// groups of three bases the read-order filter inspects (bases 1 .. 3 G): the depth above rounded to whole groups
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline int pg_ro_groups(int len, int T, int wide)
+{
+    const int J = pg_seed_depth(len, T, wide);
+    int G = J / 3;                                    // (J - 1 bases: 15 -> 5 groups, 17 -> 6, 19 -> 6, 21 -> 7)
+    if (G > PG_RO_GROUPS_MAX) G = PG_RO_GROUPS_MAX;
+    while (G > 0 && 3 * G > len - 1) G--;
+    return G;
+}
 struct PgSoaOut {
     uint8_t *rc_flag;
     uint32_t *close_last;
@@ -207,6 +233,7 @@ struct PgEnvSwitches {
 extern "C" {
 #endif
 const struct PgEnvSwitches *pg_env_switches(void);
+// TEST HOOK: not synchronised with readers -- call it only while no pg_* call is in flight on any thread.
 void pg_debug_reload_env(void);
 // number of kernel arguments whose value fetched from the kernarg segment at PgKArgs' offsets differs from the by-value one (0)
 int pg_debug_kargs_check(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch *batch, uint32_t max_len, uint32_t levels,

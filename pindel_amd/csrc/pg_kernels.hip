@@ -268,6 +268,20 @@ __device__ __forceinline__ u32 med3(u32 a, u32 b, u32 c)
     return r;
 }
 
+// Address of a read's input / output record: base + index * 2^SHIFT, done on the scalar unit by hand.  Left to itself the compiler
+// does this 64-bit arithmetic next to the per-lane addresses on the vector unit, keeps the zero-extended read index in a VGPR pair
+// for the whole read -- and spills it to scratch (the round's only VGPR spills: 8 bytes of scratch written and read per read).
+template <int SHIFT, typename T>
+__device__ __forceinline__ T *record_ptr(T *base, uint32_t rid)
+{
+    const u64 b = (u64)(uintptr_t)base;
+    const u32 blo = (u32)uni((int)(u32)b), bhi = (u32)uni((int)(u32)(b >> 32)), r = (u32)uni((int)rid);
+    u32 lo, hi;
+    asm("s_lshl_b32 %0, %4, %5\n\ts_lshr_b32 %1, %4, %6\n\ts_add_u32 %0, %0, %2\n\ts_addc_u32 %1, %1, %3"
+        : "=&s"(lo), "=&s"(hi) : "s"(blo), "s"(bhi), "s"(r), "n"(SHIFT), "n"(32 - SHIFT) : "scc");
+    return KaGlobal<T *>::of((u64)lo | ((u64)hi << 32));
+}
+
 // Candidate ids: position relative to the search's origin, kind (F/B) and window index (BreakDancer cluster).
 //   32-bit: rel(24) | kind << 24 | region << 25   -- every window of the launch has <= 2^24 positions, clusters <= 127 windows
 //   64-bit: rel(26) | kind << 26 | region << 27   -- anything the ABI accepts (56 bits are kept: clusters of up to 2^29
@@ -297,6 +311,7 @@ struct Query {
     bool allowF_, allowB_; // candidate kinds searched
     bool cF_, cB_;         // complement flag per kind
     bool first_ok_;        // first consumed base is one of ACGT
+    bool o1_;              // the planes in hand are those of orientation 1 (the read from its last base): which symbol program (seed_filter_ro)
     __device__ __forceinline__ bool allowF() const { return allowF_; }
     __device__ __forceinline__ bool allowB() const { return allowB_; }
     __device__ __forceinline__ bool cF() const { return cF_; }
@@ -378,6 +393,10 @@ struct Search {
     // the seed filter's two depths of this read (plain, wide windows), from the read's record: `depth` = J plain | J wide << 8 |
     // bound plain << 16 | bound wide << 24 (bound = min(T - 1, g_maxMismatch[J] + ADD)), jmask = bits [1, J)
     u32 depth, jmask[2];
+    u32 ro;              // PgInRec::ro (read-order filter: groups, bounds, PG_RO_OK)
+    u32 rid;             // the read's index
+    u32 rp_lo, rp_hi;    // address of the read's record, as two wave-uniform words (the filter runs fetch its symbol programs; as a
+                         // POINTER member the compiler kept it in a VGPR pair and parked that in scratch)
     // what the LDS window currently holds: bases [win_lo, win_hi) of the chromosome whose AbsLoc 0 is
     // at word index win_wo; the first staged base is wbase = win_lo (any alignment)
     long long win_wo;
@@ -1144,12 +1163,236 @@ __device__ __forceinline__ void seed_filter_run(const Search &S, const Query<NB>
     if (DUAL) mB = seed2 & (snap2 | fin2);
 }
 
+// ---------------------------------------------------------------------------------
+// SEED FILTER IN READ ORDER (round 6).  The formulation above walks the read's bases symbol by symbol and pays for that on the
+// scalar unit: ten (symbol, phase) groups per run, each with its popcount, loop tests and branches, two scalar instructions per base
+// to take it off the set -- 113 to 130 scalar instructions per run on the pipe that bounds the kernel (profiles/r05/pmc_sq.txt,
+// everything_else_breakdown.txt).  Here the bases are taken in READ order, three per carry-save add, and what selects the one-hot
+// plane of a base's symbol is the VGPR INDEX MODE of gfx9 (s_set_gpr_idx_on / M0): the five planes (A, C, G, T, not-N) of a window
+// word sit in five consecutive VGPRs, the instruction names the first one, the symbol is the index.  The symbols come as a PROGRAM
+// worked out once per read by the pack kernel (PgInRec::prog: one dword per group of three bases, each byte 0x30 | symbol), so a
+// base costs ONE scalar instruction (s_set_gpr_idx_on takes byte 0; s_bfe_u32 m0 moves bytes 1|2 and 2|3 into M0 -- the upper
+// byte's 0x3 nibble lands on M0[15:12] = "index src0 and src1") and one v_alignbit with an IMMEDIATE shift; there is no loop: the
+// groups are unrolled, the run leaves after the read's group count.  scripts/ubench_gpridx.hip: the mode works on gfx950, an index
+// written by s_set_gpr_idx_* or by s_bfe_u32 m0 is seen by the very next vector instruction.
+//   * kind B reads the complement of what kind F reads, from the pair (previous word, own word) shifted by 32 - j: its planes are
+//     laid out in COMPLEMENT order (T, G, C, A, not-N), so one index serves both kinds of the far end.
+//   * the counter starts at 7 - (T - 1): "count <= T - 1" is then "no overflow" -- the final test costs nothing; the snapshot after
+//     PRE groups ("count <= bound", bound <= T - 1) is "adding T - 1 - bound does not overflow": three carries.
+//   * depth: bases 1 .. 3 G (G from the record, >= 4); the snapshot after 3 PRE <= bps - 1 bases.  Any depth keeps every seed that
+//     can matter (relevant at some L in [bps, 3 G + 1] => count(bps - 1 bases) <= g_maxMismatch[3 G + 1] + ADD,
+//     and a count over FEWER bases is smaller still; relevant later => alive after 3 G + 1 bases), it only moves the survivor count.
+// ONLY v_alignbit and v_mov run in index mode: an indexed v_bitop3 (the seed's plane straight into the final combine) gave correct
+// masks in every single-wave test and memory faults with seven waves per SIMD -- scripts/test_rofilter.hip, variants 18 / 19: the
+// fault follows the index of that one instruction, not the program fetch, not M0[11:8], not the register numbers.
+// Everything lives in fixed registers (v32 .. v43, v48 .. v57, s84 .. s88: with VCC, FLAT_SCRATCH and XNACK_MASK a gfx9 wave addresses s0 .. s95 --
+// a scalar register above that is the NEXT wave's: the first version used s88 .. s96 and passed every single-wave test): the index needs consecutive planes at known numbers (v48 + symbol:
+// the 0x30 bias), and nothing inside is spilled, copied or padded by the compiler.  Reads with more than eight mismatch levels, fewer
+// than four groups, a base outside ACGTN among the first 25 of either orientation, or g_MinClose < 8 keep the filter above.
+#ifndef PG_NO_RO_FILTER
+#define PG_RO 1
+// planes of the window word in (x, y, z) = (code bit 0, code bit 1, N): A, C, G, T, not-N into the five registers given
+#define RO_ONEHOT(dA, dC, dG, dT, dN, x, y, z)                                                                       \
+    "v_bitop3_b32 " dA ", " x ", " y ", " z " bitop3:0x01\n\tv_bitop3_b32 " dC ", " x ", " y ", " z " bitop3:0x10\n\t" \
+    "v_bitop3_b32 " dG ", " x ", " y ", " z " bitop3:0x04\n\tv_bitop3_b32 " dT ", " x ", " y ", " z " bitop3:0x40\n\t" \
+    "v_not_b32 " dN ", " z "\n\t"
+// three match masks into the counter (c0 c1 c2, sticky overflow ov): the adds of PG_ADD3 / PG_UP3; temporaries v35 .. v38
+#define RO_ADD3(c0, c1, c2, ov, ma, mb, mc)                                                                           \
+    "v_bitop3_b32 v35, " ma ", " mb ", " mc " bitop3:0x69\n\tv_bitop3_b32 v36, " ma ", " mb ", " mc " bitop3:0x17\n\t"   \
+    "v_and_b32 v37, " c0 ", v35\n\tv_xor_b32 " c0 ", " c0 ", v35\n\t"                                                   \
+    "v_bitop3_b32 v38, " c1 ", v36, v37 bitop3:0xe8\n\tv_bitop3_b32 " c1 ", " c1 ", v36, v37 bitop3:0x96\n\t"           \
+    "v_bitop3_b32 " ov ", " c2 ", v38, " ov " bitop3:0xea\n\tv_xor_b32 " c2 ", " c2 ", v38\n\t"
+// one group: P = the SGPR with the group's program dword; F planes (own, next word) = v48.. / v53.., B planes (previous, own word,
+// complement order) = v58.. / v63..: the instruction names register - 48
+// (the index changes of a group as macros of their own: scripts/test_rofilter.hip builds variants of them)
+#ifndef RO_IDX_ON
+#define RO_IDX_ON(P) "s_set_gpr_idx_on " P ", 0x3\n\t"
+#define RO_IDX_1(P) "s_bfe_u32 m0, " P ", 0x100008\n\t"
+#define RO_IDX_2(P) "s_bfe_u32 m0, " P ", 0x100010\n\t"
+#define RO_IDX_OFF "s_set_gpr_idx_off\n\t"
+#endif
+// one group, in two halves: the three match masks (v32 .. v34) of the bases with shifts s1 .. s3 -- low planes v48 .., high planes
+// v53 .. (the instruction names register - 48) --, then their sum into the counter v40 .. v42 + sticky overflow v43
+#define RO_SH(P, s1, s2, s3)                                                                                           \
+    RO_IDX_ON(P) "v_alignbit_b32 v32, v5, v0, " #s1 "\n\t"                                                              \
+    RO_IDX_1(P) "v_alignbit_b32 v33, v5, v0, " #s2 "\n\t"                                                               \
+    RO_IDX_2(P) "v_alignbit_b32 v34, v5, v0, " #s3 "\n\t" RO_IDX_OFF
+#define RO_AD RO_ADD3("v40", "v41", "v42", "v43", "v32", "v33", "v34")
+// The program comes in two halves into the SAME four registers (groups 1 .. 4, then 5 .. 8: the second fetch is issued when group 4's
+// index changes are done and is waited for behind that group's add), the seed's index is kept in s88: five scalar registers, the
+// highest s88 -- with VCC, FLAT_SCRATCH and XNACK_MASK that is 95 of the 96 a wave may have at seven waves per SIMD (the first
+// version held all eight dwords in s84 .. s91 + s92: 99, and ran at six waves per SIMD).
+#ifndef RO_PROG_LOAD
+#define RO_PROG_LOAD "s_load_dwordx4 s[84:87], %[rp], %[off]\n\t"
+#define RO_PROG_LOAD2 "s_load_dwordx4 s[84:87], %[rp], %[off] offset:0x10\n\t"
+#endif
+// kind F: base j against the pair (own word, next word) shifted by j; kind B: (previous word, own word) shifted by 32 - j
+#define RO_SH_F(P, j1, j2, j3, n1, n2, n3) RO_SH(P, j1, j2, j3)
+#define RO_SH_B(P, j1, j2, j3, n1, n2, n3) RO_SH(P, n1, n2, n3)
+#define RO_G1(M) M("s84", 1, 2, 3, 31, 30, 29)
+#define RO_G2(M) M("s85", 4, 5, 6, 28, 27, 26)
+#define RO_G3(M) M("s86", 7, 8, 9, 25, 24, 23)
+#define RO_G4(M) M("s87", 10, 11, 12, 22, 21, 20)
+#define RO_G5(M) M("s84", 13, 14, 15, 19, 18, 17)
+#define RO_G6(M) M("s85", 16, 17, 18, 16, 15, 14)
+#define RO_G7(M) M("s86", 19, 20, 21, 13, 12, 11)
+#define RO_G8(M) M("s87", 22, 23, 24, 10, 9, 8)
+#define RO_EXIT(k) "s_cmp_eq_u32 %[G], " #k "\n\ts_cbranch_scc1 9f\n\t"
+// counter start 7 - (T - 1) = ib, as bit slices
+// (%[t] = ib | d << 3: one scalar operand)
+#define RO_INIT "v_bfe_i32 v40, %[t], 0, 1\n\tv_bfe_i32 v41, %[t], 1, 1\n\tv_bfe_i32 v42, %[t], 2, 1\n\tv_mov_b32 v43, 0\n\t"
+// snapshot into v39: positions whose count so far is <= bound -- adding d = (T - 1) - bound (slices v35 .. v37) does not overflow.
+// RO_SNAP1: ... whose count INCLUDING the next base (its match mask is v32: the group's shifts are done, its add is not) is <= bound:
+// the mismatch of that base is the carry into the lowest slice.
+#define RO_DMASK "v_bfe_i32 v35, %[t], 3, 1\n\tv_bfe_i32 v36, %[t], 4, 1\n\tv_bfe_i32 v37, %[t], 5, 1\n\t"
+#define RO_SNAP0 RO_DMASK "v_and_b32 v38, v40, v35\n\t"
+#define RO_SNAP1 RO_DMASK "v_bitop3_b32 v38, v40, v35, v32 bitop3:0xd4\n\t"
+#define RO_SNAP_REST "v_bitop3_b32 v38, v41, v36, v38 bitop3:0xe8\n\tv_bitop3_b32 v38, v42, v37, v38 bitop3:0xe8\n\t" \
+                     "v_bitop3_b32 v39, v38, v43, v43 bitop3:0x01\n\t"
+// a whole run: SH = RO_SH_F / RO_SH_B.  Close end (first evaluated length 8): the snapshot after SEVEN bases = two groups and the
+// first base of the third; far end (first evaluated length 10): after nine = three groups.
+#define RO_TAIL(SH) RO_G4(SH) RO_PROG_LOAD2 RO_AD RO_EXIT(4) "s_waitcnt lgkmcnt(0)\n\t"                                   \
+    RO_G5(SH) RO_AD RO_EXIT(5) RO_G6(SH) RO_AD RO_EXIT(6) RO_G7(SH) RO_AD RO_EXIT(7) RO_G8(SH) RO_AD
+#define RO_RUN_CLOSE(SH) RO_G1(SH) RO_AD RO_G2(SH) RO_AD RO_G3(SH) RO_SNAP1 RO_SNAP_REST RO_AD RO_TAIL(SH)
+#define RO_RUN_FAR(SH) RO_G1(SH) RO_AD RO_G2(SH) RO_AD RO_G3(SH) RO_AD RO_SNAP0 RO_SNAP_REST RO_TAIL(SH)
+// the seed's plane (index = byte 3 of the first program dword) by an indexed v_mov -- SEEDREG: "v0" (kind F: the own word is the
+// low one) or "v5" (kind B: the high one) --, then seed & (snapshot | no overflow)
+// (a run that leaves after four groups still has the second fetch in flight: waited for here)
+#define RO_FINAL(SEEDREG) "9:\n\ts_waitcnt lgkmcnt(0)\n\ts_set_gpr_idx_on s88, 0x1\n\tv_mov_b32 v32, " SEEDREG "\n\ts_set_gpr_idx_off\n\t" \
+                          "v_bitop3_b32 %[m], v32, v39, v43 bitop3:0xd0"
+#define RO_CLOBBERS "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43",                   \
+                    "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57",                               \
+                    "s84", "s85", "s86", "s87", "s88", "m0", "scc", "memory"
+// One kind.  KIND 0: F, 1: B; FAR: the far end's snapshot depth.  o1 = the read's orientation in hand (0: left to right, 1: from
+// its last base) = which program.  word: the lane's window word (scan_impl).
+template <int NB, int KIND, bool FAR>
+__device__ __forceinline__ u32 seed_filter_ro1(const Search &S, bool o1, bool wide, int word)
+{
+    const u32 ro = S.ro;
+    const u32 G = (ro >> (wide ? 4 : 0)) & 15u;
+    const int bound = (int)((ro >> (wide ? 16 : 8)) & 0xffu);
+    const int thrA = bound < S.cap_state ? bound : S.cap_state;          // (see seed_filter: the state's bound once candidates are folded)
+    const u32 t = (u32)(8 - S.T) | ((u32)(S.T - 1 - thrA) << 3);            // counter start 7 - (T - 1) | snapshot distance (T - 1) - bound
+    const u32 off = o1 ? 0x60u : 0x40u;                                   // PgInRec::prog[o1]
+    // kind F reads the words (own, next), kind B (previous, own)
+    const u32 wa = (u32)(uintptr_t)(const __attribute__((address_space(3))) uint4 *)(S.win + (2 * NB + word - (KIND == 1 ? 1 : 0)));
+#ifdef RO_TEST_RP      // (scripts/test_rofilter.hip: the record's address as the compiler works it out)
+    const PgInRec *rp;
+    {
+        const unsigned long long a = (unsigned long long)(uintptr_t)((const PgInRec *)S.mm_tab + S.rid);
+        rp = (const PgInRec *)(uintptr_t)((unsigned long long)(u32)uni((int)(u32)a) | ((unsigned long long)(u32)uni((int)(u32)(a >> 32)) << 32));
+    }
+#else
+#ifdef PG_RO_RP_RECOMPUTE     // (ablation: the record's address worked out again at every run: a kernarg fetch + wait + four scalar instructions)
+    const PgInRec *rp = record_ptr<7>(karg_load<const PgInRec *>((int)offsetof(PgKArgs, B.in)), S.rid);
+#else
+    const PgInRec *rp = KaGlobal<const PgInRec *>::of((u64)S.rp_lo | ((u64)S.rp_hi << 32));
+#endif
+#endif
+    u32 m;
+#define RO_HEAD RO_PROG_LOAD "ds_read_b128 v[32:35], %[wa]\n\tds_read_b128 v[36:39], %[wa] offset:16\n\t" RO_INIT "s_waitcnt lgkmcnt(0)\n\ts_lshr_b32 s88, s84, 24\n\t"
+#define RO_OPERANDS : [m] "=&v"(m) : [rp] "s"(rp), [off] "s"(off), [wa] "v"(wa), [t] "s"(t), [G] "s"(G) : RO_CLOBBERS
+    if (KIND == 0) {
+        // planes in natural order (A, C, G, T, not-N): low = the own word, high = the next one
+        if (FAR)
+            asm volatile(RO_HEAD RO_ONEHOT("v48", "v49", "v50", "v51", "v52", "v32", "v33", "v34") RO_ONEHOT("v53", "v54", "v55", "v56", "v57", "v36", "v37", "v38")
+                         RO_RUN_FAR(RO_SH_F) RO_FINAL("v0") RO_OPERANDS);
+        else
+            asm volatile(RO_HEAD RO_ONEHOT("v48", "v49", "v50", "v51", "v52", "v32", "v33", "v34") RO_ONEHOT("v53", "v54", "v55", "v56", "v57", "v36", "v37", "v38")
+                         RO_RUN_CLOSE(RO_SH_F) RO_FINAL("v0") RO_OPERANDS);
+    } else {
+        // planes in COMPLEMENT order (T, G, C, A, not-N): low = the previous word, high = the own one
+        if (FAR)
+            asm volatile(RO_HEAD RO_ONEHOT("v51", "v50", "v49", "v48", "v52", "v32", "v33", "v34") RO_ONEHOT("v56", "v55", "v54", "v53", "v57", "v36", "v37", "v38")
+                         RO_RUN_FAR(RO_SH_B) RO_FINAL("v5") RO_OPERANDS);
+        else
+            asm volatile(RO_HEAD RO_ONEHOT("v51", "v50", "v49", "v48", "v52", "v32", "v33", "v34") RO_ONEHOT("v56", "v55", "v54", "v53", "v57", "v36", "v37", "v38")
+                         RO_RUN_CLOSE(RO_SH_B) RO_FINAL("v5") RO_OPERANDS);
+    }
+    return m;
+}
+// KIND 0: kind F alone (close end of a '+' anchor), 1: kind B alone ('-' anchor), 2: both (far end: two runs -- one pass with both
+// kinds' planes and counters resident is 40 fixed registers, and the compiler spilled 30 of its own around it)
+template <int NB, int KIND>
+__device__ __forceinline__ void seed_filter_ro(const Search &S, bool o1, bool wide, int word, u32 &mF, u32 &mB)
+{
+    if (KIND == 2) {
+        mF = seed_filter_ro1<NB, 0, true>(S, o1, wide, word);
+        mB = seed_filter_ro1<NB, 1, true>(S, o1, wide, word);
+    } else
+        mF = seed_filter_ro1<NB, KIND, false>(S, o1, wide, word);
+}
+#endif
+
 template <int NB, int NS, bool DUAL>
 __device__ __forceinline__ void seed_filter(const Search &S, const Query<NB> &Q, bool kindB, bool wide, int lane,
                                             u32 &mF, u32 &mB)
 {
     const int T = S.T;
     PG_DG(const_cast<Search &>(S), 8);
+#ifdef PG_RO
+#ifndef PG_RO_KINDS
+#define PG_RO_KINDS 7      // (ablation: bit 0 = kind F alone, bit 1 = kind B alone, bit 2 = both kinds)
+#endif
+#ifdef PG_RO_CHECK
+    // diagnostics: both filters on every run; every seed the symbol-by-symbol filter keeps must survive the read-order one (plain
+    // depth: same bases in the final count, a shorter prefix in the snapshot).  Counters behind the launch's read counters
+    // (pg_debug_read_phase_cycles): [0] runs, [1 + kind] runs with a seed lost, [4] lanes with a seed lost.
+    // PG_RO_CHECK = 1: the search goes on with the OLD masks, 2: with the new ones.
+    if (NS == 3 && (S.ro & PG_RO_OK) && !wide) {
+        u32 nF = 0u, nB = 0u, oF = 0u, oB = 0u;
+        {   // the program as the run will fetch it: every byte 0x30 | symbol <= 4 ?  ([5] counts the runs with another)
+            const PgInRec *rp = record_ptr<7>(karg_load<const PgInRec *>((int)offsetof(PgKArgs, B.in)), S.rid);
+            u32x8 P;
+            asm volatile("s_load_dwordx8 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&s"(P) : "s"(rp), "s"(Q.o1_ ? 0x60u : 0x40u));
+            u32 badp = 0u;
+#pragma unroll
+            for (int k = 0; k < 8; k++) badp |= ((P[k] & 0xf8f8f8f8u) ^ 0x30303030u) | ((P[k] & 0x07070707u) + 0x03030303u) & 0x08080808u;
+            if (badp != 0u) {
+                if (threadIdx.x == 0) atomicAdd((unsigned long long *)(karg_load<uint32_t *>((int)offsetof(PgKArgs, B.work_ctr)) + PG_WORK_CTRS * 16u) + 5, 1ull);
+                const u32 jm = S.jmask[0], g0 = jm & low32(S.bps);
+                int c0 = (int)((S.depth >> 16) & 0xffu);
+                if (c0 > S.cap_state) c0 = S.cap_state;
+                seed_filter_run<NB, NS, DUAL>(S, Q, kindB, lane, jm, g0, c0, mF, mB);
+                return;
+            }
+        }
+#if PG_RO_CHECK == 3
+        {   // (the old filter alone: does the check code itself disturb anything?)
+            const u32 jm = S.jmask[0], g0 = jm & low32(S.bps);
+            int c0 = (int)((S.depth >> 16) & 0xffu);
+            if (c0 > S.cap_state) c0 = S.cap_state;
+            seed_filter_run<NB, NS, DUAL>(S, Q, kindB, lane, jm, g0, c0, mF, mB);
+            return;
+        }
+#endif
+        if (DUAL) seed_filter_ro<NB, 2>(S, Q.o1_, wide, lane, nF, nB);
+        else if (kindB) seed_filter_ro<NB, 1>(S, Q.o1_, wide, lane, nF, nB);
+        else seed_filter_ro<NB, 0>(S, Q.o1_, wide, lane, nF, nB);
+        {
+            const u32 jm = S.jmask[0], g0 = jm & low32(S.bps);
+            int c0 = (int)((S.depth >> 16) & 0xffu);
+            if (c0 > S.cap_state) c0 = S.cap_state;
+            seed_filter_run<NB, NS, DUAL>(S, Q, kindB, lane, jm, g0, c0, oF, oB);
+        }
+        const u64 bad = ballot64(((oF & ~nF) | (DUAL ? (oB & ~nB) : 0u)) != 0u);
+        if (threadIdx.x == 0) {
+            unsigned long long *dg = (unsigned long long *)(karg_load<uint32_t *>((int)offsetof(PgKArgs, B.work_ctr)) + PG_WORK_CTRS * 16u);
+            atomicAdd(dg, 1ull);
+            if (bad) { atomicAdd(dg + 1 + (DUAL ? 2 : (kindB ? 1 : 0)), 1ull); atomicAdd(dg + 4, (unsigned long long)__popcll(bad)); }
+        }
+        mF = PG_RO_CHECK == 1 ? oF : nF;
+        mB = PG_RO_CHECK == 1 ? oB : nB;
+        return;
+    }
+#endif
+    if (NS == 3 && (S.ro & PG_RO_OK) && ((PG_RO_KINDS >> (DUAL ? 2 : (kindB ? 1 : 0))) & 1)) {
+        if (DUAL) seed_filter_ro<NB, 2>(S, Q.o1_, wide, lane, mF, mB);
+        else if (kindB) seed_filter_ro<NB, 1>(S, Q.o1_, wide, lane, mF, mB);       // (kindB is a constant at every call site)
+        else seed_filter_ro<NB, 0>(S, Q.o1_, wide, lane, mF, mB);
+        return;
+    }
+#endif
 #if defined(PG_PAD_S) || defined(PG_PAD_VF) || defined(PG_PAD_VS)
     {   // diagnostics: what do 128 more scalar / fast-rate vector / slow-rate vector instructions per filter run cost?
         u32 pa = (u32)lane;
@@ -1596,20 +1839,6 @@ __device__ __forceinline__ u32 pool_alloc(const PgDevBatch &B, int n, int lane, 
     return shard * KA(B, pool_shard_cap) + off;
 }
 
-// Address of a read's input / output record: base + index * 2^SHIFT, done on the scalar unit by hand.  Left to itself the compiler
-// does this 64-bit arithmetic next to the per-lane addresses on the vector unit, keeps the zero-extended read index in a VGPR pair
-// for the whole read -- and spills it to scratch (the round's only VGPR spills: 8 bytes of scratch written and read per read).
-template <int SHIFT, typename T>
-__device__ __forceinline__ T *record_ptr(T *base, uint32_t rid)
-{
-    const u64 b = (u64)(uintptr_t)base;
-    const u32 blo = (u32)uni((int)(u32)b), bhi = (u32)uni((int)(u32)(b >> 32)), r = (u32)uni((int)rid);
-    u32 lo, hi;
-    asm("s_lshl_b32 %0, %4, %5\n\ts_lshr_b32 %1, %4, %6\n\ts_add_u32 %0, %0, %2\n\ts_addc_u32 %1, %1, %3"
-        : "=&s"(lo), "=&s"(hi) : "s"(blo), "s"(bhi), "s"(r), "n"(SHIFT), "n"(32 - SHIFT) : "scc");
-    return KaGlobal<T *>::of((u64)lo | ((u64)hi << 32));
-}
-
 // One read: close end, then far end.
 //   close end   attempts (R0,seq) (R0,RC) (R1,RC) (R1,seq) until one yields points    pindel.cpp:2537-2575
 //   far end     BreakDancer cluster (if the read has one), then the ranges
@@ -1638,7 +1867,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     // The read's bit planes are requested first (they need nothing but the read's index) and arrive while the record is
     // waited for; the window of the first close-end attempt follows (the scan below finds it resident).
     const u64 planes_of_read = request_planes<NB>(B, rid, lane);
-    const PgInRec *rp = record_ptr<6>(KA(B, in), rid);
+    const PgInRec *rp = record_ptr<7>(KA(B, in), rid);
     u32x8 ra;
     u32x4 rb;
     // (load and wait in ONE statement: between two statements the compiler may spill or reuse the destination registers -- it
@@ -1656,7 +1885,11 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     S.min_perfect = PRM(min_perfect, PG_DEF_MIN_PERFECT);
     S.depth = rb[0];
     S.jmask[0] = rb[1];
-    S.jmask[1] = rb[2];
+    S.jmask[1] = 0u;                                        // (the wide depth's mask comes with the far end's part of the record)
+    S.ro = rb[2];
+    S.rid = rid;
+    S.rp_lo = (u32)uni((int)(u32)(u64)(uintptr_t)rp);
+    S.rp_hi = (u32)uni((int)(u32)((u64)(uintptr_t)rp >> 32));
     PG_STOP_AT(S, 10);
     if ((mode & PG_MODE_CLOSE) && (flags & PG_RF_CLOSE_OK)) {
         // attempt 0's window -- the whole R = 1 window when that fits one chunk (PG_RF_SHARED_GRID): every attempt then runs on its grid
@@ -1719,6 +1952,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                 // '-' anchor: CurrentReadSeq = cur, grown right to left     (pindel.cpp:2298-2319)
                 Query<NB> Q;
                 Q.qp = qplanes + (!flipped ? 4 * NB : 0);
+                Q.o1_ = !flipped;
                 if (plus_k) {
                     Q.cF_ = !flipped; Q.cB_ = false; Q.allowF_ = true; Q.allowB_ = false;
                 } else {
@@ -1829,6 +2063,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
         // consumes complement(cur) walking the reference right to left.
         Query<NB> Q;
         Q.qp = qplanes + (flipped ? 4 * NB : 0);
+        Q.o1_ = flipped != 0;
         Q.cF_ = flipped; Q.cB_ = !flipped;                // (points: FORWARD / SENSE, BACKWARD / ANTISENSE)
         Q.allowF_ = Q.allowB_ = true;
         Q.first_ok_ = (flags & (flipped ? PG_RF_FIRST_OK_REV : PG_RF_FIRST_OK_FWD)) != 0u;       // (orientation 1 if flipped)
@@ -1836,8 +2071,9 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
             // the rest of the record (chromosome size, window cluster); its address again rather than two scalar registers
             // held through the close end
             u32x4 rc;
-            asm volatile("s_load_dwordx4 %0, %1, 0x30\n\ts_waitcnt lgkmcnt(0)" : "=&s"(rc) : "s"(record_ptr<6>(KA(B, in), rid)));
+            asm volatile("s_load_dwordx4 %0, %1, 0x30\n\ts_waitcnt lgkmcnt(0)" : "=&s"(rc) : "s"(record_ptr<7>(KA(B, in), rid)));
             const int chr_size = (int)rc[0];
+            S.jmask[1] = rc[3];
             int far_bases = 0;
             // a search window's result replaces UP_Far if its MaxLen is >= (NewUPFarIsBetter, farend_searcher.cpp:30-44)
             auto far_update = [&](int origin, const pg_window *bdw, int qmask) {
@@ -2367,10 +2603,10 @@ __device__ __forceinline__ u32 swar_bits(u32 m)               // the four 0x80 f
 #define PG_PACK_GRID 65536u
 #endif
 static_assert(sizeof(PgOutRec) == 32, "record_ptr<5>");
-static_assert(sizeof(PgInRec) == 64 && offsetof(PgInRec, w1s) == 0 && offsetof(PgInRec, isz) == 4 && offsetof(PgInRec, stage_s) == 8 &&
+static_assert(sizeof(PgInRec) == 128 && offsetof(PgInRec, prog) == 64 && offsetof(PgInRec, w1s) == 0 && offsetof(PgInRec, isz) == 4 && offsetof(PgInRec, stage_s) == 8 &&
               offsetof(PgInRec, stage_e) == 12 && offsetof(PgInRec, chr_wo_lo) == 16 && offsetof(PgInRec, lenf) == 24 && offsetof(PgInRec, lvl) == 28 &&
-              offsetof(PgInRec, depth) == 32 && offsetof(PgInRec, jmask0) == 36 && offsetof(PgInRec, jmask1) == 40 && offsetof(PgInRec, chr) == 44 &&
-              offsetof(PgInRec, chr_size) == 48 && offsetof(PgInRec, bd_cnt) == 52 && offsetof(PgInRec, bd_off) == 56,
+              offsetof(PgInRec, depth) == 32 && offsetof(PgInRec, jmask0) == 36 && offsetof(PgInRec, ro) == 40 && offsetof(PgInRec, chr) == 44 &&
+              offsetof(PgInRec, chr_size) == 48 && offsetof(PgInRec, bd_cnt) == 52 && offsetof(PgInRec, bd_off) == 56 && offsetof(PgInRec, jmask1) == 60,
               "pg_pack_kernel writes PgInRec as four uint4; search_read reads it as dwords 0..7, 8..11, 12..15");
 struct PgDw3 { u32 x, y, z; };
 template <int PB>
@@ -2442,10 +2678,16 @@ __global__ __launch_bounds__(256) void pg_pack_kernel(PgSoaIn a, PgInRec *in, ui
             q1.w = (u32)a.thr[lc] | (M << 16) | (T << 24);
             q2.x = (u32)(J0 < 0 ? 0 : J0) | ((u32)(J1 < 0 ? 0 : J1) << 8) | (b0 << 16) | (b1 << 24);
             q2.y = jm0;
-            q2.z = jm1;
+            {   // read-order filter (PgInRec::ro): whole groups of three bases, the relevance bound of the depth they reach
+                const int G0 = pg_ro_groups((int)len, (int)T, 0), G1 = pg_ro_groups((int)len, (int)T, 1);
+                const u32 rb0 = min(T - 1u, (a.mm[3 * G0 + 1] & 0xffu) + (u32)a.add_mm), rb1 = min(T - 1u, (a.mm[3 * G1 + 1] & 0xffu) + (u32)a.add_mm);
+                q2.z = (u32)G0 | ((u32)G1 << 4) | (rb0 << 8) | (rb1 << 16);
+                if (T <= 8u && G0 >= PG_RO_GROUPS_MIN && G1 >= PG_RO_GROUPS_MIN && a.min_close >= 8) q2.z |= PG_RO_OK;    // (the close end's snapshot covers seven bases)
+            }
             q2.w = (u32)chr;
             q3.x = a.chr_size[chr];
-            q3.y = q3.z = q3.w = 0u;
+            q3.y = q3.z = 0u;
+            q3.w = jm1;
             if (a.bd_off) {
                 uint4 w;
                 __builtin_memcpy(&w, __builtin_assume_aligned(a.bd_off + ii, 8), 16);
@@ -2518,6 +2760,46 @@ __global__ __launch_bounds__(256) void pg_pack_kernel(PgSoaIn a, PgInRec *in, ui
                     u32 *dst = (u32 *)a.planes + (size_t)(lo + r0 + (s + u) * RPW + slot) * (16u * PB);
                     dst[2u * PB * pl + D] = Fd;
                     dst[2u * PB * (4u + pl) + D] = Rd;
+                }
+                // ---- the read-order seed filter's symbol programs (PgInRec::prog): the quad D = 0 of a read holds the first 32
+                // bases of its planes (lane p = plane p: code bit 0, code bit 1, N, other).  The sixteen program dwords of a read
+                // (two orientations x eight groups) are spread over the read's lanes -- lane L builds dword L (and L + 8 when a read
+                // has only eight lanes) -- so that the read's 64 bytes go out with ONE store instruction, contiguous.
+                {
+                    const u32 q0 = slot * LPR;
+                    const u32 flo = (u32)__shfl((int)Fd, (int)(q0 & 63u)), fhi = (u32)__shfl((int)Fd, (int)((q0 + 1u) & 63u)),
+                              fnn = (u32)__shfl((int)Fd, (int)((q0 + 2u) & 63u));
+                    const u32 rlo = (u32)__shfl((int)Rd, (int)(q0 & 63u)), rhi = (u32)__shfl((int)Rd, (int)((q0 + 1u) & 63u)),
+                              rnn = (u32)__shfl((int)Rd, (int)((q0 + 2u) & 63u));
+                    u32 *rec = (u32 *)(in + (lo + r0 + (s + u) * RPW + slot));
+#pragma unroll
+                    for (u32 h = 0; h < (LPR >= 16u ? 1u : 2u); h++) {
+                        const u32 q = L + 8u * h;                        // program dword: orientation q >> 3, group q & 7
+                        if (act[u] && q < 16u) {
+                            const u32 g = q & 7u;
+                            const bool o1 = q >= 8u;
+                            const u32 plo = o1 ? rlo : flo, phi = o1 ? rhi : fhi, pnn = o1 ? rnn : fnn;
+                            const u32 j = 3u * g + 1u;
+                            // three symbols at once: bit k of (plane >> j) to bit 8 k (x 0x4081, masked: bits 0 / 7 / 14 of the factor)
+                            const u32 l3 = (((plo >> j) & 7u) * 0x4081u) & 0x010101u, h3 = (((phi >> j) & 7u) * 0x4081u) & 0x010101u,
+                                      n3 = (((pnn >> j) & 7u) * 0x4081u) & 0x010101u;
+                            u32 w = l3 | (h3 << 1);
+                            if (o1) w ^= 0x030303u;                      // orientation 1's program holds the complement
+                            w = (w & ~(n3 * 3u)) | (n3 << 2);            // N: symbol 4
+                            w |= 0x30303030u;
+                            if (g == 0u) {                               // the seed: base 0
+                                u32 x = (plo & 1u) | ((phi & 1u) << 1);
+                                if (o1) x ^= 3u;
+                                if (pnn & 1u) x = 4u;
+                                w |= x << 24;
+                            }
+                            rec[16u + q] = w;
+                        }
+                    }
+                    // a base that is none of ACGTN among those a program can cover (lane 3 of the quad holds the "other" plane of
+                    // both orientations): the read keeps the symbol-by-symbol filter.  Rare; phase A's store of this dword has
+                    // completed (the loads of this phase were waited for behind it, and the vector memory counter retires in order).
+                    if (act[u] && L == 3u && ((Fd | Rd) & 0x1ffffffu)) atomicAnd(rec + 10, ~PG_RO_OK);
                 }
             }
         }

@@ -6,5 +6,5 @@ cd "$(dirname "$0")/../pindel_amd/csrc" || exit 1
 n=$1; shift
 mkdir -p build
 [ -f build/pg_api.o ] || make build/pg_api.o > /dev/null || exit 1
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -pthread --offload-arch=gfx950 -I../../include -I. ${KFLAGS--mllvm -disable-machine-licm -mllvm -phi-elim-split-all-critical-edges} "$@" -c -x hip pg_kernels.hip -o build/pg_kernels_$n.o 2>/dev/null || exit 1
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -pthread --offload-arch=gfx950 -I../../include -I. ${KFLAGS--mllvm -disable-machine-licm -mllvm -phi-elim-split-all-critical-edges} "$@" -c -x hip pg_kernels.hip -o build/pg_kernels_$n.o 2>build/pg_kernels_$n.log || { grep -A6 -E "error" build/pg_kernels_$n.log | head -40; exit 1; }
 /opt/rocm/bin/hipcc -shared -fPIC -pthread --offload-arch=gfx950 build/pg_kernels_$n.o build/pg_api.o -o ../libpindel_pg_$n.so

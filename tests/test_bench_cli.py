@@ -81,3 +81,24 @@ def test_a_launcher_of_the_wrong_size_is_refused():
     e = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + COMMON, cwd=ROOT, env=e, capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "launcher started 3" in (p.stdout + p.stderr)
+
+
+def test_eight_ranks_on_one_device_strong_and_weak(one_gpu_line):
+    # the SCALE tier's largest launch (--gpus 8) as far as a 1-GPU box can run it: eight processes, eight contexts on device 0,
+    # the read shards of ONE batch (strong) / eight batches (weak), one JSON line, the N = 1 digest
+    eight = _run([sys.executable, "bench.py", "--gpus", "8"] + COMMON, PG_BENCH_SHARE_GPU="1")
+    assert eight["n_gpus"] == 8 and eight["scaling"] == "strong"
+    assert eight["config"]["reads_total"] == 400000 and eight["config"]["reads_per_gpu"] == 50000
+    assert eight["config"]["result_sha256"] == one_gpu_line["config"]["result_sha256"]
+    weak = _run([sys.executable, "bench.py", "--gpus", "8", "--reads", "100000", "--steps", "2", "--warmup", "1",
+                 "--no-cpu-baseline", "--no-host-path"], PG_BENCH_SHARE_GPU="1")
+    assert weak["n_gpus"] == 8 and weak["scaling"] == "weak" and weak["config"]["reads_total"] == 800000
+    assert weak["value"] > 0
+
+
+def test_value_covers_the_pack_stage(one_gpu_line):
+    # round 6: a step = pg_pack_kernel + pg_search_kernel; the search-only figure of rounds 1-5 rides along
+    c = one_gpu_line["config"]
+    assert c["pack_ms_per_step"] > 0 and c["search_ms_per_step"] > 0
+    assert one_gpu_line["ms_per_step"] >= c["pack_ms_per_step"] + c["search_ms_per_step"] * 0.98
+    assert c["value_search_only"] > one_gpu_line["value"]
