@@ -28,6 +28,6 @@ if not os.environ.get("PG_PACK_ONLY"):        # (experiment builds whose pack ou
 lens = batch.lengths()
 ml = int(lens.max())
 blocks = 1 if ml <= 64 else 2 if ml <= 128 else 3 if ml <= 192 else 4 if ml <= 256 else 8
-nbytes = float(lens.sum()) + n * (8 + 11 + 64 * blocks + 32)
+nbytes = float(lens.sum()) + n * (8 + 11 + 64 * blocks + 128)
 print(os.path.basename(sys.argv[1]), "pack ms", round(min(ms), 4), "GB/s", round(nbytes / min(ms) / 1e6, 1), "search ms",
       round(eng.last_stats()[0], 3), "digest", h.hexdigest()[:16])
