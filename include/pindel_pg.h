@@ -130,7 +130,14 @@ typedef struct {
     const pg_run   *close_runs;  /* after CleanUniquePoints (pindel.cpp:2904-2941)                                  */
     const uint64_t *far_off;     /* n_reads+1 (all zero after pg_close_end_batch)                                   */
     const pg_run   *far_runs;    /* UP_Far                                                                          */
-    const uint8_t  *rc_flag;     /* 1: GetCloseEnd left UnmatchedSeq reverse-complemented (pindel.cpp:2545)         */
+    const uint8_t  *rc_flag;     /* how GetCloseEnd left UnmatchedSeq (pindel.cpp:2545 "setUnmatchedSeq(ReverseComplement())"):
+                                  * 0 as it came; 1 reverse-complemented once; 2 TWICE -- reported only for a read that holds a
+                                  * character outside ACGTN, which two reverse complements do not restore: Convert2RC4N
+                                  * (pindel.cpp:966-970) makes such characters NUL and setUnmatchedSeq (pindel.cpp:142-157) strips
+                                  * the trailing ones, so the read is SHORTER by what it began with (after the first) and ended with
+                                  * (after the second); every other read is its old self after two and keeps 0.  The search uses the
+                                  * shortened read from that attempt on, exactly as the reference does; an adapter restores the
+                                  * post-state by applying setUnmatchedSeq(ReverseComplement()) rc_flag times (pg_adapter.hpp).    */
 } pg_result_view;
 
 /* ---- lifetime ---------------------------------------------------------- */

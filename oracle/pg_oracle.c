@@ -304,27 +304,54 @@ static int clean_unique_points(orc_point *pts, int n)
     return m;
 }
 
-static int close_end_ws(const orc_params *P, const char *chr, int chr_id, char *seq, int len,
+/* setUnmatchedSeq, pindel.cpp:142-169: trailing characters that are not alphanumeric are stripped ("while
+ * (!isalnum(UnmatchedSeq[lastCharIndex])) resize"); ReadLength, MAX_SNP_ERROR and TOTAL_SNP_ERROR_CHECKED follow the new
+ * length (close_inner / far_end_ws take them from `len`).  (A string with NO alphanumeric character walks the reference's
+ * unsigned index below zero -- undefined there; here the length becomes 0 and nothing is found.) */
+static int strip_trailing_non_alnum(const char *seq, int len)
+{
+    while (len > 0) {
+        unsigned char c = (unsigned char)seq[len - 1];
+        if ((c >= '0' && c <= '9') || (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z')) break;
+        len--;
+    }
+    return len;
+}
+
+/* "Temp_One_Read.setUnmatchedSeq( ReverseComplement( Temp_One_Read.getUnmatchedSeq() ) )", pindel.cpp:2545: Convert2RC4N maps
+ * every character outside ACGTN to 0 (pindel.cpp:966-970: the table's other entries are zero-initialised), so the characters the
+ * read BEGAN with, if they are not ACGTN, arrive at the end as NULs and are stripped: the read gets SHORTER, and stays short. */
+static int rc_and_strip(char *seq, int len)
+{
+    char tmp[ORC_MAX_READ_LEN + 4];
+    reverse_complement(seq, len, tmp);
+    memcpy(seq, tmp, (size_t)len);
+    return strip_trailing_non_alnum(seq, len);
+}
+
+static int close_end_ws(const orc_params *P, const char *chr, int chr_id, char *seq, int *len_io,
                         char anchor_strand, int32_t anchor_pos, int16_t insert_size, int clean,
                         levels *a, levels *b, orc_point *out, int cap, int *rc_flag)
 {
     /* GetCloseEnd, pindel.cpp:2531-2575: MaxRange = 2; on failure the read is
-     * reverse-complemented (setUnmatchedSeq, :2545) and STAYS so. */
-    int n = 0, flipped = 0;
-    char tmp[ORC_MAX_READ_LEN + 4];
+     * reverse-complemented (setUnmatchedSeq, :2545) and STAYS so -- with whatever length setUnmatchedSeq left it. */
+    int n = 0, n_rc = 0, len = *len_io, other = 0;
+    for (int i = 0; i < len; i++) other |= rc4n(seq[i]) == 0;          /* a character two reverse complements do not restore */
     for (int range_index = 0; range_index < 2; range_index++) {
-        n = close_inner(P, chr, chr_id, seq, len, anchor_strand, anchor_pos, insert_size,
-                        range_index, a, b, out, cap);
+        n = len > 0 ? close_inner(P, chr, chr_id, seq, len, anchor_strand, anchor_pos, insert_size,
+                                  range_index, a, b, out, cap) : 0;
         if (n == 0) {
-            reverse_complement(seq, len, tmp);
-            memcpy(seq, tmp, (size_t)len);
-            flipped ^= 1;
-            n = close_inner(P, chr, chr_id, seq, len, anchor_strand, anchor_pos, insert_size,
-                            range_index, a, b, out, cap);
+            len = rc_and_strip(seq, len);
+            n_rc++;
+            n = len > 0 ? close_inner(P, chr, chr_id, seq, len, anchor_strand, anchor_pos, insert_size,
+                                      range_index, a, b, out, cap) : 0;
         }
         if (n > 0) break;
     }
-    if (rc_flag) *rc_flag = flipped;
+    /* 1: the read is left reverse-complemented; 2: it went through TWO reverse complements that did not give the original back
+     * (characters outside ACGTN are NUL now, those at either end are gone); 0: it is as it came */
+    if (rc_flag) *rc_flag = n_rc == 1 ? 1 : (n_rc == 2 && other ? 2 : 0);
+    *len_io = len;
     if (n > cap) n = cap;
     if (clean && n > 0) n = clean_unique_points(out, n);
     return n;
@@ -332,15 +359,16 @@ static int close_end_ws(const orc_params *P, const char *chr, int chr_id, char *
 
 int orc_close_end(const orc_params *P, const char *chr, uint64_t chr_len, int chr_id,
                   char *seq, int len, char anchor_strand, int32_t anchor_pos,
-                  int16_t insert_size, int clean, orc_point *out, int cap, int *rc_flag)
+                  int16_t insert_size, int clean, orc_point *out, int cap, int *rc_flag, int *len_out)
 {
     (void)chr_len;
     if (len <= 0 || len >= ORC_MAX_READ_LEN) return -1;
     levels a, b;
     memset(&a, 0, sizeof a);
     memset(&b, 0, sizeof b);
-    int n = close_end_ws(P, chr, chr_id, seq, len, anchor_strand, anchor_pos, insert_size, clean,
+    int n = close_end_ws(P, chr, chr_id, seq, &len, anchor_strand, anchor_pos, insert_size, clean,
                          &a, &b, out, cap, rc_flag);
+    if (len_out) *len_out = len;
     levels_free(&a);
     levels_free(&b);
     return n;
@@ -566,7 +594,7 @@ int orc_search_batch(const orc_params *P, int n_chr, const char *const *chr_seq,
                      const int32_t *anchor_pos, const int16_t *insert_size,
                      const int32_t *chr_id, const orc_window *bd, const uint64_t *bd_off,
                      int do_far, uint32_t stride, uint32_t *close_cnt, orc_point *close_pts,
-                     uint32_t *far_cnt, orc_point *far_pts, uint8_t *rc_flag, int n_threads)
+                     uint32_t *far_cnt, orc_point *far_pts, uint8_t *rc_flag, uint32_t *len_out, int n_threads)
 {
     int err = 0;
 #ifdef _OPENMP
@@ -597,10 +625,11 @@ int orc_search_batch(const orc_params *P, int n_chr, const char *const *chr_seq,
             int cid = chr_id[i];
             int flip = 0;
             orc_point *cp = close_pts ? close_pts + (size_t)i * stride : scratch_c;
-            int nc = close_end_ws(P, chr_seq[cid], cid, s, len, anchor_strand[i], anchor_pos[i],
+            int nc = close_end_ws(P, chr_seq[cid], cid, s, &len, anchor_strand[i], anchor_pos[i],
                                   insert_size[i], 1, &a, &b, cp, (int)stride, &flip);
             close_cnt[i] = (uint32_t)nc;
             rc_flag[i] = (uint8_t)flip;
+            if (len_out) len_out[i] = (uint32_t)len;           /* ReadLength as GetCloseEnd left it (the far end searches with it) */
             /* read_buffer.cpp:55: only reads with a close end go on */
             if (do_far && nc > 0) {
                 const orc_window *w = NULL;

@@ -63,16 +63,21 @@ void orc_default_params(orc_params *p);
  * GetCloseEnd (pindel.cpp:2531-2605) + CleanUniquePoints (pindel.cpp:2904-2941).
  * `seq` is the read's UnmatchedSeq (len bytes, already trimmed as
  * setUnmatchedSeq does); it is reverse-complemented IN PLACE exactly when the
- * reference leaves the read reverse-complemented.  Returns the number of
- * points written to `out` (0 = no close end).  *rc_flag = 1 iff seq was left
- * reverse-complemented.  If `clean` is non-zero CleanUniquePoints is applied.
+ * reference leaves the read reverse-complemented -- through setUnmatchedSeq, which
+ * strips the NULs that ReverseComplement puts where the read BEGAN with characters
+ * outside ACGTN: *len_out (nullable) = ReadLength afterwards.  Returns the number of
+ * points written to `out` (0 = no close end).  *rc_flag = 1: seq was left
+ * reverse-complemented; 2: it went through two reverse complements and holds a
+ * character outside ACGTN (so it is NOT the original again: those are NUL now, the
+ * ones at either end are gone); 0: as it came.  If `clean` is non-zero
+ * CleanUniquePoints is applied.
  */
 int orc_close_end(const orc_params *p,
                   const char *chr_seq, uint64_t chr_len, int chr_id,
                   char *seq, int len,
                   char anchor_strand, int32_t anchor_pos, int16_t insert_size,
                   int clean,
-                  orc_point *out, int cap, int *rc_flag);
+                  orc_point *out, int cap, int *rc_flag, int *len_out);
 
 /*
  * SearchFarEnd (pindel.cpp:1001-1074): BD-hint cluster first (may be empty),
@@ -108,7 +113,7 @@ int orc_search_batch(const orc_params *p,
                      int do_far, uint32_t stride,
                      uint32_t *close_cnt, orc_point *close_pts,
                      uint32_t *far_cnt, orc_point *far_pts,
-                     uint8_t *rc_flag, int n_threads);
+                     uint8_t *rc_flag, uint32_t *len_out /* nullable: ReadLength after the close end */, int n_threads);
 
 #ifdef __cplusplus
 }

@@ -60,7 +60,7 @@ def lib():
             C.POINTER(OrcParams), C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64),
             C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
             C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
-            C.c_void_p, C.c_void_p, C.c_int]
+            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -114,6 +114,7 @@ def search_batch(params: OrcParams, chr_seqs, seq: np.ndarray, seq_off: np.ndarr
     close_pts = np.zeros(n * stride if keep_points else 0, dtype=POINT_DTYPE)
     far_pts = np.zeros(n * stride if keep_points else 0, dtype=POINT_DTYPE)
     rc_flag = np.zeros(n, dtype=np.uint8)
+    len_out = np.zeros(n, dtype=np.uint32)
     bd_p = bd_off_p = None
     if bd is not None:
         bd = np.ascontiguousarray(bd, dtype=WINDOW_DTYPE)
@@ -124,12 +125,12 @@ def search_batch(params: OrcParams, chr_seqs, seq: np.ndarray, seq_off: np.ndarr
         anchor_strand.ctypes.data, anchor_pos.ctypes.data, insert_size.ctypes.data,
         chr_id.ctypes.data, bd_p, bd_off_p, 1 if do_far else 0, stride,
         close_cnt.ctypes.data, close_pts.ctypes.data if keep_points else None, far_cnt.ctypes.data,
-        far_pts.ctypes.data if keep_points else None, rc_flag.ctypes.data, n_threads)
+        far_pts.ctypes.data if keep_points else None, rc_flag.ctypes.data, len_out.ctypes.data, n_threads)
     if rc != 0:
         raise RuntimeError(f"orc_search_batch failed: {rc}")
     if not keep_points:
-        return dict(seq=seq, rc_flag=rc_flag, close_cnt=close_cnt, far_cnt=far_cnt, stride=stride)
-    return dict(seq=seq, rc_flag=rc_flag, close_cnt=close_cnt,
+        return dict(seq=seq, rc_flag=rc_flag, close_cnt=close_cnt, far_cnt=far_cnt, stride=stride, len_out=len_out)
+    return dict(seq=seq, rc_flag=rc_flag, close_cnt=close_cnt, len_out=len_out,
                 close_pts=close_pts.reshape(n, stride) if n else close_pts,
                 far_cnt=far_cnt, far_pts=far_pts.reshape(n, stride) if n else far_pts,
                 stride=stride)

@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpindel_pg.so")
+LIB_PATH = os.environ.get("PG_LIBRARY") or os.path.join(_HERE, "libpindel_pg.so")      # (PG_LIBRARY: an experiment build, scripts/build_variant.sh)
 
 PG_OK = 0
 PG_E_DEVICE = -3

@@ -29,6 +29,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cctype>
 #include <string>
 #include <thread>
 #include <type_traits>
@@ -79,6 +80,15 @@ inline std::string rc(const std::string &s)
     return o;
 }
 
+// setUnmatchedSeq's stripping (src/pindel.cpp:142-157): trailing characters that are not alphanumeric go -- after a reverse
+// complement those are the NULs Convert2RC4N put where the read BEGAN with characters outside ACGTN
+inline void strip_trailing_non_alnum(std::string &s)
+{
+    size_t n = s.size();
+    while (n > 0 && !std::isalnum((unsigned char)s[n - 1])) n--;
+    s.resize(n);
+}
+
 struct Batch {
     std::vector<uint8_t> seq, strand;
     std::vector<uint64_t> off;
@@ -119,7 +129,7 @@ Batch make_batch(const std::vector<Read> &reads, ChrOf chr_of, const uint8_t *un
             const Read &r = reads[i];
             const std::string &s = r.UnmatchedSeq;
             uint8_t *dst = b.seq.data() + b.off[i];
-            if (un_rc && un_rc[i])
+            if (un_rc && (un_rc[i] & 1))        // (2: two reverse complements -- the read is in its original orientation)
                 for (size_t j = 0; j < s.size(); j++) dst[j] = (uint8_t)rc_char(s[s.size() - 1 - j]);
             else
                 std::copy(s.begin(), s.end(), dst);
@@ -142,7 +152,14 @@ template <class T>
 struct has_set_seq<T, decltype((void)std::declval<T &>().setUnmatchedSeq(std::declval<const std::string &>()))> : std::true_type {};
 // "read.setUnmatchedSeq(ReverseComplement(read.getUnmatchedSeq()))" (src/pindel.cpp:2545)
 template <class Read> inline void flip_read(Read &r, std::true_type) { r.setUnmatchedSeq(rc(r.UnmatchedSeq)); }
-template <class Read> inline void flip_read(Read &r, std::false_type) { rc_in_place(r.UnmatchedSeq); }
+template <class Read> inline void flip_read(Read &r, std::false_type) { rc_in_place(r.UnmatchedSeq); strip_trailing_non_alnum(r.UnmatchedSeq); }
+// pg_result_view::rc_flag -> the read as GetCloseEnd left it: 1 = one "setUnmatchedSeq(ReverseComplement())", 2 = two (a read with
+// characters outside ACGTN is then NOT the original again: they are NUL, those at either end are gone; for every other read two
+// reverse complements are the identity and the flag stays 0)
+template <class Read> inline void apply_rc_flag(Read &r, uint8_t flag)
+{
+    for (uint8_t k = 0; k < flag && k < 2; k++) flip_read(r, has_set_seq<Read>());
+}
 
 // make_point(pg_point) -> the read type's UniquePoint; the runs [lo, hi) are expanded in place
 template <class Points, class MakePoint>
@@ -185,7 +202,7 @@ int CloseEndBatch(pg_ctx *ctx, std::vector<Read> &reads, ChrOf chr_of, MakePoint
     pg_result_view_get(*result, &rv);
     parallel_ranges(reads.size(), [&](size_t lo, size_t hi) {
         for (size_t i = lo; i < hi; i++) {
-            if (rv.rc_flag[i]) flip_read(reads[i], has_set_seq<Read>());
+            apply_rc_flag(reads[i], rv.rc_flag[i]);
             fill_points(reads[i].UP_Close, rv.close_runs, rv.close_off[i], rv.close_off[i + 1], make_point);
         }
     });

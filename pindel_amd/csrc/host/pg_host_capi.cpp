@@ -1,6 +1,7 @@
 // pg_host_capi.cpp -- C entry points of the host library (libpindel_host.so): the steps
 // before and after the hot path (loaders, classifiers, reporters), callable from tests and
 // from the pindel_pg command line.  No search code here.
+#include <cctype>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -80,7 +81,10 @@ int pgh_call_from_points(const char *fasta_path, const char *reads_path, const c
         for (size_t k = 0; k < reads.size(); k++) {
             const uint32_t i = index[k];
             SplitRead &r = reads[k];
-            if (rc_flag[i]) r.UnmatchedSeq = reverse_complement(r.UnmatchedSeq);
+            for (uint8_t k = 0; k < rc_flag[i] && k < 2; k++) {      // setUnmatchedSeq(ReverseComplement()), once or twice
+                r.UnmatchedSeq = reverse_complement(r.UnmatchedSeq);
+                while (!r.UnmatchedSeq.empty() && !std::isalnum((unsigned char)r.UnmatchedSeq.back())) r.UnmatchedSeq.pop_back();
+            }
             for (uint64_t q = close_off[i]; q < close_off[i + 1]; q++) r.UP_Close.push_back(to_up(close_pts[q]));
             for (uint64_t q = far_off[i]; q < far_off[i + 1]; q++) r.UP_Far.push_back(to_up(far_pts[q]));
         }

@@ -312,7 +312,7 @@ int run_bam_pipeline(const std::vector<Chromosome> &genome, const std::vector<un
                 SplitRead &r = kept[k];
                 r.Name = in.names[i];
                 r.UnmatchedSeq.assign((const char *)in.batch.seq.data() + in.batch.off[i], (size_t)(in.batch.off[i + 1] - in.batch.off[i]));
-                if (p.rc_flag[j]) pg_adapter::rc_in_place(r.UnmatchedSeq);          // setUnmatchedSeq(RC), pindel.cpp:2545
+                pg_adapter::apply_rc_flag(r, p.rc_flag[j]);                        // setUnmatchedSeq(RC), pindel.cpp:2545 (once or twice)
                 r.ReadLength = (short)r.UnmatchedSeq.size();
                 r.MatchedD = (char)in.batch.strand[i];
                 r.MatchedRelPos = (unsigned)in.batch.pos[i];

@@ -257,6 +257,10 @@ struct pg_device_batch {
     unsigned long long *run_tot = nullptr;   // running totals of the chunked delivery (zeroed with the outputs)
     uint64_t runs_used = 0;            // total runs of the last search
     int modes_done = 0;
+    // reads with a character outside ACGTN, listed by the pack kernel for the exact kernel (pg_search_exact_kernel)
+    uint32_t *exact_list = nullptr;    // [n]
+    uint32_t *exact_count = nullptr;   // device counter (zeroed with the outputs / before a pack of the whole batch)
+    long long exact_n = -1;            // host copy of the counter; -1: not read back (the exact kernel is launched regardless)
 };
 
 struct pg_result {
@@ -416,7 +420,8 @@ void free_batch_buffers(pg_device_batch *b)
     }
     void *ptrs[] = { b->planes, b->seq, b->seq_off, b->strand, b->pos, b->isz, b->chr, b->rc_flag,
                      b->close_last, b->close_max, b->bd_off, b->bd, b->close_off, b->close_cnt,
-                     b->far_off, b->far_cnt, b->alg, b->pool, b->pool_used, b->in_rec, b->out_rec, b->run_tot };
+                     b->far_off, b->far_cnt, b->alg, b->pool, b->pool_used, b->in_rec, b->out_rec, b->run_tot,
+                     b->exact_list, b->exact_count };
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -674,6 +679,7 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, HostBuf<uint
         // allocated, and a launch over a sub-range [lo, lo + cnt) of the batch touches at most record lo + cnt, which exists.
         { (void **)&b->in_rec, (n1 + PG_IN_PAD) * sizeof(PgInRec) },
         { (void **)&b->planes, n1 * 64 * pg_plane_blocks(max_len) },
+        { (void **)&b->exact_list, n1 * 4 },
         { (void **)&b->pool, (size_t)b->pool_shard_cap * PG_POOL_SHARDS * sizeof(pg_run) },
         // ---- zero-initialised from here
         { (void **)&b->rc_flag, n1 }, { (void **)&b->close_last, n1 * 4 }, { (void **)&b->close_max, n1 * 2 },
@@ -684,8 +690,9 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, HostBuf<uint
         // cycle accumulators of a -DPG_TIMING diagnostics build, which the kernel finds right behind its counters
         { (void **)&b->pool_used, (PG_POOL_SHARDS * 16 + 2 * (PG_WORK_CTRS * 16 + PG_DIAG_WORDS * 2)) * 4 },   // + a second set of read counters  // run-pool cursors + the launch's read counters
         { (void **)&b->run_tot, 64 },
+        { (void **)&b->exact_count, 64 },
     };
-    const size_t n_items = sizeof items / sizeof items[0], first_zero = 9;
+    const size_t n_items = sizeof items / sizeof items[0], first_zero = 10;
     auto drop = [&](int code) {
         free_batch_buffers(b);
         delete b;
@@ -756,6 +763,8 @@ PgSoaIn soa_in(const pg_ctx *ctx, const pg_device_batch *b)
     a.isz = b->isz;
     a.chr = b->chr;
     a.bd_off = b->bd_off;
+    a.exact_list = b->exact_list;
+    a.exact_count = b->exact_count;
     a.mm = ctx->d_mm;
     a.thr = ctx->d_thr;
     a.chr_word_off = ctx->d_word_off;
@@ -790,10 +799,27 @@ int stale_batch(pg_ctx *ctx, const pg_device_batch *b)
     return PG_OK;
 }
 
+// The length of the exact kernel's list, once the batch's pack has finished (synchronous entries only: a device-resident batch is
+// searched many times, and every search would otherwise carry a launch that finds nothing to do).
+int read_exact_count(pg_ctx *ctx, pg_device_batch *b)
+{
+    uint32_t n = 0;
+    if (b->n) {
+        HIP_TRY(ctx, hipMemcpyAsync(&n, b->exact_count, sizeof n, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    b->exact_n = n;
+    return PG_OK;
+}
+
 // Builds the packed records of reads [lo, lo + cnt) from the SoA inputs (on the ctx stream).
 int pack_reads(pg_ctx *ctx, pg_device_batch *b, uint32_t lo, uint32_t cnt, hipStream_t st = nullptr)
 {
     const PgSoaIn a = soa_in(ctx, b);
+    if (lo == 0 && cnt == b->n && b->n) {       // the whole batch (again): the exact kernel's list starts empty
+        HIP_TRY(ctx, hipMemsetAsync(b->exact_count, 0, sizeof(uint32_t), st ? st : ctx->stream));
+        b->exact_n = -1;
+    }
     int rc = pg_pack_reads(&a, b->in_rec, lo, cnt, st ? st : ctx->stream);
     if (rc) return fail(ctx, PG_E_DEVICE, std::string("pack kernel: ") + hipGetErrorString((hipError_t)rc));
     return PG_OK;
@@ -842,6 +868,9 @@ PgDevBatch dev_batch(const pg_device_batch *b)
     d.pool_used = b->pool_used;
     d.work_ctr = b->pool_used + PG_POOL_SHARDS * 16;
     d.claim = PG_CLAIM_DEFAULT;        // (pg_launch_search sets it from the launch's grid)
+    d.exact_list = b->exact_list;
+    d.exact_count = b->exact_count;
+    d.thr_tab = nullptr;               // (launch_range: the ctx's table)
     return d;
 }
 
@@ -879,8 +908,16 @@ int launch_range(pg_ctx *ctx, pg_device_batch *b, int mode, uint32_t lo, uint32_
         ctx->kargs_checked = true;
     }
     if (!fresh) HIP_TRY(ctx, hipMemsetAsync(d.work_ctr, 0, bytes, st));
+    d.thr_tab = ctx->d_thr;
     int lrc = pg_launch_search(&ref, &prm, &d, mode, b->max_len, b->levels, small_ids(ctx, b) ? 1 : 0, st);
     if (lrc != 0) return fail(ctx, PG_E_DEVICE, std::string("kernel launch: ") + hipGetErrorString((hipError_t)lrc));
+    // ... then, behind it on the same stream, the reads of this range that hold a character outside ACGTN, with the reference's
+    // read-shortening semantics (setUnmatchedSeq, pindel.cpp:142-169, 2545): a 64-workgroup launch that finds its list empty for
+    // every batch a sequencer produced -- skipped when the host has read the list's length and it is zero
+    if (b->exact_n != 0) {
+        lrc = pg_launch_search_exact(&ref, &prm, &d, mode, b->max_len, b->levels, st);
+        if (lrc != 0) return fail(ctx, PG_E_DEVICE, std::string("exact kernel launch: ") + hipGetErrorString((hipError_t)lrc));
+    }
     return PG_OK;
 }
 
@@ -1393,7 +1430,9 @@ int pg_device_batch_upload(pg_ctx *ctx, const pg_read_batch *reads, pg_device_ba
     use_device(ctx);
     if (!ctx || !out) return PG_E_INVALID;
     *out = nullptr;
-    return upload_batch(ctx, reads, out);
+    int rc = upload_batch(ctx, reads, out);
+    if (rc) return rc;
+    return read_exact_count(ctx, *out);
 }
 
 static int attach_windows(pg_ctx *ctx, pg_device_batch *b, const pg_windows *bd_hints);
@@ -1402,7 +1441,9 @@ int pg_device_batch_set_windows(pg_ctx *ctx, pg_device_batch *b, const pg_window
 {
     use_device(ctx);
     if (!ctx || !b) return PG_E_INVALID;
-    return attach_windows(ctx, b, bd_hints);
+    int rc = attach_windows(ctx, b, bd_hints);
+    if (rc) return rc;
+    return read_exact_count(ctx, b);
 }
 
 int pg_device_batch_search(pg_ctx *ctx, pg_device_batch *b)
@@ -1426,7 +1467,7 @@ int pg_device_batch_repack(pg_ctx *ctx, pg_device_batch *b, double *pack_ms)
     float ms = 0.f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     if (pack_ms) *pack_ms = ms;
-    return PG_OK;
+    return read_exact_count(ctx, b);
 }
 
 int pg_device_batch_download(pg_ctx *ctx, pg_device_batch *b, pg_result **out)

@@ -54,6 +54,7 @@ enum PgMode { PG_MODE_CLOSE = 1, PG_MODE_FAR = 2, PG_MODE_BOTH = 3 };
 #define PG_RF_SHARED_GRID 4u    // 0 < 3 InsertSize <= PG_CHUNK
 #define PG_RF_FIRST_OK_FWD 8u   // read[0] is one of ACGT (orientation 0: left to right)
 #define PG_RF_FIRST_OK_REV 16u  // read[len - 1] is (orientation 1: from the last base)
+#define PG_RF_EXACT 32u         // the read holds a character outside ACGTN: it is on the exact kernel's list (set by an atomic of the pack kernel)
 // The seed filter in READ ORDER (round 6, pg_kernels.hip "seed_filter_ro"): the consumed bases 1 .. 3 G in groups of three, the one-hot
 // plane of a base's symbol picked by VGPR index (s_set_gpr_idx): the symbols come as a PROGRAM, one dword per group -- byte k =
 // 0x30 | symbol of base 3 g + 1 + k (A 0, C 1, G 2, T 3, N 4; the 0x3 nibble is the index mode's operand enables when a 16-bit field
@@ -118,6 +119,12 @@ struct PgDevBatch {
     uint32_t *pool_used;           // [PG_POOL_SHARDS * 16]; cursor > pool_shard_cap means overflow (retry bigger)
     uint32_t *work_ctr;            // [PG_WORK_CTRS * 16] reads claimed per XCD part (zeroed before every launch)
     uint32_t claim;                // reads per claim (set by pg_launch_search: a workgroup's share in the fewest equal claims <= PG_CLAIM)
+    // the reads with a character outside ACGTN (pg_pack_kernel appends, pg_search_exact_kernel searches them again with the
+    // reference's read-shortening semantics) and CheckMismatches' threshold per read length (the exact kernel recomputes a read's
+    // length-dependent fields)
+    const uint32_t *exact_list;
+    const uint32_t *exact_count;
+    const uint16_t *thr_tab;       // [512]
 };
 
 // SoA views for the pack / unpack kernels
@@ -135,6 +142,8 @@ struct PgSoaIn {
     const int16_t *isz;
     const int32_t *chr;
     const uint64_t *bd_off;        // nullable
+    uint32_t *exact_list;          // nullable: indices of the reads with a character outside ACGTN ...
+    uint32_t *exact_count;         // ... and how many (zeroed by the caller before the batch's first pack)
     const uint32_t *mm;            // [512] g_maxMismatch
     const uint16_t *thr;           // [512]
     const uint64_t *chr_word_off;  // [n_chr] as PgDevRef
@@ -242,6 +251,9 @@ int pg_debug_kargs_check(const PgDevRef *ref, const PgDevParams *prm, const PgDe
 // 32-bit candidate ids (see above for when that is valid).
 int pg_launch_search(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch *batch,
                      int mode, uint32_t max_len, uint32_t levels, int small_ids, void *stream);
+// ... then the reads on the batch's exact list that lie in the launch's range, with the reference's read-shortening semantics
+int pg_launch_search_exact(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch *batch, int mode,
+                           uint32_t max_len, uint32_t levels, void *stream);
 // Device-side CSR of a result list: first the scan (gather = 0: csr[0..n] = exclusive sums of cnt, cnt has
 // n + 1 readable entries), then the gather (gather = 1: out[csr[i] + k] = pool[off[i] + k]).
 size_t pg_scan_tmp_bytes(uint32_t n);

@@ -1843,7 +1843,15 @@ __device__ __forceinline__ u32 pool_alloc(const PgDevBatch &B, int n, int lane, 
 //   close end   attempts (R0,seq) (R0,RC) (R1,RC) (R1,seq) until one yields points    pindel.cpp:2537-2575
 //   far end     BreakDancer cluster (if the read has one), then the ranges
 //               r = 1 .. MaxRangeIndex+1 until goodFarEndFound                          pindel.cpp:1006-1070
-template <int NB, int NS, typename Id, int mode, bool DEF>
+// EXACT (round 6): the instantiation for reads that hold a character outside ACGTN (pg_search_exact_kernel, a handful of reads if
+// any: the pack kernel lists them).  When an attempt fails the reference does "setUnmatchedSeq(ReverseComplement(seq))"
+// (pindel.cpp:2545): Convert2RC4N turns every such character into NUL (pindel.cpp:966-970), setUnmatchedSeq strips the NULs that
+// end up at the END (pindel.cpp:142-157) -- the characters the read BEGAN with -- and recomputes ReadLength, MAX_SNP_ERROR and
+// TOTAL_SNP_ERROR_CHECKED.  The read stays short: attempts 1 and 2 and a far end after them see RC(read) without its last `ja`
+// characters (ja = leading characters outside ACGTN); the second reverse complement before attempt 3 strips what the read ENDED
+// with (jb): attempt 3 and a far end after it see the read without either.  In plane terms: orientation 0 loses its first ja bits,
+// orientation 1 its first jb, the length and everything that follows from it (levels, thresholds, filter depths) shrink.
+template <int NB, int NS, typename Id, int mode, bool DEF, bool EXACT = false>
 __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevParams &prm, const PgDevBatch &B,
                                             Search &S, u64 *qplanes, const uint32_t rid, const int slot, const int lane,
                                             const u32 res_base, const u32 res_fits)
@@ -1873,8 +1881,8 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     // (load and wait in ONE statement: between two statements the compiler may spill or reuse the destination registers -- it
     // does not know that a scalar load is still in flight -- and the late data then lands on whatever lives there)
     asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(ra), "=&s"(rb) : "s"(rp));
-    const int len = (int)(ra[6] & 0xffffu);
-    const u32 flags = ra[6] >> 16;                          // PG_RF_*
+    int len = (int)(ra[6] & 0xffffu);                       // (changes only in the EXACT instantiation)
+    u32 flags = ra[6] >> 16;                                // PG_RF_*
     const int chr = (int)rb[3];
     const long long chr_wo = (long long)((u64)ra[4] | ((u64)ra[5] << 32));
     S.len = len;
@@ -1902,6 +1910,63 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
 #if defined(PG_STOP) && PG_STOP == 1       // diagnostics (wrong results): what do the claim and the start of a read cost?
     if (uni(opaque(1))) return;
 #endif
+    // ---- EXACT: the read's two shortenings
+    int ja = 0, jb = 0, ex_stage = 0;      // leading characters outside ACGTN of orientation 0 / 1; reverse complements applied so far
+    auto ex_apply = [&](int to) __attribute__((always_inline)) {
+        // one more "setUnmatchedSeq(ReverseComplement())": stage 1 drops the first ja bases of orientation 0, stage 2 the first jb of
+        // orientation 1 (what the reverse complement left at the end as NULs); then everything that depends on ReadLength
+        while (ex_stage < to) {
+            ex_stage++;
+            const int cut = ex_stage == 1 ? ja : jb;
+            u64 *pl = qplanes + (ex_stage == 1 ? 0 : 4 * NB);
+            if (cut > 0) {
+                const int l = opaque(lane);
+                u64 v = 0ull;
+                if (l < 4 * NB) {
+                    const int w = l % NB, wi = w + (cut >> 6), sh = cut & 63;
+                    const u64 lo_ = wi < NB ? pl[(l / NB) * NB + wi] : 0ull, hi_ = wi + 1 < NB ? pl[(l / NB) * NB + wi + 1] : 0ull;
+                    v = sh ? (lo_ >> sh) | (hi_ << (64 - sh)) : lo_;
+                }
+                PG_SYNC();
+                if (l < 4 * NB) pl[l] = v;
+                PG_SYNC();
+                len = len > cut ? len - cut : 0;
+            }
+        }
+        S.len = len;
+        S.M = max_mismatch_at(prm.mm_bp, len);
+        S.T = S.M + S.add_mm + 1;
+        S.thr = (int)uni((int)KA(B, thr_tab)[len]);
+        const int J0 = pg_seed_depth(len, S.T, 0), J1 = pg_seed_depth(len, S.T, 1);
+        const u32 b0 = (u32)min(S.T - 1, max_mismatch_at(prm.mm_bp, J0 < 0 ? 0 : J0) + S.add_mm),
+                  b1 = (u32)min(S.T - 1, max_mismatch_at(prm.mm_bp, J1 < 0 ? 0 : J1) + S.add_mm);
+        S.depth = (u32)(J0 < 0 ? 0 : J0) | ((u32)(J1 < 0 ? 0 : J1) << 8) | (b0 << 16) | (b1 << 24);
+        S.jmask[0] = J0 > 1 ? (low32(J0) & ~1u) : 0u;
+        S.jmask[1] = J1 > 1 ? (low32(J1) & ~1u) : 0u;
+        S.ro = 0u;
+        // is the first consumed base of either orientation one of ACGT ?  (bit 0 of the N / other planes)
+        const u32 f0 = (u32)uni((int)(u32)(qplanes[QP_NN * NB] | qplanes[QP_OO * NB])) & 1u,
+                  f1 = (u32)uni((int)(u32)(qplanes[4 * NB + QP_NN * NB] | qplanes[4 * NB + QP_OO * NB])) & 1u;
+        flags &= ~(PG_RF_FIRST_OK_FWD | PG_RF_FIRST_OK_REV);
+        if (!f0 && len > 0) flags |= PG_RF_FIRST_OK_FWD;
+        if (!f1 && len > 0) flags |= PG_RF_FIRST_OK_REV;
+    };
+    if (EXACT) {
+        // leading characters outside ACGTN = the run of set bits from bit 0 of the "other" plane
+        auto lead = [&](const u64 *oo) {
+            int n = 0;
+            for (int w = 0; w < NB; w++) {
+                const u64 x = (u64)(u32)uni((int)(u32)oo[w]) | ((u64)(u32)uni((int)(u32)(oo[w] >> 32)) << 32);
+                if (x == ~0ull) { n += 64; continue; }
+                n += __ffsll((long long)~x) - 1;
+                break;
+            }
+            return n < len ? n : len;
+        };
+        ja = lead(qplanes + QP_OO * NB);
+        jb = lead(qplanes + 4 * NB + QP_OO * NB);
+        S.add_mm = PRM(add_mm, PG_DEF_ADD_MM);
+    }
     const bool do_close = (mode & PG_MODE_CLOSE) != 0, do_far = (mode & PG_MODE_FAR) != 0;
     int flipped = 0, close_max = 0, n_close = 0;
     u32 close_last = 0, close_base = 0, alg = 0u;
@@ -1948,6 +2013,14 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                 S.t_base = att == 0 ? 1 : 4;
 #endif
                 flipped = (att == 1 || att == 2) ? 1 : 0;
+                if (EXACT && (att == 1 || att == 3)) {
+                    // the failed attempt's "setUnmatchedSeq(ReverseComplement())": the read may be shorter now, and nothing worked out for
+                    // the other length is valid any more
+                    ex_apply(att == 1 ? 1 : 2);
+                    cr0 = cr1 = co0 = co1 = 0u;
+                    vr = vo = 0u;
+                }
+                if (EXACT && len - 1 < PRM(min_close, PG_DEF_MIN_CLOSE)) return false;      // BP_End < BP_Start: no point (pindel.cpp:2268-2269)
                 // '+' anchor: CurrentReadSeq = RC(cur), grown left to right (pindel.cpp:2271-2291)
                 // '-' anchor: CurrentReadSeq = cur, grown right to left     (pindel.cpp:2298-2319)
                 Query<NB> Q;
@@ -2034,6 +2107,12 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
             PG_STOPPED(S);
         }
         if (n_close == 0) { flipped = 0; close_max = 0; }       // back to the original orientation
+        if (EXACT) {
+            // what GetCloseEnd left: 1 = reverse-complemented once; 2 = twice (attempt 3 ran, or nothing was found) -- NOT the original
+            // again for a read of this kernel: its characters outside ACGTN are NUL now, those at either end gone
+            if (n_close == 0) ex_stage = 2;       // (GetCloseEnd reverse-complements twice whether or not GetCloseEndInner could search)
+            flipped = ex_stage == 1 ? 1 : (ex_stage == 2 ? 2 : 0);
+        }
         alg = (u32)(8 * len + 3 * (close_bases + 2 * len) + 96 * n_close);   // x 8: the read once, 3 bits per base, 12 bytes per run
     } else {
         // far-end launch: the close-end summary of the earlier launch
@@ -2042,7 +2121,10 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
         close_max = uni((int)(o1.y & 0xffffu));
         flipped = uni((int)((o1.y >> 16) & 0xffu));
         alg = (u32)uni((int)o1.z) << 3;
+        if (EXACT) ex_apply(flipped);                          // the read as the close end left it (rc_flag 1 / 2)
     }
+    const int rc_out = flipped;                                // PgOutRec::rc_flag
+    if (EXACT) flipped &= 1;                                   // (orientation in hand for the far end: 2 = the original orientation)
 
     // ------------------------------------------------------------------------------- far end
 #ifdef PG_TIMING
@@ -2318,9 +2400,9 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
         if (do_close) {
             op[0] = make_uint4(close_base, (u32)n_close, far_base, (u32)n_far);
 #ifdef PG_DIAG
-            op[1] = make_uint4(close_last, (u32)close_max | ((u32)flipped << 16), alg, S.dg);
+            op[1] = make_uint4(close_last, (u32)close_max | ((u32)rc_out << 16), alg, S.dg);
 #else
-            op[1] = make_uint4(close_last, (u32)close_max | ((u32)flipped << 16), alg, (u32)S.nsurv_total);
+            op[1] = make_uint4(close_last, (u32)close_max | ((u32)rc_out << 16), alg, (u32)S.nsurv_total);
 #endif
         } else {
             u32 *o = (u32 *)op;
@@ -2440,6 +2522,70 @@ __global__ __launch_bounds__(WAVE, PG_WAVES(NB, Id)) void pg_search_kernel(PgDev
 #endif
 }
 
+// EXACT kernel (search_read<..., EXACT = true>): the reads the pack kernel listed because they hold a character outside ACGTN
+// (PgDevBatch::exact_list / exact_count), searched again with the reference's read-shortening semantics; their output records and runs
+// replace what the launch before wrote for them.  Same parameter list as pg_search_kernel (KA()).  One instantiation per mode: eight
+// blocks (any read the ABI accepts), five counter slices (any number of levels), 64-bit candidate ids (any window), generic
+// parameters -- speed is no concern for a handful of reads.  A small fixed grid walks the list; entries outside the launch's read
+// range [first_read, first_read + n_reads) are another chunk's.
+template <int mode>
+__global__ __launch_bounds__(WAVE, PG_WAVES(8, u64)) void pg_search_exact_kernel(PgDevRef ref, PgDevParams prm, PgDevBatch B,
+                                                                               uint32_t max_len, uint32_t levels)
+{
+    constexpr int NB = 8;
+    typedef u64 Id;
+    __shared__ Lds<NB, Id> lds;
+    const int lane = threadIdx.x;
+    for (int L = lane; L < 64 * NB + 64; L += WAVE) lds.mm_tab[L] = (uint8_t)max_mismatch_at(prm.mm_bp, L);
+    PG_SYNC();
+    Search S;
+    S.queue = lds.queue;
+    S.win = lds.win;
+    S.bufA = lds.bufA;
+    S.bufB = lds.bufB;
+    S.hdrB = lds.hdrB;
+    S.ringB = lds.ringB;
+    S.accB = lds.accB;
+    S.mm_tab = lds.mm_tab;
+    S.chr_tab = lds.chr_tab;
+    u64 *qplanes = lds.qp;
+    if (lane < 8 * NB) qplanes[lane] = 0ull;
+#ifdef PG_TIMING
+    S.t_acc = lds.t_acc;
+    S.t_last = &lds.t_last;
+    S.t_base = 1;
+#endif
+    const uint32_t n_list = *KA(B, exact_count), first = KA(B, first_read), n = KA(B, n_reads);
+    const uint32_t *list = KA(B, exact_list);
+    for (uint32_t i = blockIdx.x; i < n_list; i += gridDim.x) {
+        const uint32_t rid = (u32)uni((int)list[i]);
+        if (rid - first >= n) continue;
+        // (a read that was listed has rows of its own in the run pool: one reservation per read)
+        u32 res = 0u;
+        const u32 shard = blockIdx.x & (PG_POOL_SHARDS - 1u);
+        uint32_t *cur = KA(B, pool_used) + shard * 16u;
+        if (lane == 0) res = atomicAdd(cur, (u32)PG_RESERVE);
+        res = (u32)uni((int)res);
+        const u32 res_fits = (u64)res + (u64)PG_RESERVE <= (u64)KA(B, pool_shard_cap) ? 1u : 0u;
+        res += shard * KA(B, pool_shard_cap);
+        search_read<NB, 5, Id, mode, false, true>(ref, prm, B, S, qplanes, rid, 0, lane_now(), res, res_fits);
+    }
+}
+extern "C" int pg_launch_search_exact(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch *batch, int mode,
+                                      uint32_t max_len, uint32_t levels, void *stream)
+{
+    if (batch->n_reads == 0 || !batch->exact_list) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(64), block(WAVE);
+    if (mode == PG_MODE_BOTH)
+        hipLaunchKernelGGL((pg_search_exact_kernel<PG_MODE_BOTH>), grid, block, 0, st, *ref, *prm, *batch, max_len, levels);
+    else if (mode == PG_MODE_CLOSE)
+        hipLaunchKernelGGL((pg_search_exact_kernel<PG_MODE_CLOSE>), grid, block, 0, st, *ref, *prm, *batch, max_len, levels);
+    else
+        hipLaunchKernelGGL((pg_search_exact_kernel<PG_MODE_FAR>), grid, block, 0, st, *ref, *prm, *batch, max_len, levels);
+    return (int)hipGetLastError();
+}
+
 // Self-check of KA(): a kernel with pg_search_kernel's parameter list compares what KA() / KAP() fetch from the kernarg segment at
 // PgKArgs' offsets with the by-value arguments the compiler passes (one launch per context, pg_debug_kargs_check); a mismatch --
 // a changed parameter list, an ABI that lays the segment out differently -- is reported instead of searched with.
@@ -2455,6 +2601,7 @@ __global__ void pg_kargs_check_kernel(PgDevRef ref, PgDevParams prm, PgDevBatch 
     PG_CHK(prm, max_range_index); PG_CHK(prm, add_mm); PG_CHK(prm, min_perfect); PG_CHK(prm, min_close); PG_CHK(prm, spacer);
     PG_CHK(B, n_reads); PG_CHK(B, first_read); PG_CHK(B, in); PG_CHK(B, out); PG_CHK(B, seq); PG_CHK(B, planes); PG_CHK(B, plane_blocks);
     PG_CHK(B, bd); PG_CHK(B, pool); PG_CHK(B, pool_shard_cap); PG_CHK(B, pool_used); PG_CHK(B, work_ctr); PG_CHK(B, claim);
+    PG_CHK(B, exact_list); PG_CHK(B, exact_count); PG_CHK(B, thr_tab);
 #undef PG_CHK
     {
         const u32 *glo, *ghi, *gnn;
@@ -2800,6 +2947,12 @@ __global__ __launch_bounds__(256) void pg_pack_kernel(PgSoaIn a, PgInRec *in, ui
                     // both orientations): the read keeps the symbol-by-symbol filter.  Rare; phase A's store of this dword has
                     // completed (the loads of this phase were waited for behind it, and the vector memory counter retires in order).
                     if (act[u] && L == 3u && ((Fd | Rd) & 0x1ffffffu)) atomicAnd(rec + 10, ~PG_RO_OK);
+                    // ANY character outside ACGTN anywhere in the read (this lane: 32 bases of the "other" plane): the read goes on the
+                    // list of the exact kernel (pg_search_exact_kernel), once -- the flag in the record says who was first
+                    if (act[u] && pl == 3u && Fd != 0u && a.exact_list) {
+                        const u32 old = atomicOr(rec + 6, (u32)PG_RF_EXACT << 16);
+                        if (!(old & ((u32)PG_RF_EXACT << 16))) a.exact_list[atomicAdd(a.exact_count, 1u)] = lo + r0 + (s + u) * RPW + slot;
+                    }
                 }
             }
         }
