@@ -31,7 +31,7 @@ if ROOT not in sys.path:
 CHR20_LEN = 62_435_964       # demo/hs_ref_chr20.fa.fai:1
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # the round's committed counter files (scripts/profile_round.sh); PMC counters cannot be read from inside this process
-PROFILE_ROUND = next((r for r in ("r05", "r04") if os.path.exists(os.path.join(ROOT, "profiles", r, "hbm_traffic.json"))), "r05")
+PROFILE_ROUND = next((r for r in ("r06", "r05", "r04") if os.path.exists(os.path.join(ROOT, "profiles", r, "hbm_traffic.json"))), "r05")
 PROFILE_DIR = os.path.join(ROOT, "profiles", PROFILE_ROUND)
 TRAFFIC_FILE = "hbm_traffic.json"
 PMC_FILE = "pmc_sq.txt"

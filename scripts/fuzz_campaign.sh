@@ -13,4 +13,6 @@ cd "$root" || exit 1
     FUZZ_QUIET=1 timeout 900 python scripts/fuzz_parity.py ${N2:-600} 500000 2>&1 | grep -v amdgpu.ids | tail -3
     echo "== Pindel's default search parameters (seeds 300000-399999), each seed through the default-parameter AND the generic kernels"
     FUZZ_QUIET=1 FUZZ_BOTH_FAMILIES=1 timeout 1200 python scripts/fuzz_parity.py ${N3:-400} 310000 2>&1 | grep -v amdgpu.ids | tail -3
+    echo "== characters outside ACGTN in one read in twelve (seeds >= 600000): the exact kernel"
+    FUZZ_QUIET=1 timeout 900 python scripts/fuzz_parity.py ${N4:-300} 600000 2>&1 | grep -v amdgpu.ids | tail -3
 } | tee "$out/fuzz_log.txt"

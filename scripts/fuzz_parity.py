@@ -103,6 +103,32 @@ def one_iteration(seed, n_reads=1500, verbose=True, generic=False):
     # full of repeats and most of them have no close end at all
     k = n_reads // 3
     batch.anchor_pos[:k] = rng.integers(2 * isz + 10, length - 2 * isz - 10, k).astype(np.int32)
+    # seeds from 600000 on: characters outside ACGTN (IUPAC codes, lower case, '*', '=') at the start, the end or inside of one
+    # read in twelve -- the reads the reference shortens when it reverse-complements them (setUnmatchedSeq, pindel.cpp:142-169);
+    # they go through pg_search_exact_kernel
+    if seed >= 600000:
+        junk = np.frombuffer(b"RYKMSWBDHVrykmacgtn*=.", dtype=np.uint8)
+        off = batch.seq_off.astype(np.int64)
+        for i in np.nonzero(rng.random(n_reads) < 1.0 / 12)[0]:
+            a, b = int(off[i]), int(off[i + 1])
+            how = int(rng.integers(0, 6))
+            k1, k2 = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+            if how in (0, 2, 5):
+                batch.seq[a:a + k1] = junk[rng.integers(0, len(junk), k1)]
+            if how in (1, 2, 5):
+                batch.seq[b - k2:b] = junk[rng.integers(0, 10, k2)]          # (alphanumeric at the very end: setUnmatchedSeq at creation)
+            if how in (3, 4, 5):
+                m = int(rng.integers(1, 4))
+                batch.seq[rng.integers(a, b, m)] = junk[rng.integers(0, len(junk), m)]
+            if how == 4 and b - a > 8:                                        # reverse-complemented behind the junk: attempt 1 finds it
+                body = batch.seq[a + 1:b].copy()
+                comp = np.zeros(256, dtype=np.uint8)
+                for x, y in zip(b"ACGTN", b"TGCAN"):
+                    comp[x] = y
+                batch.seq[a + 1:b] = comp[body][::-1]
+                batch.seq[a] = junk[rng.integers(0, 10)]
+            if not ((48 <= batch.seq[b - 1] <= 57) or (65 <= batch.seq[b - 1] <= 90) or (97 <= batch.seq[b - 1] <= 122)):
+                batch.seq[b - 1] = ord("R")
     # a third of the iterations: a second chromosome and per-read BreakDancer window clusters (0-4 windows,
     # some on the other chromosome, some with start < 0, some overlapping), searched before the ranges
     bd = bd_off = None

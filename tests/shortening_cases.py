@@ -41,7 +41,8 @@ def batch_of(seqs, strand, pos, isz, chr_id=0):
     off[1:] = np.cumsum([len(s) for s in seqs])
     return ReadBatch(seq=np.frombuffer(b"".join(seqs), dtype=np.uint8).copy(), seq_off=off,
                      anchor_strand=np.asarray(strand, dtype=np.uint8), anchor_pos=np.asarray(pos, dtype=np.int32),
-                     insert_size=np.asarray(isz, dtype=np.int16), chr_id=np.full(len(seqs), chr_id, dtype=np.int32))
+                     insert_size=np.asarray(isz, dtype=np.int16),
+                     chr_id=np.full(len(seqs), chr_id, dtype=np.int32) if np.isscalar(chr_id) else np.asarray(chr_id, dtype=np.int32))
 
 
 def seqs_of(batch):

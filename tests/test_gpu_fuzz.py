@@ -48,3 +48,11 @@ def test_fuzz_block_both_kernel_families(block):
     for seed in range(300100 + 10 * block, 300110 + 10 * block):
         assert one_iteration(seed, verbose=False), seed
         assert one_iteration(seed, verbose=False, generic=True), (seed, "generic kernels")
+
+
+# ... and 30 seeds of the stream with characters outside ACGTN in one read in twelve (seeds >= 600000): the reads the reference shortens
+# when it reverse-complements them, searched by pg_search_exact_kernel (random parameters, lengths, window clusters as above)
+@pytest.mark.parametrize("block", range(3))
+def test_fuzz_block_characters_outside_acgtn(block):
+    for seed in range(600000 + 10 * block, 600010 + 10 * block):
+        assert one_iteration(seed, verbose=False), seed

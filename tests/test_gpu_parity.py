@@ -748,6 +748,13 @@ def test_adapter_on_reference_shapes(engine_factory, tmp_path):
         f.write(">tail\nA\n")
     chroms_loaded = chroms + [("tail", b"N" * spacer + b"AA" + b"N" * spacer)]
     batch = synth.make_reads_genome(chroms, 2500, seed=23)
+    # every 25th read arrives reverse-complemented behind a character outside ACGTN: GetCloseEnd's first
+    # setUnmatchedSeq(ReverseComplement()) strips it, the read type's own setUnmatchedSeq (pg_adapter::apply_rc_flag) does so here
+    from tests import shortening_cases as sc
+    seqs = sc.seqs_of(batch)
+    for i in range(0, batch.n, 25):
+        seqs[i] = b"K" + sc.rc_ref(seqs[i])
+    batch = sc.batch_of(seqs, batch.anchor_strand, batch.anchor_pos, batch.insert_size, batch.chr_id)
     tab = tmp_path / "reads.txt"
     with open(tab, "w") as f:
         for i in range(batch.n):
@@ -769,9 +776,12 @@ def test_adapter_on_reference_shapes(engine_factory, tmp_path):
         i = int(tok[0][1:])
         k = 1
         if not first:
-            s = bytes(batch.seq[batch.seq_off[i]:batch.seq_off[i + 1]])
-            want = s.translate(comp)[::-1] if orc["rc_flag"][i] else s
-            assert tok[1].encode() == want, f"read {i}: UnmatchedSeq"
+            a = int(batch.seq_off[i])
+            want = bytes(orc["seq"][a:a + int(orc["len_out"][i])])      # UnmatchedSeq as GetCloseEnd left it
+            if i % 25:
+                s = bytes(batch.seq[batch.seq_off[i]:batch.seq_off[i + 1]])
+                assert want == (s.translate(comp)[::-1] if orc["rc_flag"][i] else s)
+            assert b"\0" not in want and tok[1].encode() == want, f"read {i}: UnmatchedSeq"
             k = 2
         while k < len(tok):
             which = {"C": "close", "F": "far"}[tok[k]]
@@ -784,3 +794,5 @@ def test_adapter_on_reference_shapes(engine_factory, tmp_path):
             assert got == exp, f"read {i} {which}{' (one-flush overload)' if first else ''}"
     assert len(lines) - n_first == batch.n and n_first == 700
     assert (orc["far_cnt"] > 0).sum() > 800
+    short = [i for i in range(0, batch.n, 25) if orc["rc_flag"][i] == 1]
+    assert len(short) > 40 and all(orc["len_out"][i] == int(batch.seq_off[i + 1] - batch.seq_off[i]) - 1 for i in short)
