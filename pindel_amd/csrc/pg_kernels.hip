@@ -1856,6 +1856,11 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                                             Search &S, u64 *qplanes, const uint32_t rid, const int slot, const int lane,
                                             const u32 res_base, const u32 res_fits)
 {
+    // The lane index where the rest of a read needs it.  Kept from the start of the read it is a VGPR the compiler parks in scratch in
+    // the kernels for reads of up to 128 bases (8 bytes per lane: a store per read and a reload per use -- 190 bytes of HBM writes per
+    // read, profiles/r06): worked out again instead (two v_mbcnt; +18 vector instructions per read, +0.3 % time, no scratch).  The
+    // longer classes keep the value (recomputing cost them 1 %).
+#define PG_LANE (NB <= 2 ? lane_now() : opaque(lane))
     S.win_wo = -1;
     S.win_hi = S.wbase = 0;
     S.nsurv_total = 0u;
@@ -1920,7 +1925,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
             const int cut = ex_stage == 1 ? ja : jb;
             u64 *pl = qplanes + (ex_stage == 1 ? 0 : 4 * NB);
             if (cut > 0) {
-                const int l = opaque(lane);
+                const int l = PG_LANE;
                 u64 v = 0ull;
                 if (l < 4 * NB) {
                     const int w = l % NB, wi = w + (cut >> 6), sh = cut & 63;
@@ -2053,7 +2058,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                 const bool own_grid = att == 0 && !shared_grid;
                 PG_STOP_AT_V(S, 12, true);
                 scan_range<NB, NS, Id>(ref, S, Q, A, chr_wo, own_grid ? s1 : w1s, s1, e1, own_grid ? e1 : w1e, ps, pe, w1s, 0u,
-                                   opaque(lane), (att == 1 || att == 2 ? 1u : 0u) | shared_grid, cr0, cr1, vr);
+                                   PG_LANE, (att == 1 || att == 2 ? 1u : 0u) | shared_grid, cr0, cr1, vr);
                 PG_STOPPED_V(S, true);
                 PG_STOP_AT_V(S, 19, true);
                 ps = s1;
@@ -2066,7 +2071,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                         Acc<NB, Id> A2 = A;
                         A2.m1 = (u32)opaque((int)A.m1); A2.a1 = (u32)opaque((int)A.a1);
                         Eval<NB, Id> E2;
-                        evaluate<NB, Id>(S, A2, E2, opaque(lane));
+                        evaluate<NB, Id>(S, A2, E2, PG_LANE);
                         {
                             u32 chk = (u32)E2.n_runs ^ (u32)E2.max_len ^ (u32)E2.id_last;
 #pragma unroll
@@ -2075,7 +2080,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                         }
                     }
 #endif
-                    evaluate<NB, Id>(S, A, E, opaque(lane));
+                    evaluate<NB, Id>(S, A, E, PG_LANE);
                     PG_STOP_AT_V(S, 20, true);
                     close_max = uni(E.max_len);
                     if (uni(E.n_runs) > 0) {
@@ -2088,9 +2093,9 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                         } else
                             close_base = pool_alloc(B, n_close, lane, fits);
 #if defined(PG_DUP) && PG_DUP == 7
-                        if (fits) emit_runs<NB, Id>(S, true, false, chr, opaque(w1s), nullptr, E, kept, KA(B, pool) + close_base, opaque(lane));
+                        if (fits) emit_runs<NB, Id>(S, true, false, chr, opaque(w1s), nullptr, E, kept, KA(B, pool) + close_base, PG_LANE);
 #endif
-                        if (fits) emit_runs<NB, Id>(S, true, false, chr, w1s, nullptr, E, kept, KA(B, pool) + close_base, opaque(lane));
+                        if (fits) emit_runs<NB, Id>(S, true, false, chr, w1s, nullptr, E, kept, KA(B, pool) + close_base, PG_LANE);
                         // AbsLoc of the last point (getLastAbsLocCloseEnd)
                         const u64 idl = (u64)E.id_last;
                         const int pl = w1s + (int)(u32)(idl & ((1ull << IdFmt<Id>::RB) - 1ull));
@@ -2165,7 +2170,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                     Acc<NB, Id> A2 = A;
                     A2.m1 = (u32)opaque((int)A.m1); A2.a1 = (u32)opaque((int)A.a1);
                     Eval<NB, Id> E2;
-                    evaluate<NB, Id>(S, A2, E2, opaque(lane), qmask);
+                    evaluate<NB, Id>(S, A2, E2, PG_LANE, qmask);
                     {
                         u32 chk = (u32)E2.n_runs ^ (u32)E2.max_len ^ (u32)E2.id_last;
 #pragma unroll
@@ -2174,7 +2179,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                     }
                 }
 #endif
-                evaluate<NB, Id>(S, A, E, opaque(lane), qmask);
+                evaluate<NB, Id>(S, A, E, PG_LANE, qmask);
                 const int mx = uni(E.max_len);
                 if (mx >= far_max) {
                     far_max = mx;
@@ -2192,9 +2197,9 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                             fits &= f2;
                         }
 #if defined(PG_DUP) && PG_DUP == 7
-                        if (fits) emit_runs<NB, Id>(S, false, true, chr, opaque(origin), bdw, E, kept, KA(B, pool) + far_base, opaque(lane));
+                        if (fits) emit_runs<NB, Id>(S, false, true, chr, opaque(origin), bdw, E, kept, KA(B, pool) + far_base, PG_LANE);
 #endif
-                        if (fits) emit_runs<NB, Id>(S, false, true, chr, origin, bdw, E, kept, KA(B, pool) + far_base, opaque(lane));
+                        if (fits) emit_runs<NB, Id>(S, false, true, chr, origin, bdw, E, kept, KA(B, pool) + far_base, PG_LANE);
                     }
                 }
             };
@@ -2215,7 +2220,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                     const int s = st < 0 ? 0 : st, e = bw.end > csz ? csz : bw.end;
                     far_bases += (e > s ? e - s : 0) + 2 * len;
                     scan_range<NB, NS, Id>(ref, S, Q, A, own_chr ? chr_wo : chr_word_off_of<NB>(ref, S, uni(bw.chr_id)), s, s, e, e, 0, 0, st,
-                                       (u32)w, opaque(lane), false, unused0, unused1, unused_valid);
+                                       (u32)w, PG_LANE, false, unused0, unused1, unused_valid);
                     PG_STOPPED(S);
                 }
                 if (S.nsurv > 0) far_update(0, bd, 15);
@@ -2280,7 +2285,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
 #if defined(PG_DUP) && PG_DUP == 8
                         {
                             u32 dF, dB;
-                            seed_filter<NB, NS, true>(S, Q, false, false, opaque(lane), dF, dB);
+                            seed_filter<NB, NS, true>(S, Q, false, false, PG_LANE, dF, dB);
                             mF &= dF | (u32)opaque(0);
                             mB &= dB | (u32)opaque(0);
                         }
@@ -2325,7 +2330,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                                 {
                                     Acc<NB, Id> A2 = A;
                                     int rn2[3];
-                                    fold_candidates<NB, Id, true>(S, Q, A2, wb, origin, 0u, total, opaque(lane),
+                                    fold_candidates<NB, Id, true>(S, Q, A2, wb, origin, 0u, total, PG_LANE,
                                                                   Rings{ true, rs[0], re[0], rs[1], re[1] }, rn2);
                                     if (A2.m1 == 0x12345u) A.m1 = A2.m2;
                                 }
@@ -2343,7 +2348,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
 #if defined(PG_DUP) && PG_DUP == 6
                                         {
                                             Acc<NB, Id> A2 = A;
-                                            fold_tier_b<NB, Id>(S, Q, A2, longm, opaque(lane));
+                                            fold_tier_b<NB, Id>(S, Q, A2, longm, PG_LANE);
                                             if (A2.m1 == 0x12345u) A.m1 = A2.m2;
                                         }
 #endif
@@ -2369,7 +2374,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                     int s, e;
                     range_of(span, s, e);
                     if (s < e) {
-                        scan_range<NB, NS, Id>(ref, S, Q, A, chr_wo, g0, s, e, emax, ps, pe, origin, 0u, opaque(lane), true,
+                        scan_range<NB, NS, Id>(ref, S, Q, A, chr_wo, g0, s, e, emax, ps, pe, origin, 0u, PG_LANE, true,
                                            cacheF, cacheB, cache_valid);
                         PG_STOPPED(S);
                         if (ps < pe) {
@@ -2395,7 +2400,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     PG_STOP_AT(S, 32);
     PG_T(S, 9);
     alg = (alg + 4u) >> 3;
-    if (lane == 0) {
+    if (PG_LANE == 0) {      // (the lane index again: kept from the start of the read it is a VGPR the compiler parks in scratch)
         uint4 *op = (uint4 *)record_ptr<5>(KA(B, out), rid);
         if (do_close) {
             op[0] = make_uint4(close_base, (u32)n_close, far_base, (u32)n_far);
@@ -2413,6 +2418,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
         }
     }
 }
+#undef PG_LANE
 
 // Persistent 64-thread workgroups.  The reads of the launch are split into PG_N_XCD contiguous parts; a
 // workgroup (which the dispatcher places on XCD blockIdx % 8) claims PG_CLAIM reads at a time from its own

@@ -27,8 +27,14 @@ d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][0])
 rows = [r for r in csv.DictReader(open(sys.argv[2])) if "pg_search_kernel" in r["Name"]]
 avg = float(rows[0]["AverageNs"]) / 1e6 if rows else float("nan")
 calls = rows[0]["Calls"] if rows else "?"
-print(f"same run, 10 M reads: tracer AverageNs {avg:.3f} ms over {calls} launches | HIP-event kernel_ms {d['roofline']['kernel_ms']:.3f} | "
-      f"ms_per_step {d['ms_per_step']:.3f} | value {d['value'] / 1e6:.1f} M reads/s | spread {100 * (max(avg, d['ms_per_step'], d['roofline']['kernel_ms']) / min(avg, d['ms_per_step'], d['roofline']['kernel_ms']) - 1):.2f} %")
+prow = [r for r in csv.DictReader(open(sys.argv[2])) if "pg_pack_kernel" in r["Name"]]
+pavg = float(prow[0]["AverageNs"]) / 1e6 if prow else float("nan")
+c = d["config"]
+step_events = c["search_ms_per_step"] + c["pack_ms_per_step"]
+print(f"same run, 10 M reads: pg_search_kernel tracer AverageNs {avg:.3f} ms over {calls} launches | HIP-event kernel_ms {d['roofline']['kernel_ms']:.3f} | "
+      f"pg_pack_kernel tracer {pavg:.3f} ms | HIP-event {c['pack_ms_per_step']:.3f} | step = pack + search: events {step_events:.3f} ms, tracer {avg + pavg:.3f} ms, "
+      f"wall ms_per_step {d['ms_per_step']:.3f} | value {d['value'] / 1e6:.1f} M reads/s (search only {c['value_search_only'] / 1e6:.1f}) | "
+      f"spread of the three step times {100 * (max(step_events, avg + pavg, d['ms_per_step']) / min(step_events, avg + pavg, d['ms_per_step']) - 1):.2f} %")
 PY
 
 # 2. the SQ counter passes of the search kernel (bench workload unless PG_X / PG_LEN say otherwise)
@@ -47,6 +53,7 @@ pmc_set "$out/pmc_sq.txt" PG_NONE=1
 cat "$out/pmc_sq.txt"
 pmc_set "$out/pmc_sq_x5.txt" PG_X=5
 pmc_set "$out/pmc_sq_150bp.txt" PG_LEN=150
+pmc_set "$out/pmc_sq_wgsreal.txt" PG_LEN=150 PG_SORT=1 PG_MIX=0.02,0.01,0.01,0.01,0.95
 
 # 3. HBM traffic of the search kernel: FETCH_SIZE / WRITE_SIZE in passes of their own + the calibration stream
 rm -rf /tmp/rp_fetch /tmp/rp_write /tmp/rp_calib /tmp/rp_stats
@@ -77,7 +84,7 @@ python scripts/pack_rate.py pindel_amd/libpindel_pg.so 10000000 2>/dev/null | ta
 PG_LEN=150 python scripts/pack_rate.py pindel_amd/libpindel_pg.so 10000000 2>/dev/null | tail -1 >> "$out/pack_rate.txt"
 cat "$out/pack_rate.txt"
 {
-    for w in colo-bd repeat-rich wgs-bins grch38-150; do
+    for w in colo-bd repeat-rich wgs-bins grch38-150 wgs-real; do
         python bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-host-path 2>/dev/null | tail -1
     done
     python bench.py --steps 3 --warmup 1 --max-range-index 5 --reads 2000000 --no-cpu-baseline --no-host-path 2>/dev/null | tail -1

@@ -19,6 +19,8 @@ if os.environ.get("PG_X"):
     kw["max_range_index"] = int(os.environ["PG_X"])
 if os.environ.get("PG_LEN"):
     rkw["read_len"] = int(os.environ["PG_LEN"])
+if os.environ.get("PG_MIX"):          # fractions of (D, SI, TD, INV, none), e.g. the wgs-real workload's 0.04,0.02,0.02,0.02,0.9
+    rkw["mix"] = tuple(float(x) for x in os.environ["PG_MIX"].split(","))
 batch = synth.make_reads(ref, n, seed=20260928, device=dev, **rkw)
 if os.environ.get("PG_SORT"):
     # coordinate order (every window a neighbour's window: the L2-resident upper bound of any prefetching)
