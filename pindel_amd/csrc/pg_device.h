@@ -63,7 +63,7 @@ enum PgMode { PG_MODE_CLOSE = 1, PG_MODE_FAR = 2, PG_MODE_BOTH = 3 };
 // consumes (kind F reads them as they are; kind B reads the complement, and its planes are laid out in complement order).
 #define PG_RO_GROUPS_MAX 8
 #define PG_RO_GROUPS_MIN 4
-#define PG_RO_OK 0x80000000u     // PgInRec::ro: this read may take the read-order filter (<= 8 mismatch levels, >= 4 groups, ACGTN only
+#define PG_RO_OK 0x80000000u     // PgInRec::ro: this read may take the read-order filter (<= 16 mismatch levels, >= 4 groups, ACGTN only
                                  // among the bases a program covers, g_MinClose >= 8)
 struct PgInRec {
     // dwords 0 .. 11: fetched at the start of a read

@@ -1196,14 +1196,14 @@ __device__ __forceinline__ void seed_filter_run(const Search &S, const Query<NB>
     "v_bitop3_b32 " dA ", " x ", " y ", " z " bitop3:0x01\n\tv_bitop3_b32 " dC ", " x ", " y ", " z " bitop3:0x10\n\t" \
     "v_bitop3_b32 " dG ", " x ", " y ", " z " bitop3:0x04\n\tv_bitop3_b32 " dT ", " x ", " y ", " z " bitop3:0x40\n\t" \
     "v_not_b32 " dN ", " z "\n\t"
-// three match masks into the counter (c0 c1 c2, sticky overflow ov): the adds of PG_ADD3 / PG_UP3; temporaries v35 .. v38
-#define RO_ADD3(c0, c1, c2, ov, ma, mb, mc)                                                                           \
+// three match masks into the counter (c0 c1 c2 [c3], sticky overflow ov): the adds of PG_ADD3 / PG_UP3 / PG_UP4; temporaries v35 .. v38
+#define RO_ADD3_CORE(c0, c1, ma, mb, mc)                                                                              \
     "v_bitop3_b32 v35, " ma ", " mb ", " mc " bitop3:0x69\n\tv_bitop3_b32 v36, " ma ", " mb ", " mc " bitop3:0x17\n\t"   \
     "v_and_b32 v37, " c0 ", v35\n\tv_xor_b32 " c0 ", " c0 ", v35\n\t"                                                   \
-    "v_bitop3_b32 v38, " c1 ", v36, v37 bitop3:0xe8\n\tv_bitop3_b32 " c1 ", " c1 ", v36, v37 bitop3:0x96\n\t"           \
-    "v_bitop3_b32 " ov ", " c2 ", v38, " ov " bitop3:0xea\n\tv_xor_b32 " c2 ", " c2 ", v38\n\t"
-// one group: P = the SGPR with the group's program dword; F planes (own, next word) = v48.. / v53.., B planes (previous, own word,
-// complement order) = v58.. / v63..: the instruction names register - 48
+    "v_bitop3_b32 v38, " c1 ", v36, v37 bitop3:0xe8\n\tv_bitop3_b32 " c1 ", " c1 ", v36, v37 bitop3:0x96\n\t"
+#define RO_UP3(c2, ov) "v_bitop3_b32 " ov ", " c2 ", v38, " ov " bitop3:0xea\n\tv_xor_b32 " c2 ", " c2 ", v38\n\t"
+#define RO_UP4(c2, c3, ov) "v_and_b32 v37, " c2 ", v38\n\tv_xor_b32 " c2 ", " c2 ", v38\n\t"                            \
+                           "v_bitop3_b32 " ov ", " c3 ", v37, " ov " bitop3:0xea\n\tv_xor_b32 " c3 ", " c3 ", v37\n\t"
 // (the index changes of a group as macros of their own: scripts/test_rofilter.hip builds variants of them)
 #ifndef RO_IDX_ON
 #define RO_IDX_ON(P) "s_set_gpr_idx_on " P ", 0x3\n\t"
@@ -1217,7 +1217,9 @@ __device__ __forceinline__ void seed_filter_run(const Search &S, const Query<NB>
     RO_IDX_ON(P) "v_alignbit_b32 v32, v5, v0, " #s1 "\n\t"                                                              \
     RO_IDX_1(P) "v_alignbit_b32 v33, v5, v0, " #s2 "\n\t"                                                               \
     RO_IDX_2(P) "v_alignbit_b32 v34, v5, v0, " #s3 "\n\t" RO_IDX_OFF
-#define RO_AD RO_ADD3("v40", "v41", "v42", "v43", "v32", "v33", "v34")
+// counter: slices v40 v41 v42 (+ v44 when a read may have up to 16 mismatch levels), sticky overflow v43
+#define RO_AD3 RO_ADD3_CORE("v40", "v41", "v32", "v33", "v34") RO_UP3("v42", "v43")
+#define RO_AD4 RO_ADD3_CORE("v40", "v41", "v32", "v33", "v34") RO_UP4("v42", "v44", "v43")
 // The program comes in two halves into the SAME four registers (groups 1 .. 4, then 5 .. 8: the second fetch is issued when group 4's
 // index changes are done and is waited for behind that group's add), the seed's index is kept in s88: five scalar registers, the
 // highest s88 -- with VCC, FLAT_SCRATCH and XNACK_MASK that is 95 of the 96 a wave may have at seven waves per SIMD (the first
@@ -1238,89 +1240,85 @@ __device__ __forceinline__ void seed_filter_run(const Search &S, const Query<NB>
 #define RO_G7(M) M("s86", 19, 20, 21, 13, 12, 11)
 #define RO_G8(M) M("s87", 22, 23, 24, 10, 9, 8)
 #define RO_EXIT(k) "s_cmp_eq_u32 %[G], " #k "\n\ts_cbranch_scc1 9f\n\t"
-// counter start 7 - (T - 1) = ib, as bit slices
-// (%[t] = ib | d << 3: one scalar operand)
-#define RO_INIT "v_bfe_i32 v40, %[t], 0, 1\n\tv_bfe_i32 v41, %[t], 1, 1\n\tv_bfe_i32 v42, %[t], 2, 1\n\tv_mov_b32 v43, 0\n\t"
-// snapshot into v39: positions whose count so far is <= bound -- adding d = (T - 1) - bound (slices v35 .. v37) does not overflow.
-// RO_SNAP1: ... whose count INCLUDING the next base (its match mask is v32: the group's shifts are done, its add is not) is <= bound:
-// the mismatch of that base is the carry into the lowest slice.
-#define RO_DMASK "v_bfe_i32 v35, %[t], 3, 1\n\tv_bfe_i32 v36, %[t], 4, 1\n\tv_bfe_i32 v37, %[t], 5, 1\n\t"
-#define RO_SNAP0 RO_DMASK "v_and_b32 v38, v40, v35\n\t"
-#define RO_SNAP1 RO_DMASK "v_bitop3_b32 v38, v40, v35, v32 bitop3:0xd4\n\t"
-#define RO_SNAP_REST "v_bitop3_b32 v38, v41, v36, v38 bitop3:0xe8\n\tv_bitop3_b32 v38, v42, v37, v38 bitop3:0xe8\n\t" \
-                     "v_bitop3_b32 v39, v38, v43, v43 bitop3:0x01\n\t"
-// a whole run: SH = RO_SH_F / RO_SH_B.  Close end (first evaluated length 8): the snapshot after SEVEN bases = two groups and the
-// first base of the third; far end (first evaluated length 10): after nine = three groups.
-#define RO_TAIL(SH) RO_G4(SH) RO_PROG_LOAD2 RO_AD RO_EXIT(4) "s_waitcnt lgkmcnt(0)\n\t"                                   \
-    RO_G5(SH) RO_AD RO_EXIT(5) RO_G6(SH) RO_AD RO_EXIT(6) RO_G7(SH) RO_AD RO_EXIT(7) RO_G8(SH) RO_AD
-#define RO_RUN_CLOSE(SH) RO_G1(SH) RO_AD RO_G2(SH) RO_AD RO_G3(SH) RO_SNAP1 RO_SNAP_REST RO_AD RO_TAIL(SH)
-#define RO_RUN_FAR(SH) RO_G1(SH) RO_AD RO_G2(SH) RO_AD RO_G3(SH) RO_AD RO_SNAP0 RO_SNAP_REST RO_TAIL(SH)
+// counter start (2^NS - 1) - (T - 1) = ib, as bit slices  (%[t] = ib | d << 4: one scalar operand)
+#define RO_INIT3 "v_bfe_i32 v40, %[t], 0, 1\n\tv_bfe_i32 v41, %[t], 1, 1\n\tv_bfe_i32 v42, %[t], 2, 1\n\tv_mov_b32 v43, 0\n\t"
+#define RO_INIT4 RO_INIT3 "v_bfe_i32 v44, %[t], 3, 1\n\t"
+// snapshot into v39: positions whose count so far is <= bound -- adding d = (T - 1) - bound (slices v35 .. v37 [, v45]) does not
+// overflow.  RO_SNAP1: ... whose count INCLUDING the next base (its match mask is v32: the group's shifts are done, its add is not)
+// is <= bound: the mismatch of that base is the carry into the lowest slice.
+#define RO_DMASK3 "v_bfe_i32 v35, %[t], 4, 1\n\tv_bfe_i32 v36, %[t], 5, 1\n\tv_bfe_i32 v37, %[t], 6, 1\n\t"
+#define RO_DMASK4 RO_DMASK3 "v_bfe_i32 v45, %[t], 7, 1\n\t"
+#define RO_CARRY0 "v_and_b32 v38, v40, v35\n\t"
+#define RO_CARRY1 "v_bitop3_b32 v38, v40, v35, v32 bitop3:0xd4\n\t"
+#define RO_REST3 "v_bitop3_b32 v38, v41, v36, v38 bitop3:0xe8\n\tv_bitop3_b32 v38, v42, v37, v38 bitop3:0xe8\n\t" \
+                 "v_bitop3_b32 v39, v38, v43, v43 bitop3:0x01\n\t"
+#define RO_REST4 "v_bitop3_b32 v38, v41, v36, v38 bitop3:0xe8\n\tv_bitop3_b32 v38, v42, v37, v38 bitop3:0xe8\n\t" \
+                 "v_bitop3_b32 v38, v44, v45, v38 bitop3:0xe8\n\tv_bitop3_b32 v39, v38, v43, v43 bitop3:0x01\n\t"
+// a whole run: SH = RO_SH_F / RO_SH_B, AD = RO_AD3 / RO_AD4, DM / RS = the snapshot's pieces for the counter width.  Close end (first
+// evaluated length 8): the snapshot after SEVEN bases = two groups and the first base of the third; far end (first evaluated length
+// 10): after nine = three groups.
+#define RO_TAIL(SH, AD) RO_G4(SH) RO_PROG_LOAD2 AD RO_EXIT(4) "s_waitcnt lgkmcnt(0)\n\t"                                \
+    RO_G5(SH) AD RO_EXIT(5) RO_G6(SH) AD RO_EXIT(6) RO_G7(SH) AD RO_EXIT(7) RO_G8(SH) AD
+#define RO_RUN_CLOSE(SH, AD, DM, RS) RO_G1(SH) AD RO_G2(SH) AD RO_G3(SH) DM RO_CARRY1 RS AD RO_TAIL(SH, AD)
+#define RO_RUN_FAR(SH, AD, DM, RS) RO_G1(SH) AD RO_G2(SH) AD RO_G3(SH) AD DM RO_CARRY0 RS RO_TAIL(SH, AD)
 // the seed's plane (index = byte 3 of the first program dword) by an indexed v_mov -- SEEDREG: "v0" (kind F: the own word is the
 // low one) or "v5" (kind B: the high one) --, then seed & (snapshot | no overflow)
 // (a run that leaves after four groups still has the second fetch in flight: waited for here)
 #define RO_FINAL(SEEDREG) "9:\n\ts_waitcnt lgkmcnt(0)\n\ts_set_gpr_idx_on s88, 0x1\n\tv_mov_b32 v32, " SEEDREG "\n\ts_set_gpr_idx_off\n\t" \
                           "v_bitop3_b32 %[m], v32, v39, v43 bitop3:0xd0"
+#define RO_CLOBBERS4 "v44", "v45",
 #define RO_CLOBBERS "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43",                   \
                     "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57",                               \
                     "s84", "s85", "s86", "s87", "s88", "m0", "scc", "memory"
 // One kind.  KIND 0: F, 1: B; FAR: the far end's snapshot depth.  o1 = the read's orientation in hand (0: left to right, 1: from
 // its last base) = which program.  word: the lane's window word (scan_impl).
-template <int NB, int KIND, bool FAR>
+template <int NB, int KIND, bool FAR, int NS>
 __device__ __forceinline__ u32 seed_filter_ro1(const Search &S, bool o1, bool wide, int word)
 {
+    static_assert(NS == 3 || NS == 4, "three slices (up to 8 mismatch levels) or four (up to 16)");
     const u32 ro = S.ro;
     const u32 G = (ro >> (wide ? 4 : 0)) & 15u;
     const int bound = (int)((ro >> (wide ? 16 : 8)) & 0xffu);
     const int thrA = bound < S.cap_state ? bound : S.cap_state;          // (see seed_filter: the state's bound once candidates are folded)
-    const u32 t = (u32)(8 - S.T) | ((u32)(S.T - 1 - thrA) << 3);            // counter start 7 - (T - 1) | snapshot distance (T - 1) - bound
+    const u32 t = (u32)((1 << NS) - S.T) | ((u32)(S.T - 1 - thrA) << 4);  // counter start (2^NS - 1) - (T - 1) | snapshot distance (T - 1) - bound
     const u32 off = o1 ? 0x60u : 0x40u;                                   // PgInRec::prog[o1]
     // kind F reads the words (own, next), kind B (previous, own)
     const u32 wa = (u32)(uintptr_t)(const __attribute__((address_space(3))) uint4 *)(S.win + (2 * NB + word - (KIND == 1 ? 1 : 0)));
-#ifdef RO_TEST_RP      // (scripts/test_rofilter.hip: the record's address as the compiler works it out)
-    const PgInRec *rp;
-    {
-        const unsigned long long a = (unsigned long long)(uintptr_t)((const PgInRec *)S.mm_tab + S.rid);
-        rp = (const PgInRec *)(uintptr_t)((unsigned long long)(u32)uni((int)(u32)a) | ((unsigned long long)(u32)uni((int)(u32)(a >> 32)) << 32));
-    }
-#else
 #ifdef PG_RO_RP_RECOMPUTE     // (ablation: the record's address worked out again at every run: a kernarg fetch + wait + four scalar instructions)
     const PgInRec *rp = record_ptr<7>(karg_load<const PgInRec *>((int)offsetof(PgKArgs, B.in)), S.rid);
 #else
     const PgInRec *rp = KaGlobal<const PgInRec *>::of((u64)S.rp_lo | ((u64)S.rp_hi << 32));
 #endif
-#endif
     u32 m;
-#define RO_HEAD RO_PROG_LOAD "ds_read_b128 v[32:35], %[wa]\n\tds_read_b128 v[36:39], %[wa] offset:16\n\t" RO_INIT "s_waitcnt lgkmcnt(0)\n\ts_lshr_b32 s88, s84, 24\n\t"
-#define RO_OPERANDS : [m] "=&v"(m) : [rp] "s"(rp), [off] "s"(off), [wa] "v"(wa), [t] "s"(t), [G] "s"(G) : RO_CLOBBERS
-    if (KIND == 0) {
-        // planes in natural order (A, C, G, T, not-N): low = the own word, high = the next one
-        if (FAR)
-            asm volatile(RO_HEAD RO_ONEHOT("v48", "v49", "v50", "v51", "v52", "v32", "v33", "v34") RO_ONEHOT("v53", "v54", "v55", "v56", "v57", "v36", "v37", "v38")
-                         RO_RUN_FAR(RO_SH_F) RO_FINAL("v0") RO_OPERANDS);
-        else
-            asm volatile(RO_HEAD RO_ONEHOT("v48", "v49", "v50", "v51", "v52", "v32", "v33", "v34") RO_ONEHOT("v53", "v54", "v55", "v56", "v57", "v36", "v37", "v38")
-                         RO_RUN_CLOSE(RO_SH_F) RO_FINAL("v0") RO_OPERANDS);
+#define RO_HEAD(INIT) RO_PROG_LOAD "ds_read_b128 v[32:35], %[wa]\n\tds_read_b128 v[36:39], %[wa] offset:16\n\t" INIT "s_waitcnt lgkmcnt(0)\n\ts_lshr_b32 s88, s84, 24\n\t"
+#define RO_OPERANDS(MORE) : [m] "=&v"(m) : [rp] "s"(rp), [off] "s"(off), [wa] "v"(wa), [t] "s"(t), [G] "s"(G) : MORE RO_CLOBBERS
+// planes in natural order (A, C, G, T, not-N): low = the own word, high = the next one (kind F); in COMPLEMENT order (T, G, C, A,
+// not-N): low = the previous word, high = the own one (kind B)
+#define RO_PLANES_F RO_ONEHOT("v48", "v49", "v50", "v51", "v52", "v32", "v33", "v34") RO_ONEHOT("v53", "v54", "v55", "v56", "v57", "v36", "v37", "v38")
+#define RO_PLANES_B RO_ONEHOT("v51", "v50", "v49", "v48", "v52", "v32", "v33", "v34") RO_ONEHOT("v56", "v55", "v54", "v53", "v57", "v36", "v37", "v38")
+    if (NS == 3) {
+        if (KIND == 0 && FAR) asm volatile(RO_HEAD(RO_INIT3) RO_PLANES_F RO_RUN_FAR(RO_SH_F, RO_AD3, RO_DMASK3, RO_REST3) RO_FINAL("v0") RO_OPERANDS());
+        else if (KIND == 0) asm volatile(RO_HEAD(RO_INIT3) RO_PLANES_F RO_RUN_CLOSE(RO_SH_F, RO_AD3, RO_DMASK3, RO_REST3) RO_FINAL("v0") RO_OPERANDS());
+        else if (FAR) asm volatile(RO_HEAD(RO_INIT3) RO_PLANES_B RO_RUN_FAR(RO_SH_B, RO_AD3, RO_DMASK3, RO_REST3) RO_FINAL("v5") RO_OPERANDS());
+        else asm volatile(RO_HEAD(RO_INIT3) RO_PLANES_B RO_RUN_CLOSE(RO_SH_B, RO_AD3, RO_DMASK3, RO_REST3) RO_FINAL("v5") RO_OPERANDS());
     } else {
-        // planes in COMPLEMENT order (T, G, C, A, not-N): low = the previous word, high = the own one
-        if (FAR)
-            asm volatile(RO_HEAD RO_ONEHOT("v51", "v50", "v49", "v48", "v52", "v32", "v33", "v34") RO_ONEHOT("v56", "v55", "v54", "v53", "v57", "v36", "v37", "v38")
-                         RO_RUN_FAR(RO_SH_B) RO_FINAL("v5") RO_OPERANDS);
-        else
-            asm volatile(RO_HEAD RO_ONEHOT("v51", "v50", "v49", "v48", "v52", "v32", "v33", "v34") RO_ONEHOT("v56", "v55", "v54", "v53", "v57", "v36", "v37", "v38")
-                         RO_RUN_CLOSE(RO_SH_B) RO_FINAL("v5") RO_OPERANDS);
+        if (KIND == 0 && FAR) asm volatile(RO_HEAD(RO_INIT4) RO_PLANES_F RO_RUN_FAR(RO_SH_F, RO_AD4, RO_DMASK4, RO_REST4) RO_FINAL("v0") RO_OPERANDS(RO_CLOBBERS4));
+        else if (KIND == 0) asm volatile(RO_HEAD(RO_INIT4) RO_PLANES_F RO_RUN_CLOSE(RO_SH_F, RO_AD4, RO_DMASK4, RO_REST4) RO_FINAL("v0") RO_OPERANDS(RO_CLOBBERS4));
+        else if (FAR) asm volatile(RO_HEAD(RO_INIT4) RO_PLANES_B RO_RUN_FAR(RO_SH_B, RO_AD4, RO_DMASK4, RO_REST4) RO_FINAL("v5") RO_OPERANDS(RO_CLOBBERS4));
+        else asm volatile(RO_HEAD(RO_INIT4) RO_PLANES_B RO_RUN_CLOSE(RO_SH_B, RO_AD4, RO_DMASK4, RO_REST4) RO_FINAL("v5") RO_OPERANDS(RO_CLOBBERS4));
     }
     return m;
 }
 // KIND 0: kind F alone (close end of a '+' anchor), 1: kind B alone ('-' anchor), 2: both (far end: two runs -- one pass with both
 // kinds' planes and counters resident is 40 fixed registers, and the compiler spilled 30 of its own around it)
-template <int NB, int KIND>
+template <int NB, int KIND, int NS = 3>
 __device__ __forceinline__ void seed_filter_ro(const Search &S, bool o1, bool wide, int word, u32 &mF, u32 &mB)
 {
     if (KIND == 2) {
-        mF = seed_filter_ro1<NB, 0, true>(S, o1, wide, word);
-        mB = seed_filter_ro1<NB, 1, true>(S, o1, wide, word);
+        mF = seed_filter_ro1<NB, 0, true, NS>(S, o1, wide, word);
+        mB = seed_filter_ro1<NB, 1, true, NS>(S, o1, wide, word);
     } else
-        mF = seed_filter_ro1<NB, KIND, false>(S, o1, wide, word);
+        mF = seed_filter_ro1<NB, KIND, false, NS>(S, o1, wide, word);
 }
 #endif
 
@@ -1339,7 +1337,8 @@ __device__ __forceinline__ void seed_filter(const Search &S, const Query<NB> &Q,
     // depth: same bases in the final count, a shorter prefix in the snapshot).  Counters behind the launch's read counters
     // (pg_debug_read_phase_cycles): [0] runs, [1 + kind] runs with a seed lost, [4] lanes with a seed lost.
     // PG_RO_CHECK = 1: the search goes on with the OLD masks, 2: with the new ones.
-    if (NS == 3 && (S.ro & PG_RO_OK) && !wide) {
+    if (NS <= 4 && (S.ro & PG_RO_OK) && !wide) {
+        constexpr int RNS = NS <= 3 ? 3 : 4;
         u32 nF = 0u, nB = 0u, oF = 0u, oB = 0u;
         {   // the program as the run will fetch it: every byte 0x30 | symbol <= 4 ?  ([5] counts the runs with another)
             const PgInRec *rp = record_ptr<7>(karg_load<const PgInRec *>((int)offsetof(PgKArgs, B.in)), S.rid);
@@ -1366,9 +1365,9 @@ __device__ __forceinline__ void seed_filter(const Search &S, const Query<NB> &Q,
             return;
         }
 #endif
-        if (DUAL) seed_filter_ro<NB, 2>(S, Q.o1_, wide, lane, nF, nB);
-        else if (kindB) seed_filter_ro<NB, 1>(S, Q.o1_, wide, lane, nF, nB);
-        else seed_filter_ro<NB, 0>(S, Q.o1_, wide, lane, nF, nB);
+        if (DUAL) seed_filter_ro<NB, 2, RNS>(S, Q.o1_, wide, lane, nF, nB);
+        else if (kindB) seed_filter_ro<NB, 1, RNS>(S, Q.o1_, wide, lane, nF, nB);
+        else seed_filter_ro<NB, 0, RNS>(S, Q.o1_, wide, lane, nF, nB);
         {
             const u32 jm = S.jmask[0], g0 = jm & low32(S.bps);
             int c0 = (int)((S.depth >> 16) & 0xffu);
@@ -1386,10 +1385,11 @@ __device__ __forceinline__ void seed_filter(const Search &S, const Query<NB> &Q,
         return;
     }
 #endif
-    if (NS == 3 && (S.ro & PG_RO_OK) && ((PG_RO_KINDS >> (DUAL ? 2 : (kindB ? 1 : 0))) & 1)) {
-        if (DUAL) seed_filter_ro<NB, 2>(S, Q.o1_, wide, lane, mF, mB);
-        else if (kindB) seed_filter_ro<NB, 1>(S, Q.o1_, wide, lane, mF, mB);       // (kindB is a constant at every call site)
-        else seed_filter_ro<NB, 0>(S, Q.o1_, wide, lane, mF, mB);
+    if (NS <= 4 && (S.ro & PG_RO_OK) && ((PG_RO_KINDS >> (DUAL ? 2 : (kindB ? 1 : 0))) & 1)) {
+        constexpr int RNS = NS <= 3 ? 3 : 4;          // (the counter of the launch: three slices up to 8 mismatch levels, four up to 16)
+        if (DUAL) seed_filter_ro<NB, 2, RNS>(S, Q.o1_, wide, lane, mF, mB);
+        else if (kindB) seed_filter_ro<NB, 1, RNS>(S, Q.o1_, wide, lane, mF, mB);       // (kindB is a constant at every call site)
+        else seed_filter_ro<NB, 0, RNS>(S, Q.o1_, wide, lane, mF, mB);
         return;
     }
 #endif
@@ -2835,7 +2835,7 @@ __global__ __launch_bounds__(256) void pg_pack_kernel(PgSoaIn a, PgInRec *in, ui
                 const int G0 = pg_ro_groups((int)len, (int)T, 0), G1 = pg_ro_groups((int)len, (int)T, 1);
                 const u32 rb0 = min(T - 1u, (a.mm[3 * G0 + 1] & 0xffu) + (u32)a.add_mm), rb1 = min(T - 1u, (a.mm[3 * G1 + 1] & 0xffu) + (u32)a.add_mm);
                 q2.z = (u32)G0 | ((u32)G1 << 4) | (rb0 << 8) | (rb1 << 16);
-                if (T <= 8u && G0 >= PG_RO_GROUPS_MIN && G1 >= PG_RO_GROUPS_MIN && a.min_close >= 8) q2.z |= PG_RO_OK;    // (the close end's snapshot covers seven bases)
+                if (T <= 16u && G0 >= PG_RO_GROUPS_MIN && G1 >= PG_RO_GROUPS_MIN && a.min_close >= 8) q2.z |= PG_RO_OK;    // (the close end's snapshot covers seven bases)
             }
             q2.w = (u32)chr;
             q3.x = a.chr_size[chr];

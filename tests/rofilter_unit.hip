@@ -55,14 +55,20 @@ __global__ __launch_bounds__(64, 7) void k_test(PgDevRef ref, PgDevParams prm, P
         S.cap_state = (c % 3 == 2) ? (int)(c % 4) : 255;
         const int T = S.T;
         for (int kind = 0; kind < 3; kind++) {
-            if (!((levels >> kind) & 1u)) continue;
+            if (!((levels >> kind) & 1u)) continue;        // (levels: kinds to run | counter slices << 8)
             for (int o1 = 0; o1 < 2; o1++) {
                 for (int wide = 0; wide < 2; wide++) {
                     u32 mF = 0u, mB = 0u;
 #if RO_TEST_VARIANT != 4
-                    if (kind == 0) seed_filter_ro<2, 0>(S, o1 != 0, wide != 0, lane, mF, mB);
-                    else if (kind == 1) seed_filter_ro<2, 1>(S, o1 != 0, wide != 0, lane, mF, mB);
-                    else seed_filter_ro<2, 2>(S, o1 != 0, wide != 0, lane, mF, mB);
+                    if ((levels >> 8) == 4u) {             // four counter slices: up to 16 mismatch levels
+                        if (kind == 0) seed_filter_ro<2, 0, 4>(S, o1 != 0, wide != 0, lane, mF, mB);
+                        else if (kind == 1) seed_filter_ro<2, 1, 4>(S, o1 != 0, wide != 0, lane, mF, mB);
+                        else seed_filter_ro<2, 2, 4>(S, o1 != 0, wide != 0, lane, mF, mB);
+                    } else {
+                        if (kind == 0) seed_filter_ro<2, 0, 3>(S, o1 != 0, wide != 0, lane, mF, mB);
+                        else if (kind == 1) seed_filter_ro<2, 1, 3>(S, o1 != 0, wide != 0, lane, mF, mB);
+                        else seed_filter_ro<2, 2, 3>(S, o1 != 0, wide != 0, lane, mF, mB);
+                    }
 #endif
                     // brute force
                     const u32 G = (S.ro >> (wide ? 4 : 0)) & 15u;
@@ -122,10 +128,8 @@ __global__ __launch_bounds__(64, 7) void k_test(PgDevRef ref, PgDevParams prm, P
 static uint32_t rnd_state = 12345u;
 static uint32_t rnd() { rnd_state = rnd_state * 1664525u + 1013904223u; return rnd_state >> 8; }
 
-int main(int argc, char **argv)
+static void run(const unsigned kinds, const int slices)
 {
-    const unsigned kinds = argc > 1 ? (unsigned)atoi(argv[1]) : 7u;
-    setvbuf(stdout, nullptr, _IONBF, 0);
     const int n_cases = 64;
     std::vector<PgInRec> recs(n_cases);
     std::vector<uint32_t> win((size_t)n_cases * 80 * 3);
@@ -143,7 +147,7 @@ int main(int argc, char **argv)
         }
         PgInRec &r = recs[c];
         memset(&r, 0, sizeof r);
-        const uint32_t T = 3 + rnd() % 6;              // 3 .. 8
+        const uint32_t T = 3 + rnd() % (slices == 4 ? 14 : 6);      // 3 .. 8 (three counter slices) / 3 .. 16 (four)
         const uint32_t G0 = 4 + rnd() % 3, G1 = G0 + rnd() % 2;
         const uint32_t b0 = rnd() % T, b1 = rnd() % T;
         r.lvl = T << 24;
@@ -173,19 +177,17 @@ int main(int argc, char **argv)
     hipMalloc(&d_rec2, recs.size() * sizeof(PgInRec));
     hipMemcpy(d_rec2, recs.data(), recs.size() * sizeof(PgInRec), hipMemcpyHostToDevice);
     B.planes = (const uint64_t *)d_rec2;
-    printf("d_rec2 %p\n", (void *)d_rec2);
     B.in = d_rec; B.seq = (const uint8_t *)d_win; B.out = (PgOutRec *)d_out;
     uint32_t *d_cnt;
     hipMalloc(&d_cnt, 16);
     B.pool_used = d_cnt;
-    printf("d_rec %p d_win %p d_out %p d_cnt %p\n", (void *)d_rec, (void *)d_win, (void *)d_out, (void *)d_cnt);
     for (int grid : { 1, 256, 256 * 4 * 7 }) {
         hipMemset(d_cnt, 0, 16);
-        hipLaunchKernelGGL(k_test, dim3(grid), dim3(64), 0, 0, ref, prm, B, (uint32_t)n_cases, kinds);
+        hipLaunchKernelGGL(k_test, dim3(grid), dim3(64), 0, 0, ref, prm, B, (uint32_t)n_cases, kinds | ((unsigned)slices << 8));
         hipError_t e = hipDeviceSynchronize();
         uint32_t cnt[4];
         hipMemcpy(cnt, d_cnt, 16, hipMemcpyDeviceToHost);
-        printf("grid %5d: %s; lanes that differ from the brute force: F %u B %u DUAL %u\n", grid, hipGetErrorString(e), cnt[0], cnt[1], cnt[2]);
+        printf("slices %d grid %5d: %s; lanes that differ from the brute force: F %u B %u DUAL %u\n", slices, grid, hipGetErrorString(e), cnt[0], cnt[1], cnt[2]);
     }
     std::vector<uint32_t> out(n_out);
     hipMemcpy(out.data(), d_out, n_out * 4, hipMemcpyDeviceToHost);
@@ -204,7 +206,16 @@ int main(int argc, char **argv)
                             if (shown++ < 4) printf("  %s case %d o1 %d wide %d lane %d: got %08x %08x want %08x %08x\n", kn[kind], c, o1, wide, lane, out[o], out[o + 1], out[o + 2], out[o + 3]);
                         }
                     }
-        printf("kind %-4s: %zu lane results differ of %zu (survivors in the expectation: %zu)\n", kn[kind], bad, tot / 2, surv);
+        printf("slices %d kind %-4s: %zu lane results differ of %zu (survivors in the expectation: %zu)\n", slices, kn[kind], bad, tot / 2, surv);
     }
+    hipFree(d_rec); hipFree(d_rec2); hipFree(d_win); hipFree(d_out); hipFree(d_cnt);
+}
+
+int main(int argc, char **argv)
+{
+    const unsigned kinds = argc > 1 ? (unsigned)atoi(argv[1]) : 7u;
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    run(kinds, 3);      // three counter slices: up to 8 mismatch levels
+    run(kinds, 4);      // four: up to 16
     return 0;
 }
