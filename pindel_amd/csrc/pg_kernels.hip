@@ -1183,12 +1183,13 @@ __device__ __forceinline__ void seed_filter_run(const Search &S, const Query<NB>
 //     can matter (relevant at some L in [bps, 3 G + 1] => count(bps - 1 bases) <= g_maxMismatch[3 G + 1] + ADD,
 //     and a count over FEWER bases is smaller still; relevant later => alive after 3 G + 1 bases), it only moves the survivor count.
 // ONLY v_alignbit and v_mov run in index mode: an indexed v_bitop3 (the seed's plane straight into the final combine) gave correct
-// masks in every single-wave test and memory faults with seven waves per SIMD -- scripts/test_rofilter.hip, variants 18 / 19: the
-// fault follows the index of that one instruction, not the program fetch, not M0[11:8], not the register numbers.
-// Everything lives in fixed registers (v32 .. v43, v48 .. v57, s84 .. s88: with VCC, FLAT_SCRATCH and XNACK_MASK a gfx9 wave addresses s0 .. s95 --
-// a scalar register above that is the NEXT wave's: the first version used s88 .. s96 and passed every single-wave test): the index needs consecutive planes at known numbers (v48 + symbol:
-// the 0x30 bias), and nothing inside is spilled, copied or padded by the compiler.  Reads with more than eight mismatch levels, fewer
-// than four groups, a base outside ACGTN among the first 25 of either orientation, or g_MinClose < 8 keep the filter above.
+// masks in every single-wave test and memory faults with seven waves per SIMD -- delta-debugged with variants of tests/rofilter_unit.hip:
+// the fault follows the index of that one instruction, not the program fetch, not M0[11:8], not the register numbers.
+// Everything lives in fixed registers (v32 .. v43 [+ v44, v45 with four slices], v48 .. v57, s84 .. s88): the index needs consecutive
+// planes at known numbers (v48 + symbol: the 0x30 bias), and nothing inside is spilled, copied or padded by the compiler.  s88 is the
+// highest scalar register on purpose: with VCC, FLAT_SCRATCH and XNACK_MASK that is 95 of the 96 scalar registers a wave may own at
+// seven waves per SIMD.  Reads with more than 16 mismatch levels (NS = 5 launches), fewer than four groups, a base outside ACGTN among
+// the first 25 of either orientation, or g_MinClose < 8 keep the filter above.
 #ifndef PG_NO_RO_FILTER
 #define PG_RO 1
 // planes of the window word in (x, y, z) = (code bit 0, code bit 1, N): A, C, G, T, not-N into the five registers given
