@@ -159,7 +159,9 @@ def pack_roofline(batch, pack_ms):
     nbytes = float(lens.sum()) + batch.n * (8 + 11 + 64 * blocks + 128)    # offsets + SoA fields in; bit planes + the 128-byte record out
     achieved = nbytes / (pack_ms * 1e-3) / 1e9 if pack_ms > 0 else 0.0
     return {"bound": "hbm", "kernel": "pg_pack_kernel", "kernel_ms": pack_ms, "achieved": achieved, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes, "traffic": None}
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes, "traffic": None,
+            "note": "as a launch of its own, measured outside the timed region; inside the step of a batch of a million reads "
+                    "and more the same code runs in pg_search_kernel, claim by claim"}
 
 
 def self_spawn(args):
@@ -299,6 +301,9 @@ def main():
     ap.add_argument("--seed", type=int, default=20260927)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive pg_search_batch sample")
+    ap.add_argument("--no-standalone", action="store_true",
+                    help="skip the launches that time the pack and the search as kernels of their own after the timed region "
+                         "(config.pack_ms_standalone / search_ms_standalone / value_search_only): a traced run then holds the steps' launches only")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--genome-scale", type=float, default=1.0, help="grch38-150: scale every chromosome (tests)")
     ap.add_argument("--workload", choices=["sv10m", "colo-bd", "grch38-150", "repeat-rich", "wgs-bins", "wgs-real"], default="sv10m",
@@ -360,22 +365,18 @@ def main():
     t_setup.append(time.perf_counter())
 
     # One step = what the device does for one batch whose raw inputs (ASCII bases, offsets, anchor fields) are resident in HBM:
-    # the PACK stage (pg_pack_kernel: bit planes + packed records, the form the search kernel reads -- part of every call of the
-    # ABI, so part of `value` since round 6) and the SEARCH (pg_search_kernel).  Both synchronous; HIP-event times of each.
-    pack_ms_steps = []
-
+    # the PACK (bit planes + packed records, the form the search reads -- part of every call of the ABI, so part of `value`
+    # since round 6) and the SEARCH, through pg_device_batch_pack_search: ONE launch for batches of a million reads and more
+    # (pg_search_kernel packs the reads of each claim itself just before it searches them), pg_pack_kernel + pg_search_kernel
+    # for smaller ones.  Synchronous; the HIP-event time covers everything the step put on the device.
     def one_step():
         if bins is None:
-            pk = eng.repack(dbatch)
-            eng.search_device(dbatch)    # synchronous: returns when the kernel finished
-            pack_ms_steps.append(pk)
+            eng.pack_search_device(dbatch)    # synchronous: returns when the kernel finished
             return eng.last_stats()[0]
-        ms = pk = 0.0
-        for h in bins:                   # one launch per 5-Mbp bin
-            pk += eng.repack(h)
-            eng.search_device(h)
+        ms = 0.0
+        for h in bins:                   # one step per 5-Mbp bin
+            eng.pack_search_device(h)
             ms += eng.last_stats()[0]
-        pack_ms_steps.append(pk)
         return ms
 
     def barrier():
@@ -386,7 +387,6 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    pack_ms_steps.clear()
     barrier()
     t0 = time.perf_counter()
     kernel_ms = []
@@ -400,13 +400,22 @@ def main():
         elapsed = float(t.item())
 
     # ---- outside the timed region: accounting, result digests, the host-buffer seam, the CPU baseline
-    # The pack stage (pg_pack_kernel: ASCII bases as src/reader.cpp:852-856 hands them over -> the bit planes + packed
-    # records the search kernel reads) is timed inside every step (HIP events on the ctx's stream: config.pack_ms_per_step,
-    # roofline.pack).  Bytes per read: len + 8 (offset) + 11 (strand, position, insert size, chromosome) in, 64 x blocks
-    # (planes) + 128 (record + symbol programs) out.
-    pack_ms = sum(pack_ms_steps) / max(len(pack_ms_steps), 1)      # inside the timed steps (HIP events around pg_pack_kernel)
-    if bins is not None:
-        eng.search_device(dbatch)                 # the whole batch once, for the accounting below (same reads)
+    # The pack (ASCII bases as src/reader.cpp:852-856 hands them over -> the bit planes + packed records the search reads) is
+    # part of every timed step.  Bytes per read: len + 8 (offset) + 11 (strand, position, insert size, chromosome) in, 64 x
+    # blocks (planes) + 128 (record + symbol programs) out (roofline.pack).
+    # The two stages on their own, OUTSIDE the timed region (three launches each, HIP events): pg_pack_kernel as a launch of its
+    # own and pg_search_kernel on records already packed -- the latter is what rounds 1-5 reported as `value`
+    # (config.value_search_only), kept for comparison.
+    pack_ms = search_only_ms = None
+    if not args.no_standalone:
+        pack_ms = min(eng.repack(dbatch) for _ in range(3))
+        search_only_ms = []
+        for _ in range(3):
+            eng.search_device(dbatch)
+            search_only_ms.append(eng.last_stats()[0])
+        search_only_ms = min(search_only_ms)
+    if bins is not None or not args.no_standalone:
+        eng.pack_search_device(dbatch)            # the step once more on the whole batch, for the accounting below
     alg_bytes = eng.algorithmic_bytes(dbatch)     # per launch
     n_cand = eng.candidates(dbatch)
     res = eng.download(dbatch)
@@ -467,12 +476,16 @@ def main():
                 "result_sha256": shard.digest_hex(digests),
                 "host_path_reads_per_s": host_path,
                 # `value` covers pack + search; the search alone (rounds 1-5's `value`: inputs already packed) for comparison
-                "step": "pg_pack_kernel + pg_search_kernel on raw inputs resident in HBM",
+                "step": ("pack + search on raw inputs resident in HBM (pg_device_batch_pack_search): " +
+                         ("ONE launch, pg_search_kernel packs the reads of each claim before it searches them"
+                          if batch.n >= 1_000_000 and bins is None else "pg_pack_kernel + pg_search_kernel for launches under a million reads")),
                 "setup_seconds": {"synthetic_inputs": t_setup[1] - t_setup[0], "reference_to_hbm": t_setup[2] - t_setup[1],
                                   "reads_to_hbm": t_setup[3] - t_setup[2]},
-                "pack_ms_per_step": pack_ms,
-                "search_ms_per_step": avg_ms,
-                "value_search_only": units * args.steps / max(elapsed - args.steps * pack_ms * 1e-3, 1e-9),
+                "device_ms_per_step": avg_ms,
+                # outside the timed region, three launches each: the stages as launches of their own
+                "pack_ms_standalone": pack_ms,
+                "search_ms_standalone": search_only_ms,
+                "value_search_only": batch.n * world / (search_only_ms * 1e-3) if search_only_ms else None,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -482,11 +495,13 @@ def main():
                 "hbm_achieved_gbs": traffic / (avg_ms * 1e-3) / 1e9 if traffic and avg_ms > 0 else None,
                 "hbm_achieved_frac": traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic and avg_ms > 0 else None,
                 "traffic_over_algorithmic": traffic / alg_bytes if traffic and alg_bytes else None,
+                # (the step's launch: with the pack inside for batches of a million reads and more; `achieved` counts the SEARCH's
+                # algorithmic bytes only -- the planes and records the pack writes are intermediates, see roofline.pack)
                 "kernel": "pg_search_kernel", "kernel_ms": avg_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "actual_bound": "instruction issue (VALU + scalar), see DESIGN.md section 4",
                 "issue": issue_model(args, avg_ms, batch.n),
-                "pack": pack_roofline(batch, pack_ms),
+                "pack": pack_roofline(batch, pack_ms) if pack_ms else None,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -68,7 +68,7 @@ EXPORTS = [
     "pg_search_batch", "pg_search_batch_multi", "pg_result_view_get", "pg_result_free", "pg_expand_runs",
     "pg_device_batch_upload", "pg_device_batch_set_windows", "pg_device_batch_search", "pg_device_batch_download",
     "pg_device_batch_free", "pg_last_search_stats", "pg_device_batch_algorithmic_bytes",
-    "pg_device_batch_candidates", "pg_device_batch_repack"]
+    "pg_device_batch_candidates", "pg_device_batch_repack", "pg_device_batch_pack_search"]
 
 
 def build(force: bool = False) -> str:
@@ -150,6 +150,7 @@ def lib():
     L.pg_device_batch_algorithmic_bytes.argtypes = [vp, vp, C.POINTER(C.c_double)]
     L.pg_device_batch_candidates.argtypes = [vp, vp, C.POINTER(C.c_double)]
     L.pg_device_batch_repack.argtypes = [vp, vp, C.POINTER(C.c_double)]
+    L.pg_device_batch_pack_search.argtypes = [vp, vp]
     _lib = L
     return L
 
@@ -365,6 +366,20 @@ class Engine:
 
     def search_device(self, dbatch):
         self._check(self._L.pg_device_batch_search(self._h, dbatch))
+
+    def pack_search_device(self, dbatch):
+        """repack + search_device as one step (large batches: one launch, the search kernel packs its own reads)"""
+        self._check(self._L.pg_device_batch_pack_search(self._h, dbatch))
+
+    def last_step_in_place(self) -> bool:
+        """tests: did the last pack_search_device build its records inside the search kernel (one launch)?"""
+        self._L.pg_debug_last_pack_in_place.argtypes = [C.c_void_p]
+        return bool(self._L.pg_debug_last_pack_in_place(self._h))
+
+    def scribble_records(self, dbatch):
+        """tests: overwrite the packed records and planes of the batch"""
+        self._L.pg_debug_scribble_records.argtypes = [C.c_void_p, C.c_void_p]
+        self._check(self._L.pg_debug_scribble_records(self._h, dbatch))
 
     def repack(self, dbatch) -> float:
         """The pack stage (ASCII bases -> bit planes + packed records) again on the resident batch; HIP-event ms."""

@@ -50,6 +50,9 @@ void load_env()
     e.split_launch = getenv("PG_SPLIT_LAUNCH") != nullptr;
     e.generic_kernels = getenv("PG_GENERIC_KERNELS") != nullptr;
     e.lds_pad = getenv("PG_LDS_PAD") ? (uint32_t)atoi(getenv("PG_LDS_PAD")) : 0u;
+    e.no_pack_in_place = getenv("PG_NO_PACK_IN_PLACE") != nullptr;
+    e.pack_claim = getenv("PG_PACK_CLAIM") ? (uint32_t)std::max(1, atoi(getenv("PG_PACK_CLAIM"))) : 0u;
+    e.pack_in_place_min = getenv("PG_PACK_IN_PLACE_MIN") ? (uint32_t)std::max(1, atoi(getenv("PG_PACK_IN_PLACE_MIN"))) : PG_PACK_IN_PLACE_MIN;
     g_env = e;
 }
 const PgEnvSwitches &env()
@@ -223,6 +226,7 @@ struct pg_ctx {
     bool counted = false;              // in g_live_ctx (the pinned-memory cache is trimmed with the last context)
     uint32_t ref_epoch = 0;            // counts reference (re)loads: a device batch's records hold chromosome offsets and sizes
     bool kargs_checked = false;        // the kernels' view of the kernarg segment was checked on this device (pg_debug_kargs_check)
+    bool last_in_place = false;        // the last launch asked to pack did so inside the search kernel (pg_debug_last_pack_in_place)
 };
 
 struct pg_device_batch {
@@ -260,6 +264,9 @@ struct pg_device_batch {
     // reads with a character outside ACGTN, listed by the pack kernel for the exact kernel (pg_search_exact_kernel)
     uint32_t *exact_list = nullptr;    // [n]
     uint32_t *exact_count = nullptr;   // device counter (zeroed with the outputs / before a pack of the whole batch)
+    PgSoaIn *d_soa = nullptr;          // the pack's view of the inputs, in device memory, for launches that pack in place (PgDevBatch::soa)
+    PgSoaIn h_soa;                     // ... and what was copied there last (the source of an asynchronous copy)
+    bool soa_uploaded = false;
     long long exact_n = -1;            // host copy of the counter; -1: not read back (the exact kernel is launched regardless)
 };
 
@@ -421,7 +428,7 @@ void free_batch_buffers(pg_device_batch *b)
     void *ptrs[] = { b->planes, b->seq, b->seq_off, b->strand, b->pos, b->isz, b->chr, b->rc_flag,
                      b->close_last, b->close_max, b->bd_off, b->bd, b->close_off, b->close_cnt,
                      b->far_off, b->far_cnt, b->alg, b->pool, b->pool_used, b->in_rec, b->out_rec, b->run_tot,
-                     b->exact_list, b->exact_count };
+                     b->exact_list, b->exact_count, b->d_soa };
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -643,6 +650,7 @@ static size_t deliver_cap(size_t n) { return env().tiny_delivery ? n / 2 + 8 : 2
 // Validates the batch and allocates its device buffers.  copy = true also copies the inputs
 // (synchronously); otherwise the caller streams them in (search_host).  off = read offsets rebased to 0.
 // use_arena: carve the buffers out of the ctx arena (host-path calls: the batch dies with the call).
+PgSoaIn soa_in(const pg_ctx *ctx, const pg_device_batch *b);
 int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, HostBuf<uint64_t> &off, pg_device_batch **out,
                 bool use_arena = false)
 {
@@ -680,6 +688,7 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, HostBuf<uint
         { (void **)&b->in_rec, (n1 + PG_IN_PAD) * sizeof(PgInRec) },
         { (void **)&b->planes, n1 * 64 * pg_plane_blocks(max_len) },
         { (void **)&b->exact_list, n1 * 4 },
+        { (void **)&b->d_soa, sizeof(PgSoaIn) },
         { (void **)&b->pool, (size_t)b->pool_shard_cap * PG_POOL_SHARDS * sizeof(pg_run) },
         // ---- zero-initialised from here
         { (void **)&b->rc_flag, n1 }, { (void **)&b->close_last, n1 * 4 }, { (void **)&b->close_max, n1 * 2 },
@@ -692,7 +701,7 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, HostBuf<uint
         { (void **)&b->run_tot, 64 },
         { (void **)&b->exact_count, 64 },
     };
-    const size_t n_items = sizeof items / sizeof items[0], first_zero = 10;
+    const size_t n_items = sizeof items / sizeof items[0], first_zero = 11;
     auto drop = [&](int code) {
         free_batch_buffers(b);
         delete b;
@@ -747,6 +756,14 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, HostBuf<uint
         if (e == hipSuccess) e = hipMemcpy(b->chr, reads->chr_id, n * sizeof(int32_t), hipMemcpyHostToDevice);
         if (e != hipSuccess) return drop(fail(ctx, PG_E_DEVICE, std::string("input upload: ") + hipGetErrorString(e)));
     }
+    // the pack's view of the inputs for launches that pack in place (launch_range replaces it when the windows or the parameters
+    // change); on the ctx stream, which every launch of the batch is ordered behind
+    b->h_soa = soa_in(ctx, b);
+    {
+        hipError_t e = hipMemcpyAsync(b->d_soa, &b->h_soa, sizeof b->h_soa, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) return drop(fail(ctx, PG_E_DEVICE, std::string("input upload: ") + hipGetErrorString(e)));
+    }
+    b->soa_uploaded = true;
     *out = b;
     return PG_OK;
 }
@@ -754,6 +771,7 @@ int alloc_batch(pg_ctx *ctx, const pg_read_batch *reads, bool copy, HostBuf<uint
 PgSoaIn soa_in(const pg_ctx *ctx, const pg_device_batch *b)
 {
     PgSoaIn a;
+    std::memset(&a, 0, sizeof a);      // (compared bytewise by launch_range)
     a.seq = b->seq;
     a.planes = b->planes;
     a.plane_blocks = pg_plane_blocks(b->max_len);
@@ -871,6 +889,7 @@ PgDevBatch dev_batch(const pg_device_batch *b)
     d.exact_list = b->exact_list;
     d.exact_count = b->exact_count;
     d.thr_tab = nullptr;               // (launch_range: the ctx's table)
+    d.soa = nullptr;                   // (launch_range: a launch that packs in place)
     return d;
 }
 
@@ -885,8 +904,10 @@ bool small_ids(const pg_ctx *ctx, const pg_device_batch *b)
 // Launches the search for reads [lo, lo + cnt) of the batch on the ctx stream.
 // st / set: the stream to launch on and the set of read counters to use (launches that may overlap need their own)
 // fresh: the set's counters are still zero from the batch's allocation (the first launch on each set)
+// pack: the records of the range are (re)built from the batch's SoA inputs first -- by the search kernel itself where that is
+// possible (pg_pack_in_place_ok: PgDevBatch::soa), by a pack launch in front of it otherwise
 int launch_range(pg_ctx *ctx, pg_device_batch *b, int mode, uint32_t lo, uint32_t cnt, hipStream_t st = nullptr, int set = 0,
-                 bool fresh = false)
+                 bool fresh = false, bool pack = false)
 {
     PgDevRef ref = dev_ref(ctx);
     PgDevParams prm = dev_params(ctx);
@@ -909,6 +930,26 @@ int launch_range(pg_ctx *ctx, pg_device_batch *b, int mode, uint32_t lo, uint32_
     }
     if (!fresh) HIP_TRY(ctx, hipMemsetAsync(d.work_ctr, 0, bytes, st));
     d.thr_tab = ctx->d_thr;
+    if (pack && cnt) {
+        if (pg_pack_in_place_ok(mode, b->max_len, small_ids(ctx, b) ? 1 : 0, cnt, d.plane_blocks)) {
+            const PgSoaIn a = soa_in(ctx, b);
+            if (std::memcmp(&a, &b->h_soa, sizeof a) != 0 || !b->soa_uploaded) {     // (the parameters or the windows changed)
+                // (launches that overlap on the two kernel streams read the same copy: wait for them before it is replaced)
+                if (b->soa_uploaded) HIP_TRY(ctx, hipDeviceSynchronize());
+                b->h_soa = a;
+                // (blocking: the chunks of the host path alternate between two kernel streams, and every one of them reads this copy)
+                HIP_TRY(ctx, hipMemcpy(b->d_soa, &b->h_soa, sizeof a, hipMemcpyHostToDevice));
+                b->soa_uploaded = true;
+            }
+            if (lo == 0 && cnt == b->n) {                 // the whole batch (again): the exact kernel's list starts empty
+                HIP_TRY(ctx, hipMemsetAsync(b->exact_count, 0, sizeof(uint32_t), st));
+                b->exact_n = -1;
+            }
+            d.soa = b->d_soa;
+        } else if (int rc = pack_reads(ctx, b, lo, cnt, st))
+            return rc;
+        ctx->last_in_place = d.soa != nullptr;
+    }
     int lrc = pg_launch_search(&ref, &prm, &d, mode, b->max_len, b->levels, small_ids(ctx, b) ? 1 : 0, st);
     if (lrc != 0) return fail(ctx, PG_E_DEVICE, std::string("kernel launch: ") + hipGetErrorString((hipError_t)lrc));
     // ... then, behind it on the same stream, the reads of this range that hold a character outside ACGTN, with the reference's
@@ -937,7 +978,7 @@ int read_cursors(pg_ctx *ctx, pg_device_batch *b, uint32_t *worst, uint64_t *tot
 
 // Runs the kernel(s) of `mode`; if a pool shard overflowed, the pool is regrown and the launch
 // repeated (still entirely on the GPU).
-int run_search(pg_ctx *ctx, pg_device_batch *b, int mode)
+int run_search(pg_ctx *ctx, pg_device_batch *b, int mode, bool pack = false)
 {
     if (ctx->names.empty()) return fail(ctx, PG_E_NO_REFERENCE, "no reference loaded");
     // (a batch is validated and its records are packed against the reference loaded at upload time: chromosome offsets and sizes,
@@ -946,7 +987,7 @@ int run_search(pg_ctx *ctx, pg_device_batch *b, int mode)
     for (int attempt = 0; attempt < 8; attempt++) {
         HIP_TRY(ctx, hipMemsetAsync(b->pool_used, 0, PG_POOL_SHARDS * 16 * sizeof(uint32_t), ctx->stream));
         HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-        int rc = launch_range(ctx, b, mode, 0, b->n);
+        int rc = launch_range(ctx, b, mode, 0, b->n, nullptr, 0, false, pack);
         if (rc) return rc;
         HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1454,6 +1495,16 @@ int pg_device_batch_search(pg_ctx *ctx, pg_device_batch *b)
     return run_search(ctx, b, PG_MODE_BOTH);
 }
 
+int pg_device_batch_pack_search(pg_ctx *ctx, pg_device_batch *b)
+{
+    use_device(ctx);
+    if (!ctx || !b) return PG_E_INVALID;
+    b->modes_done = 0;
+    int rc = run_search(ctx, b, PG_MODE_BOTH, true);
+    if (rc) return rc;
+    return b->exact_n < 0 ? read_exact_count(ctx, b) : PG_OK;      // (later searches of the batch skip the exact kernel when its list is empty)
+}
+
 int pg_device_batch_repack(pg_ctx *ctx, pg_device_batch *b, double *pack_ms)
 {
     use_device(ctx);
@@ -1491,6 +1542,22 @@ void pg_device_batch_free(pg_ctx *ctx, pg_device_batch *b)
     if (!b) return;
     free_batch_buffers(b);
     delete b;
+}
+
+// Diagnostics (not in the public header): did the last launch that was asked to pack build its records inside the search kernel ?
+int pg_debug_last_pack_in_place(const pg_ctx *ctx) { return ctx && ctx->last_in_place ? 1 : 0; }
+
+// Diagnostics (not in the public header): overwrites the batch's packed records and bit planes (tests: what a search that packs in
+// place finds afterwards is what it packed itself).
+int pg_debug_scribble_records(pg_ctx *ctx, pg_device_batch *b)
+{
+    use_device(ctx);
+    if (!ctx || !b) return PG_E_INVALID;
+    const size_t n1 = std::max<size_t>(b->n, 1);
+    HIP_TRY(ctx, hipMemsetAsync(b->in_rec, 0xa5, n1 * sizeof(PgInRec), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(b->planes, 0x5a, n1 * 64 * pg_plane_blocks(b->max_len), ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PG_OK;
 }
 
 // Diagnostics (not in the public header): raw per-read words of the alg-bytes array.
@@ -1727,8 +1794,8 @@ static int search_host(pg_ctx *ctx, const pg_read_batch *reads, int mode, pg_res
             hipStream_t ks = (k & 1u) ? ctx->stream2 : ctx->stream;
             if (e == hipSuccess && k == 1) e = hipStreamWaitEvent(ks, ctx->events[2 * n_chunks], 0);     // (the memsets above)
             if (e == hipSuccess) e = hipStreamWaitEvent(ks, ctx->events[2 * k], 0);
-            if (e == hipSuccess) rc = pack_reads(ctx, b, lo, cn, ks);
-            if (e == hipSuccess && rc == PG_OK) rc = launch_range(ctx, b, mode, lo, cn, ks, (int)(k & 1u), k < 2);
+            // (the chunk's records: packed by its search launch itself where the chunk is large enough, by a launch of their own otherwise)
+            if (e == hipSuccess) rc = launch_range(ctx, b, mode, lo, cn, ks, (int)(k & 1u), k < 2, true);
             if (e == hipSuccess && rc == PG_OK) {
                 if (k > 0) e = hipStreamWaitEvent(ks, ctx->events[2 * (k - 1) + 1], 0);
                 if (e == hipSuccess)

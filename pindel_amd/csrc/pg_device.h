@@ -86,6 +86,8 @@ struct PgInRec {
     // dwords 16 .. 31: fetched by a seed-filter run (one orientation)
     uint32_t prog[2][PG_RO_GROUPS_MAX];
 };
+#define PG_PACK_CLAIM 16u          // ... of a launch that packs in place (PgDevBatch::soa)
+#define PG_PACK_IN_PLACE_MIN 1000000u      // fewest reads of such a launch (a wave then takes several claims)
 #define PG_CLAIM_DEFAULT 8u  // reads a workgroup of the persistent launch claims per atomic, at most
 #define PG_IN_PAD 8u        // records allocated behind the last one (the kernel prefetches the next read's record)
 struct PgOutRec {
@@ -98,6 +100,7 @@ struct PgOutRec {
     uint32_t reserved;      // diagnostics: candidates (survivors of the seed filter) folded for this read
 };
 
+struct PgSoaIn;
 struct PgDevBatch {
     uint32_t n_reads;
     uint32_t first_read;           // offset into the batch arrays handled by this launch
@@ -125,6 +128,9 @@ struct PgDevBatch {
     const uint32_t *exact_list;
     const uint32_t *exact_count;
     const uint16_t *thr_tab;       // [512]
+    // PACK IN PLACE (pg_launch_search, BOTH mode): non-null = the records and planes of the launch's reads are built from these SoA
+    // arrays (a PgSoaIn in device memory) by the search kernel itself, claim by claim, instead of by a pg_pack_reads launch before it
+    const struct PgSoaIn *soa;
 };
 
 // SoA views for the pack / unpack kernels
@@ -236,6 +242,9 @@ struct PgEnvSwitches {
     bool force_wide_cells;      // PG_FORCE_WIDE_CELLS: 64-bit candidate ids
     bool split_launch;          // PG_SPLIT_LAUNCH: close end and far end as two launches
     bool generic_kernels;       // PG_GENERIC_KERNELS: never the default-parameter kernels
+    bool no_pack_in_place;      // PG_NO_PACK_IN_PLACE: pg_device_batch_pack_search = pack launch + search launch
+    uint32_t pack_claim;        // PG_PACK_CLAIM: reads per claim of a launch that packs in place (0 = the default)
+    uint32_t pack_in_place_min; // PG_PACK_IN_PLACE_MIN: fewest reads of such a launch (tests: the path on small batches)
 };
 
 #ifdef __cplusplus
@@ -251,6 +260,8 @@ int pg_debug_kargs_check(const PgDevRef *ref, const PgDevParams *prm, const PgDe
 // 32-bit candidate ids (see above for when that is valid).
 int pg_launch_search(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch *batch,
                      int mode, uint32_t max_len, uint32_t levels, int small_ids, void *stream);
+// may that launch build the records of its reads itself (PgDevBatch::soa) ?
+int pg_pack_in_place_ok(int mode, uint32_t max_len, int small_ids, uint32_t n_reads, uint32_t plane_blocks);
 // ... then the reads on the batch's exact list that lie in the launch's range, with the reference's read-shortening semantics
 int pg_launch_search_exact(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch *batch, int mode,
                            uint32_t max_len, uint32_t levels, void *stream);

@@ -374,6 +374,9 @@ struct Lds {
     u32 t_acc[12];
     u32 t_pad[2];
 #endif
+#ifdef PG_PREFETCH
+    u32 pf[64];                               // where the claim's prefetch loads land (never read)
+#endif
     // staged window: code planes (lo, hi, N).  LAST member: for NB = 3 its second chunk's words are the launch's dynamic LDS,
     // which begins where this object ends (PG_WIN_STATIC_WORDS, pg_device.h; checked at the start of the kernel)
     uint4 win[PG_WIN_STATIC_WORDS(NB)];
@@ -1505,12 +1508,15 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
                     const u32 rmask = bits32(ns - pbase, ne - pbase) & ~bits32(xs - pbase, xe - pbase);
                     mF &= rmask;
                     mB &= rmask;
+                    h++;
+#ifdef PG_WIDE_SKIP
+                    if (ballot64((mF | mB) != 0u) == 0ull) continue;      // (most halves of a wide window: nobody passed the filter)
+#endif
                     const u32 cnt = (u32)(__popc(mF) + __popc(mB));
                     const u32 incl = wave_scan(cnt);
                     slot = end + (int)(incl - cnt);
                     end += (int)read_lane(incl, 63);
                     pos0 = (u32)(64 * NB + 32 * word);
-                    h++;
                     continue;
                 }
                 else if (end > 0) n = end;
@@ -1854,7 +1860,7 @@ __device__ __forceinline__ u32 pool_alloc(const PgDevBatch &B, int n, int lane, 
 // orientation 1 its first jb, the length and everything that follows from it (levels, thresholds, filter depths) shrink.
 template <int NB, int NS, typename Id, int mode, bool DEF, bool EXACT = false>
 __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevParams &prm, const PgDevBatch &B,
-                                            Search &S, u64 *qplanes, const uint32_t rid, const int slot, const int lane,
+                                            Search &S, u64 *qplanes, const uint32_t rid, const int touch_next, const int lane,
                                             const u32 res_base, const u32 res_fits)
 {
     // The lane index where the rest of a read needs it.  Kept from the start of the read it is a VGPR the compiler parks in scratch in
@@ -1908,7 +1914,8 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
     if ((mode & PG_MODE_CLOSE) && (flags & PG_RF_CLOSE_OK)) {
         // attempt 0's window -- the whole R = 1 window when that fits one chunk (PG_RF_SHARED_GRID): every attempt then runs on its grid
         const int ss = (int)ra[2], se = (int)ra[3];
-        if (ss < se) stage_window<NB>(ref, S, chr_wo, ss - 64 * NB, se + 64 * NB, lane, rp + 1);
+        // (touch_next = 0: the next record is another claim's and is still to be written -- pack in place; the read's own record then)
+        if (ss < se) stage_window<NB>(ref, S, chr_wo, ss - 64 * NB, se + 64 * NB, lane, rp + uni(touch_next));
     }
     store_planes<NB>(B, planes_of_read, lane, qplanes);
 
@@ -2421,6 +2428,9 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
 }
 #undef PG_LANE
 
+template <int PB>
+__device__ __forceinline__ void pack_block(const PgSoaIn &a, PgInRec *in, const u32 lo, const u32 r0, const u32 nb, const u32 lane);
+
 // Persistent 64-thread workgroups.  The reads of the launch are split into PG_N_XCD contiguous parts; a
 // workgroup (which the dispatcher places on XCD blockIdx % 8) claims PG_CLAIM reads at a time from its own
 // part's counter and moves on to the next part when that one is exhausted.
@@ -2506,6 +2516,37 @@ __global__ __launch_bounds__(WAVE, PG_WAVES(NB, Id)) void pg_search_kernel(PgDev
         }
         const uint32_t first = lo + got, end = hi - first < claim ? hi : first + claim;
         PG_T(S, 11);
+        uint32_t no_touch = ~0u;                          // the read that must not touch its successor's record (none)
+        if (mode == PG_MODE_BOTH) {
+            // PACK IN PLACE (PgDevBatch::soa set): the wave builds the records and bit planes of its claim from the SoA arrays
+            // before it searches them -- the pack kernel's body on the claim's reads.  A streaming transpose (HBM-bound on its own,
+            // 3 TB/s) inside a kernel that is bound by instruction issue and leaves 90 % of the HBM bandwidth idle: ~30 instructions
+            // per read instead of a launch of its own in front of this one.  What the wave wrote it reads back itself, through the
+            // caches of its own CU and XCD (scalar loads of the records, vector loads of the planes): the stores' completion is all
+            // there is to wait for.  (The host sets soa only when the batch's plane layout is this kernel's: plane_blocks == NB.)
+            const PgSoaIn *soa = KA(B, soa);
+            if (soa) {
+                const PgSoaIn a = *soa;
+                pack_block<NB>(a, const_cast<PgInRec *>(KA(B, in)), KA(B, first_read) + first, 0u, end - first, (u32)lane_now());
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // (a read touches the next read's record while it waits for its first window: the claim's last read would bring
+                // the line of a record nobody has written yet into the scalar cache, where its owner might then find it)
+                no_touch = end - 1u;
+            }
+        }
+#ifdef PG_PREFETCH
+        {
+            // The claim's records and bit planes on their way into L2 while the first read is searched: one LDS-direct load (no
+            // destination register, nothing waits for it), lanes 0..7 a record each, lanes 8..15 a read's planes.
+            const u32 l = (u32)lane_now(), idx = l & 7u;
+            const u32 pb = KA(B, plane_blocks);
+            const u32 r = KA(B, first_read) + first + idx;
+            const char *src = l < 8u ? (const char *)record_ptr<7>(KA(B, in), r) : (const char *)(KA(B, planes) + (size_t)r * 8u * pb);
+            if (l < 16u && PG_PREFETCH_FROM <= idx && first + idx < end)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) u32 *)src,
+                                                 (__attribute__((address_space(3))) u32 *)lds.pf, 4, 0, 0);
+        }
+#endif
         // run-pool slots of the claim's reads: one atomic per claim
         u32 res = 0u;
         {
@@ -2516,7 +2557,7 @@ __global__ __launch_bounds__(WAVE, PG_WAVES(NB, Id)) void pg_search_kernel(PgDev
             const u32 res_fits = (u64)res + (u64)(claim * PG_RESERVE) <= (u64)KA(B, pool_shard_cap) ? 1u : 0u;
             res += shard * KA(B, pool_shard_cap);
             for (uint32_t i = first; i < end; i++)
-                search_read<NB, NS, Id, mode, DEF>(ref, prm, B, S, qplanes, KA(B, first_read) + i, (int)(i - first), lane_now(),
+                search_read<NB, NS, Id, mode, DEF>(ref, prm, B, S, qplanes, KA(B, first_read) + i, i != no_touch ? 1 : 0, lane_now(),
                                           res + (i - first) * PG_RESERVE, res_fits);
             PG_T(S, 10);
         }
@@ -2608,7 +2649,7 @@ __global__ void pg_kargs_check_kernel(PgDevRef ref, PgDevParams prm, PgDevBatch 
     PG_CHK(prm, max_range_index); PG_CHK(prm, add_mm); PG_CHK(prm, min_perfect); PG_CHK(prm, min_close); PG_CHK(prm, spacer);
     PG_CHK(B, n_reads); PG_CHK(B, first_read); PG_CHK(B, in); PG_CHK(B, out); PG_CHK(B, seq); PG_CHK(B, planes); PG_CHK(B, plane_blocks);
     PG_CHK(B, bd); PG_CHK(B, pool); PG_CHK(B, pool_shard_cap); PG_CHK(B, pool_used); PG_CHK(B, work_ctr); PG_CHK(B, claim);
-    PG_CHK(B, exact_list); PG_CHK(B, exact_count); PG_CHK(B, thr_tab);
+    PG_CHK(B, exact_list); PG_CHK(B, exact_count); PG_CHK(B, thr_tab); PG_CHK(B, soa);
 #undef PG_CHK
     {
         const u32 *glo, *ghi, *gnn;
@@ -2680,6 +2721,13 @@ static void launch_ns(const PgDevRef *ref, const PgDevParams *prm, const PgDevBa
         const uint32_t per_wg = (batch->n_reads + grid.x - 1u) / grid.x, n_claims = (per_wg + PG_CLAIM - 1u) / PG_CLAIM;
         with_claim.claim = per_wg >= 8u * PG_CLAIM ? PG_CLAIM : (per_wg + n_claims - 1u) / n_claims;
         if (with_claim.claim == 0u) with_claim.claim = 1u;
+        // pack in place: claims of PG_PACK_CLAIM reads (the pack's per-read lane = a quarter of the wave busy; the launch's tail
+        // grows with the claim).  The caller offers it only for launches that are large enough (pg_pack_in_place_ok).
+        if (batch->soa) {
+            const uint32_t pc = pg_env_switches()->pack_claim ? pg_env_switches()->pack_claim : PG_PACK_CLAIM;
+            with_claim.claim = pc > 64u ? 64u : pc;
+            if (mode != PG_MODE_BOTH || pg_env_switches()->split_launch || batch->plane_blocks != (uint32_t)NB) abort();   // (pg_pack_in_place_ok)
+        }
     }
     batch = &with_claim;
     if (PG_WIN_DYN_BYTES(NB) != 0u && prm->max_range_index >= 3) lds_pad += PG_WIN_DYN_BYTES(NB);   // two chunks per fill need their LDS
@@ -2763,21 +2811,19 @@ static_assert(sizeof(PgInRec) == 128 && offsetof(PgInRec, prog) == 64 && offseto
               offsetof(PgInRec, chr_size) == 48 && offsetof(PgInRec, bd_cnt) == 52 && offsetof(PgInRec, bd_off) == 56 && offsetof(PgInRec, jmask1) == 60,
               "pg_pack_kernel writes PgInRec as four uint4; search_read reads it as dwords 0..7, 8..11, 12..15");
 struct PgDw3 { u32 x, y, z; };
+// One wave, reads [lo + r0, lo + r0 + nb) of the SoA arrays, nb <= 64 (pg_pack_kernel: 64 at a time; pg_search_kernel with
+// PgDevBatch::soa set: the reads of a claim, just before it searches them).
 template <int PB>
-__global__ __launch_bounds__(256) void pg_pack_kernel(PgSoaIn a, PgInRec *in, uint32_t lo, uint32_t cnt)
+__device__ __forceinline__ void pack_block(const PgSoaIn &a, PgInRec *in, const u32 lo, const u32 r0, const u32 nb, const u32 lane)
 {
     constexpr u32 LPR = 8u * PB;                       // lanes per read in phase B
     constexpr u32 RPW = 64u / LPR;                     // reads per step (PB = 3: two reads on 48 lanes)
     constexpr u32 STEPS = (64u + RPW - 1u) / RPW;
     constexpr u32 U = PG_PACK_UNROLL < STEPS ? PG_PACK_UNROLL : STEPS;
     static_assert(STEPS % U == 0, "unroll must divide the steps");
-    const u32 lane = threadIdx.x & 63u;
     const u32 slot = lane / LPR, L = lane % LPR;
     const u32 D = L >> 2, pl = L & 3u, idx0 = 8u * L;
-    const u32 n_blocks = (cnt + 63u) >> 6, n_waves = gridDim.x * 4u;
-    for (u32 g = blockIdx.x * 4u + (threadIdx.x >> 6); g < n_blocks; g += n_waves) {
-        const u32 r0 = g << 6;
-        const u32 nb = cnt - r0 < 64u ? cnt - r0 : 64u;
+    {
         // ---- phase A: lane = read.  The whole 64-byte record from one lane (the wave writes 4 KB contiguous): everything the search
         // kernel would otherwise derive per read on its scalar unit (PgInRec, pg_device.h)
         u32 so_lo = 0u, so_hi = 0u, len = 0u;
@@ -2855,7 +2901,7 @@ __global__ __launch_bounds__(256) void pg_pack_kernel(PgSoaIn a, PgInRec *in, ui
             dst[3] = q3;
         }
         // ---- phase B: 8 PB lanes = one read
-        for (u32 s = 0; s < STEPS; s += U) {
+        for (u32 s = 0; s < STEPS && s * RPW < nb; s += U) {
             u32 d0[U], d1[U], d2[U], ln[U], sh[U];
             bool act[U];
 #pragma unroll
@@ -2963,6 +3009,15 @@ __global__ __launch_bounds__(256) void pg_pack_kernel(PgSoaIn a, PgInRec *in, ui
                 }
             }
         }
+    }
+}
+template <int PB>
+__global__ __launch_bounds__(256) void pg_pack_kernel(PgSoaIn a, PgInRec *in, uint32_t lo, uint32_t cnt)
+{
+    const u32 n_blocks = (cnt + 63u) >> 6, n_waves = gridDim.x * 4u;
+    for (u32 g = blockIdx.x * 4u + (threadIdx.x >> 6); g < n_blocks; g += n_waves) {
+        const u32 r0 = g << 6;
+        pack_block<PB>(a, in, lo, r0, cnt - r0 < 64u ? cnt - r0 : 64u, threadIdx.x & 63u);
     }
 }
 
@@ -3107,6 +3162,22 @@ extern "C" int pg_debug_occupancy(uint32_t max_len, uint32_t levels, int small_i
         e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(far_blocks, pg_search_kernel<2, 3, u64, PG_MODE_BOTH, false>, WAVE, 0);
     }
     return (int)e1 | (int)e2;
+}
+
+// 64-base blocks per read of the kernels pg_launch_search picks for a batch
+static int search_class_blocks(uint32_t max_len, int small_ids)
+{
+    const int nb = max_len <= 128 ? 2 : (max_len <= 256 ? 4 : 8);
+    if (!small_ids) return nb;
+    return max_len <= 64 ? 1 : (nb == 2 ? 2 : (max_len <= 192 ? 3 : nb));
+}
+// May a launch of `mode` over n_reads reads build its records itself (PgDevBatch::soa) ?  BOTH mode in one launch, the batch's plane
+// layout that of the kernels' class, and enough reads that every wave takes several claims of PG_PACK_CLAIM.
+extern "C" int pg_pack_in_place_ok(int mode, uint32_t max_len, int small_ids, uint32_t n_reads, uint32_t plane_blocks)
+{
+    if (mode != PG_MODE_BOTH || pg_env_switches()->split_launch || pg_env_switches()->no_pack_in_place) return 0;
+    if ((uint32_t)search_class_blocks(max_len, small_ids) != plane_blocks) return 0;
+    return n_reads >= pg_env_switches()->pack_in_place_min ? 1 : 0;
 }
 
 extern "C" int pg_launch_search(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch *batch,

@@ -1,7 +1,8 @@
 """Diagnostics: run the device-resident search of the bench workload with another build of the library
 (e.g. one compiled with -DPG_STOP=n or -DPG_DUP=n), for rocprofv3 counter passes and A/B timing.  Prints the kernel
 time, the candidates per read and a digest of the downloaded result (equal digests = bit-identical results).
-  PG_X=<n> selects -x n, PG_LEN=<bases> the read length, PG_SORT=1 the reads in coordinate order."""
+  PG_X=<n> selects -x n, PG_LEN=<bases> the read length, PG_SORT=1 the reads in coordinate order, PG_STEP=1 the step of bench.py
+  (pg_device_batch_pack_search: a million reads and more = one launch that packs in place) instead of the search of packed records."""
 import hashlib
 import os
 import sys
@@ -35,7 +36,10 @@ eng.load_reference([("20", ref)])
 db = eng.upload(batch)
 ms = []
 for _ in range(3):
-    eng.search_device(db)
+    if os.environ.get("PG_STEP"):
+        eng.pack_search_device(db)
+    else:
+        eng.search_device(db)
     ms.append(eng.last_stats()[0])
 res = eng.download(db)
 h = hashlib.sha256()

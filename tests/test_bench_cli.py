@@ -97,8 +97,10 @@ def test_eight_ranks_on_one_device_strong_and_weak(one_gpu_line):
 
 
 def test_value_covers_the_pack_stage(one_gpu_line):
-    # round 6: a step = pg_pack_kernel + pg_search_kernel; the search-only figure of rounds 1-5 rides along
+    # round 6: a step = pack + search (pg_device_batch_pack_search); the search-only figure of rounds 1-5 rides along, measured
+    # outside the timed region
     c = one_gpu_line["config"]
-    assert c["pack_ms_per_step"] > 0 and c["search_ms_per_step"] > 0
-    assert one_gpu_line["ms_per_step"] >= c["pack_ms_per_step"] + c["search_ms_per_step"] * 0.98
+    assert c["device_ms_per_step"] > 0 and c["pack_ms_standalone"] > 0 and c["search_ms_standalone"] > 0
+    assert one_gpu_line["ms_per_step"] >= c["device_ms_per_step"] * 0.98
+    assert c["device_ms_per_step"] >= c["search_ms_standalone"] * 0.98          # the pack is in the step
     assert c["value_search_only"] > one_gpu_line["value"]
