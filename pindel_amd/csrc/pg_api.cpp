@@ -205,6 +205,7 @@ struct pg_ctx {
     uint16_t thr[512]{};
     uint16_t *d_thr = nullptr;
     uint32_t *d_mm = nullptr;
+    PgLenRec *d_len_tab = nullptr;     // [512] pg_len_rec of every read length under this context's parameters (the pack's per-length fields)
     hipStream_t stream = nullptr, copy_stream = nullptr;   // kernels / host-to-device input copies
     hipStream_t dl_stream = nullptr;                       // device-to-host result copies of the chunked host path
     hipStream_t stream2 = nullptr;                         // second kernel stream of the chunked host path (odd chunks)
@@ -783,8 +784,7 @@ PgSoaIn soa_in(const pg_ctx *ctx, const pg_device_batch *b)
     a.bd_off = b->bd_off;
     a.exact_list = b->exact_list;
     a.exact_count = b->exact_count;
-    a.mm = ctx->d_mm;
-    a.thr = ctx->d_thr;
+    a.len_tab = ctx->d_len_tab;
     a.chr_word_off = ctx->d_word_off;
     a.chr_size = ctx->d_chr_size;
     a.spacer = ctx->prm.spacer;
@@ -1199,7 +1199,10 @@ int pg_create(const pg_params *p, pg_ctx **out)
             pg_destroy(ctx);
             return PG_E_UNSUPPORTED;
         }
-    if (dev_upload(ctx, &ctx->d_thr, ctx->thr, 512) || dev_upload(ctx, &ctx->d_mm, ctx->mm, 512)) {
+    std::vector<PgLenRec> len_tab(512);
+    for (int len = 0; len < 512; len++) len_tab[len] = pg_len_rec(len, ctx->mm, ctx->thr, ctx->prm.additional_mismatch, ctx->prm.min_close);
+    if (dev_upload(ctx, &ctx->d_thr, ctx->thr, 512) || dev_upload(ctx, &ctx->d_mm, ctx->mm, 512) ||
+        dev_upload(ctx, &ctx->d_len_tab, len_tab.data(), 512)) {
         pg_destroy(ctx);
         return PG_E_DEVICE;
     }
@@ -1228,6 +1231,7 @@ void pg_destroy(pg_ctx *ctx)
     if (ctx->arena.base) (void)hipFree(ctx->arena.base);
     if (ctx->d_thr) (void)hipFree(ctx->d_thr);
     if (ctx->d_mm) (void)hipFree(ctx->d_mm);
+    if (ctx->d_len_tab) (void)hipFree(ctx->d_len_tab);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

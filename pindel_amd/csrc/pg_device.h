@@ -86,8 +86,9 @@ struct PgInRec {
     // dwords 16 .. 31: fetched by a seed-filter run (one orientation)
     uint32_t prog[2][PG_RO_GROUPS_MAX];
 };
-#define PG_PACK_CLAIM 16u          // ... of a launch that packs in place (PgDevBatch::soa)
-#define PG_PACK_IN_PLACE_MIN 1000000u      // fewest reads of such a launch (a wave then takes several claims)
+#define PG_PACK_CLAIM 8u            // ... of a launch that packs in place (PgDevBatch::soa) ...
+#define PG_PACK_CLAIM_LONG 16u      // ... and when a wave takes many of them (pg_launch_search)
+#define PG_PACK_IN_PLACE_MIN 2000000u      // fewest reads of such a launch (a wave then takes dozens of claims)
 #define PG_CLAIM_DEFAULT 8u  // reads a workgroup of the persistent launch claims per atomic, at most
 #define PG_IN_PAD 8u        // records allocated behind the last one (the kernel prefetches the next read's record)
 struct PgOutRec {
@@ -150,8 +151,7 @@ struct PgSoaIn {
     const uint64_t *bd_off;        // nullable
     uint32_t *exact_list;          // nullable: indices of the reads with a character outside ACGTN ...
     uint32_t *exact_count;         // ... and how many (zeroed by the caller before the batch's first pack)
-    const uint32_t *mm;            // [512] g_maxMismatch
-    const uint16_t *thr;           // [512]
+    const struct PgLenRec *len_tab; // [512] the fields of a read's record that follow from its length alone (pg_len_rec)
     const uint64_t *chr_word_off;  // [n_chr] as PgDevRef
     const uint32_t *chr_size;      // [n_chr]
     uint32_t spacer;
@@ -186,6 +186,34 @@ static inline int pg_ro_groups(int len, int T, int wide)
     if (G > PG_RO_GROUPS_MAX) G = PG_RO_GROUPS_MAX;
     while (G > 0 && 3 * G > len - 1) G--;
     return G;
+}
+// What PgInRec holds that is a function of the read's LENGTH and the search parameters alone (lvl, depth, jmask0, ro, jmask1): one
+// table per context, built on the host when the context is created (the pack's per-read lane used to work these out -- two depths,
+// two group counts, six table look-ups -- for every read; inside the search kernel that lane's instructions are paid for by a claim of
+// eight reads).
+struct PgLenRec { uint32_t lvl, depth, jmask0, ro, jmask1, pad[3]; };
+static inline struct PgLenRec pg_len_rec(int len, const uint32_t *mm, const uint16_t *thr, int add_mm, int min_close)
+{
+    struct PgLenRec r;
+    const uint32_t M = mm[len] & 0xffu, T = M + (uint32_t)add_mm + 1u;
+    const int J0 = pg_seed_depth(len, (int)T, 0), J1 = pg_seed_depth(len, (int)T, 1);
+    // relevance bound of a seed: min(T - 1, g_maxMismatch[J] + ADD)  (J >= 0; a one-base read has J = 0)
+    uint32_t b0 = (mm[J0 < 0 ? 0 : J0] & 0xffu) + (uint32_t)add_mm, b1 = (mm[J1 < 0 ? 0 : J1] & 0xffu) + (uint32_t)add_mm;
+    if (b0 > T - 1u) b0 = T - 1u;
+    if (b1 > T - 1u) b1 = T - 1u;
+    r.lvl = (uint32_t)thr[len] | (M << 16) | (T << 24);
+    r.depth = (uint32_t)(J0 < 0 ? 0 : J0) | ((uint32_t)(J1 < 0 ? 0 : J1) << 8) | (b0 << 16) | (b1 << 24);
+    r.jmask0 = J0 > 1 ? ((J0 >= 32 ? 0xffffffffu : (1u << J0) - 1u) & ~1u) : 0u;
+    r.jmask1 = J1 > 1 ? ((J1 >= 32 ? 0xffffffffu : (1u << J1) - 1u) & ~1u) : 0u;
+    // read-order filter (PgInRec::ro): whole groups of three bases, the relevance bound of the depth they reach
+    const int G0 = pg_ro_groups(len, (int)T, 0), G1 = pg_ro_groups(len, (int)T, 1);
+    uint32_t rb0 = (mm[3 * G0 + 1] & 0xffu) + (uint32_t)add_mm, rb1 = (mm[3 * G1 + 1] & 0xffu) + (uint32_t)add_mm;
+    if (rb0 > T - 1u) rb0 = T - 1u;
+    if (rb1 > T - 1u) rb1 = T - 1u;
+    r.ro = (uint32_t)G0 | ((uint32_t)G1 << 4) | (rb0 << 8) | (rb1 << 16);
+    if (T <= 16u && G0 >= PG_RO_GROUPS_MIN && G1 >= PG_RO_GROUPS_MIN && min_close >= 8) r.ro |= PG_RO_OK;     // (the close end's snapshot covers seven bases)
+    r.pad[0] = r.pad[1] = r.pad[2] = 0u;
+    return r;
 }
 struct PgSoaOut {
     uint8_t *rc_flag;

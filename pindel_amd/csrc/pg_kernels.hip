@@ -374,9 +374,6 @@ struct Lds {
     u32 t_acc[12];
     u32 t_pad[2];
 #endif
-#ifdef PG_PREFETCH
-    u32 pf[64];                               // where the claim's prefetch loads land (never read)
-#endif
     // staged window: code planes (lo, hi, N).  LAST member: for NB = 3 its second chunk's words are the launch's dynamic LDS,
     // which begins where this object ends (PG_WIN_STATIC_WORDS, pg_device.h; checked at the start of the kernel)
     uint4 win[PG_WIN_STATIC_WORDS(NB)];
@@ -1509,8 +1506,8 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
                     mF &= rmask;
                     mB &= rmask;
                     h++;
-#ifdef PG_WIDE_SKIP
-                    if (ballot64((mF | mB) != 0u) == 0ull) continue;      // (most halves of a wide window: nobody passed the filter)
+#ifndef PG_NO_WIDE_SKIP
+                    if (ballot64((mF | mB) != 0u) == 0ull) continue;      // (most halves of a wide window: nobody passed the filter -- no prefix sum)
 #endif
                     const u32 cnt = (u32)(__popc(mF) + __popc(mB));
                     const u32 incl = wave_scan(cnt);
@@ -2493,6 +2490,10 @@ __global__ __launch_bounds__(WAVE, PG_WAVES(NB, Id)) void pg_search_kernel(PgDev
     // (Claims of ONE read for the last round and a half of a launch, to shorten its tail, were measured and rejected: a claim
     // is a dependent chain atomic -> records -> first window, 2 us that eight reads share -- 262 144 reads 0.94 -> 0.98 ms.)
     // Nothing but `part` and `tried` lives from one claim to the next: the launch's size comes from the kernarg segment again.
+    // (Quarter claims for the last rounds of a launch that packs in place -- the waves finish spread over one claim's duration -- were
+    // measured and rejected, round 6: a claim is a dependent chain atomic -> pack (three HBM round trips) -> records, and the short
+    // claims cost more than the shorter tail gives back: 2 M reads at -x 5 22.16 -> 22.24 ms, 2 M at -x 2 4.55 -> 4.58 / 4.70 ms
+    // for two / four rounds.  Claims of eight, as without the pack: sixteen and more lose at -x 5, where a read takes 79 us.)
     uint32_t part = blockIdx.x % PG_N_XCD, tried = 0;
     while (tried < PG_N_XCD) {
         const uint32_t n = KA(B, n_reads);
@@ -2534,19 +2535,6 @@ __global__ __launch_bounds__(WAVE, PG_WAVES(NB, Id)) void pg_search_kernel(PgDev
                 no_touch = end - 1u;
             }
         }
-#ifdef PG_PREFETCH
-        {
-            // The claim's records and bit planes on their way into L2 while the first read is searched: one LDS-direct load (no
-            // destination register, nothing waits for it), lanes 0..7 a record each, lanes 8..15 a read's planes.
-            const u32 l = (u32)lane_now(), idx = l & 7u;
-            const u32 pb = KA(B, plane_blocks);
-            const u32 r = KA(B, first_read) + first + idx;
-            const char *src = l < 8u ? (const char *)record_ptr<7>(KA(B, in), r) : (const char *)(KA(B, planes) + (size_t)r * 8u * pb);
-            if (l < 16u && PG_PREFETCH_FROM <= idx && first + idx < end)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) u32 *)src,
-                                                 (__attribute__((address_space(3))) u32 *)lds.pf, 4, 0, 0);
-        }
-#endif
         // run-pool slots of the claim's reads: one atomic per claim
         u32 res = 0u;
         {
@@ -2721,10 +2709,15 @@ static void launch_ns(const PgDevRef *ref, const PgDevParams *prm, const PgDevBa
         const uint32_t per_wg = (batch->n_reads + grid.x - 1u) / grid.x, n_claims = (per_wg + PG_CLAIM - 1u) / PG_CLAIM;
         with_claim.claim = per_wg >= 8u * PG_CLAIM ? PG_CLAIM : (per_wg + n_claims - 1u) / n_claims;
         if (with_claim.claim == 0u) with_claim.claim = 1u;
-        // pack in place: claims of PG_PACK_CLAIM reads (the pack's per-read lane = a quarter of the wave busy; the launch's tail
-        // grows with the claim).  The caller offers it only for launches that are large enough (pg_pack_in_place_ok).
+        // pack in place: the pack's per-read lane (phase A) costs the same ~100 instructions for a claim of 8 or 16 reads, but a longer
+        // claim lengthens the launch's tail where a wave is busy with it for long.  Measured (ms, pack launch + search launch -> one
+        // launch with claims of 8 / 16): 10 M x 100 bp 22.25 -> 21.91 / 21.68; 10 M x 150 bp 25.58 -> 25.24 / 25.07; 2 M 4.60 -> 4.53 / 4.52;
+        // 1 M 2.43 -> 2.38 / 2.42; 2 M at -x 5 (79 us per read) 21.95 -> 21.88 / 22.29.  Sixteen where a wave takes at least 32 such
+        // claims and the ranges are the default ones, eight otherwise.  The caller offers the path only for launches that are large
+        // enough (pg_pack_in_place_ok).
         if (batch->soa) {
-            const uint32_t pc = pg_env_switches()->pack_claim ? pg_env_switches()->pack_claim : PG_PACK_CLAIM;
+            const uint32_t dflt = prm->max_range_index <= 2 && per_wg >= 32u * PG_PACK_CLAIM_LONG ? PG_PACK_CLAIM_LONG : PG_PACK_CLAIM;
+            const uint32_t pc = pg_env_switches()->pack_claim ? pg_env_switches()->pack_claim : dflt;
             with_claim.claim = pc > 64u ? 64u : pc;
             if (mode != PG_MODE_BOTH || pg_env_switches()->split_launch || batch->plane_blocks != (uint32_t)NB) abort();   // (pg_pack_in_place_ok)
         }
@@ -2772,22 +2765,12 @@ static void launch(const PgDevRef *ref, const PgDevParams *prm, const PgDevBatch
 // (len + 27 bytes in, 64 PB + 32 out per read), so it is laid out for bandwidth, not for a wave per block:
 //   * 8 PB consecutive lanes own one read, lane L its bases [8 L, 8 L + 8): the wave's loads walk the concatenated
 //     sequence buffer in 8-byte steps (three aligned dword loads + v_alignbyte per lane; any read alignment), the
-//     bases are classified four at a time with exact SWAR byte compares, no ballots;
+//     bases are classified four at a time (v_perm + one SWAR compare, exact for every byte value), no ballots;
 //   * a 4 x 4 byte transpose inside every lane quad (two quad shuffles) turns "8 bases x 4 planes" per lane into
 //     "32 bases of ONE plane" per lane: lane (D, p) = dword D of plane p, so the read's 8 PB lanes write its forward
 //     planes as 8 PB dwords that tile 32 PB contiguous bytes;
 //   * the reversed orientation is the same bit string mirrored: dword D of it is a 32-bit window of the forward plane
 //     at bit len - 32 - 32 D, bit-reversed -- two lane shuffles + v_alignbit + v_bfrev, no second pass over the bases.
-__device__ __forceinline__ u32 swar_eq(u32 w, u32 k)         // 0x80 in every byte of w that equals the byte of k
-{
-    const u32 x = w ^ k;
-    const u32 t = (x & 0x7f7f7f7fu) + 0x7f7f7f7fu;
-    return ~(t | x) & 0x80808080u;
-}
-__device__ __forceinline__ u32 swar_bits(u32 m)               // the four 0x80 flags of m as bits 0..3
-{
-    return (((m >> 7) * 0x01020408u) >> 24) & 0xfu;
-}
 // A wave takes 64 CONSECUTIVE reads at a time.  What bounds this kernel is neither ALU (-8 % with the classification removed)
 // nor bytes in flight per wave (unrolling does nothing) nor the number of memory instructions, but the number of memory
 // REQUESTS (cache lines touched) per byte moved -- measured on 10 M x 100 bp, profiles/r04/pack_kernel.txt: four reads
@@ -2840,11 +2823,11 @@ __device__ __forceinline__ void pack_block(const PgSoaIn &a, PgInRec *in, const 
             const u32 strand = a.strand[ii];
             const int chr = a.chr[ii];
             const u64 wo = a.chr_word_off[chr];
-            const u32 M = a.mm[lc] & 0xffu, T = M + (u32)a.add_mm + 1u;
-            const int J0 = pg_seed_depth((int)len, (int)T, 0), J1 = pg_seed_depth((int)len, (int)T, 1);
-            // relevance bound of a seed: min(T - 1, g_maxMismatch[J] + ADD)  (J >= 0; a one-base read has J = 0)
-            const u32 b0 = min(T - 1u, (a.mm[J0 < 0 ? 0 : J0] & 0xffu) + (u32)a.add_mm), b1 = min(T - 1u, (a.mm[J1 < 0 ? 0 : J1] & 0xffu) + (u32)a.add_mm);
-            const u32 jm0 = J0 > 1 ? ((J0 >= 32 ? 0xffffffffu : (1u << J0) - 1u) & ~1u) : 0u, jm1 = J1 > 1 ? ((J1 >= 32 ? 0xffffffffu : (1u << J1) - 1u) & ~1u) : 0u;
+            // what follows from the read's length alone: mismatch levels, CheckMismatches' threshold, the seed filter's depths, bounds
+            // and masks (pg_len_rec, one table per context; two 16-byte loads)
+            uint4 lt0, lt1;
+            __builtin_memcpy(&lt0, __builtin_assume_aligned(a.len_tab + lc, 16), 16);
+            __builtin_memcpy(&lt1, __builtin_assume_aligned((const char *)(a.len_tab + lc) + 16, 16), 16);
             u32 flags = 0u;
             const bool plus = strand == (u32)'+';
             if ((int)len - 1 >= a.min_close && (plus || strand == (u32)'-')) flags |= PG_RF_CLOSE_OK;
@@ -2875,19 +2858,14 @@ __device__ __forceinline__ void pack_block(const PgSoaIn &a, PgInRec *in, const 
             q1.x = (u32)wo;
             q1.y = (u32)(wo >> 32);
             q1.z = (len & 0xffffu) | (flags << 16);
-            q1.w = (u32)a.thr[lc] | (M << 16) | (T << 24);
-            q2.x = (u32)(J0 < 0 ? 0 : J0) | ((u32)(J1 < 0 ? 0 : J1) << 8) | (b0 << 16) | (b1 << 24);
-            q2.y = jm0;
-            {   // read-order filter (PgInRec::ro): whole groups of three bases, the relevance bound of the depth they reach
-                const int G0 = pg_ro_groups((int)len, (int)T, 0), G1 = pg_ro_groups((int)len, (int)T, 1);
-                const u32 rb0 = min(T - 1u, (a.mm[3 * G0 + 1] & 0xffu) + (u32)a.add_mm), rb1 = min(T - 1u, (a.mm[3 * G1 + 1] & 0xffu) + (u32)a.add_mm);
-                q2.z = (u32)G0 | ((u32)G1 << 4) | (rb0 << 8) | (rb1 << 16);
-                if (T <= 16u && G0 >= PG_RO_GROUPS_MIN && G1 >= PG_RO_GROUPS_MIN && a.min_close >= 8) q2.z |= PG_RO_OK;    // (the close end's snapshot covers seven bases)
-            }
+            q1.w = lt0.x;               // PgLenRec: lvl, depth, jmask0, ro | jmask1
+            q2.x = lt0.y;
+            q2.y = lt0.z;
+            q2.z = lt0.w;
             q2.w = (u32)chr;
             q3.x = a.chr_size[chr];
             q3.y = q3.z = 0u;
-            q3.w = jm1;
+            q3.w = lt1.x;
             if (a.bd_off) {
                 uint4 w;
                 __builtin_memcpy(&w, __builtin_assume_aligned(a.bd_off + ii, 8), 16);
@@ -2929,17 +2907,32 @@ __device__ __forceinline__ void pack_block(const PgSoaIn &a, PgInRec *in, const 
                 const u32 nv = ln[u] > idx0 ? (ln[u] - idx0 < 8u ? ln[u] - idx0 : 8u) : 0u;
                 const u32 vm0 = nv >= 4u ? 0x80808080u : (0x80808080u & ((1u << (8u * nv)) - 1u));
                 const u32 vm1 = nv >= 8u ? 0x80808080u : (nv > 4u ? (0x80808080u & ((1u << (8u * (nv - 4u))) - 1u)) : 0u);
+                // Eight bases -> P: byte j = plane j (code bit 0, code bit 1, N, other) of bases [8 L, 8 L + 8), bit k = base k.
+                // (Round 6, when this code began to run inside the search kernel -- pack in place -- where every issue slot counts:
+                // ten SWAR compares and eight multiply-gathers, 106 instructions with eight quarter-rate multiplies, became 55.)
+                // Per word of four characters: bits 1-2 of the ASCII code tell A / C / T / G apart (0 1 2 3); v_perm turns them back
+                // into the letter they stand for, and a character IS one of ACGT iff it equals that letter -- exact for all 256 byte
+                // values; N by one compare; the rest is "other".  The four flags of a base make a nibble (code bit 0 = C|T =
+                // bit 0 ^ bit 1 of the two-bit code, code bit 1 = G|T = its bit 1), two words make "byte k = bases k and k + 4", and
+                // three delta swaps (distances 7, 14, 21) transpose both 4 x 4 bit matrices at once.
                 u32 P;
                 {
-                    const u32 a0 = swar_eq(w0, 0x41414141u), c0 = swar_eq(w0, 0x43434343u), g0 = swar_eq(w0, 0x47474747u),
-                              t0 = swar_eq(w0, 0x54545454u), n0 = swar_eq(w0, 0x4e4e4e4eu);
-                    const u32 a1 = swar_eq(w1, 0x41414141u), c1 = swar_eq(w1, 0x43434343u), g1 = swar_eq(w1, 0x47474747u),
-                              t1 = swar_eq(w1, 0x54545454u), n1 = swar_eq(w1, 0x4e4e4e4eu);
-                    const u32 lo8 = swar_bits((c0 | t0) & vm0) | (swar_bits((c1 | t1) & vm1) << 4);
-                    const u32 hi8 = swar_bits((g0 | t0) & vm0) | (swar_bits((g1 | t1) & vm1) << 4);
-                    const u32 nn8 = swar_bits(n0 & vm0) | (swar_bits(n1 & vm1) << 4);
-                    const u32 oo8 = swar_bits(vm0 & ~(a0 | c0 | g0 | t0 | n0)) | (swar_bits(vm1 & ~(a1 | c1 | g1 | t1 | n1)) << 4);
-                    P = lo8 | (hi8 << 8) | (nn8 << 16) | (oo8 << 24);     // byte j = plane j of bases [8 L, 8 L + 8)
+                    auto nibbles = [](u32 w, u32 vm) {
+                        const u32 code = (w >> 1) & 0x03030303u;
+                        const u32 x = w ^ __builtin_amdgcn_perm(0x47544341u, 0x47544341u, code);
+                        const u32 V = ~((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x)) & vm;           // 0x80 where the byte is one of ACGT (and valid)
+                        const u32 xn = w ^ 0x4e4e4e4eu;
+                        const u32 N = ~((((xn & 0x7f7f7f7fu) + 0x7f7f7f7fu) | xn)) & vm;
+                        const u32 O = vm & ~(V | N);
+                        const u32 c = code & ((V >> 7) | (V >> 6));
+                        return ((c ^ (c >> 1)) & 0x01010101u) | (c & 0x02020202u) | (N >> 5) | (O >> 4);
+                    };
+                    u32 Z = nibbles(w0, vm0) | (nibbles(w1, vm1) << 4);
+                    u32 t;
+                    t = (Z ^ (Z >> 7)) & 0x884422u;  Z ^= t | (t << 7);
+                    t = (Z ^ (Z >> 14)) & 0x8844u;   Z ^= t | (t << 14);
+                    t = (Z ^ (Z >> 21)) & 0x88u;     Z ^= t | (t << 21);
+                    P = Z;
                 }
                 // ---- 4 x 4 byte transpose in the quad: lane (D = L >> 2, p = L & 3) <- dword D of plane p
                 const u32 t = (u32)__shfl_xor((int)P, 2);

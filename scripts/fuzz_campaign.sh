@@ -15,4 +15,7 @@ cd "$root" || exit 1
     FUZZ_QUIET=1 FUZZ_BOTH_FAMILIES=1 timeout 1200 python scripts/fuzz_parity.py ${N3:-400} 310000 2>&1 | grep -v amdgpu.ids | tail -3
     echo "== characters outside ACGTN in one read in twelve (seeds >= 600000): the exact kernel"
     FUZZ_QUIET=1 timeout 900 python scripts/fuzz_parity.py ${N4:-300} 600000 2>&1 | grep -v amdgpu.ids | tail -3
+    echo "== every launch packing in place (PG_PACK_IN_PLACE_MIN=1: the chunks of the host path, any size), seeds of the first and the fourth stream"
+    PG_PACK_IN_PLACE_MIN=1 FUZZ_QUIET=1 timeout 900 python scripts/fuzz_parity.py ${N5:-200} 90000 2>&1 | grep -v amdgpu.ids | tail -3
+    PG_PACK_IN_PLACE_MIN=1 FUZZ_QUIET=1 timeout 900 python scripts/fuzz_parity.py ${N5:-200} 620000 2>&1 | grep -v amdgpu.ids | tail -3
 } | tee "$out/fuzz_log.txt"

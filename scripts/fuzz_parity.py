@@ -167,7 +167,11 @@ def one_iteration(seed, n_reads=1500, verbose=True, generic=False):
             orc = run_oracle(kw, chroms, batch, bd=bd, bd_off=bd_off)
             db = eng.upload(batch)                    # and the fused device-resident launch with windows
             eng.set_windows(db, bd, bd_off)
-            eng.search_device(db)
+            if os.environ.get("PG_PACK_IN_PLACE_MIN"):     # the step as one launch: the search kernel packs its claims (records overwritten first)
+                eng.scribble_records(db)
+                eng.pack_search_device(db)
+            else:
+                eng.search_device(db)
             compare_result(eng.download(db), orc, batch.n)
             eng.free_device_batch(db)
         compare_result(gpu, orc, batch.n)

@@ -10,7 +10,7 @@ names = sys.argv[4:]
 rows = collections.defaultdict(dict)          # dispatch id -> counter -> value
 for path in sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(path)):
-        if "pg_search" in r["Kernel_Name"]:
+        if "pg_search_kernel" in r["Kernel_Name"]:
             rows[int(r["Dispatch_Id"])][r["Counter_Name"]] = rows[int(r["Dispatch_Id"])].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
 ids = sorted(rows)
 ctrs = sorted({c for v in rows.values() for c in v})

@@ -20,8 +20,8 @@ def counter(directory, kernel, name):
 
 
 fetch_dir, write_dir, calib_dir, reads = sys.argv[1], sys.argv[2], sys.argv[3], float(sys.argv[4])
-fetch_kb, nf = counter(fetch_dir, "pg_search", "FETCH_SIZE")
-write_kb, nw = counter(write_dir, "pg_search", "WRITE_SIZE")
+fetch_kb, nf = counter(fetch_dir, "pg_search_kernel", "FETCH_SIZE")
+write_kb, nw = counter(write_dir, "pg_search_kernel", "WRITE_SIZE")
 calib_kb, _ = counter(calib_dir, "pg_calib_stream", "FETCH_SIZE")
 true_bytes = 2147483648
 factor = true_bytes / (calib_kb * 1024.0) if calib_kb else 2.0
@@ -34,7 +34,8 @@ if len(sys.argv) > 5:
     except Exception:
         pass
 out = {
-    "workload": f"scripts/run_variant.py, {int(reads)} reads (100 bp, -x 2), one launch; averages over {nf} / {nw} launches",
+    "workload": f"scripts/run_variant.py PG_STEP=1 (the step of bench.py: pg_search_kernel packing its claims in place), {int(reads)} reads "
+                f"(100 bp, -x 2), one launch; averages over {nf} / {nw} launches",
     "FETCH_SIZE_raw_KB_per_launch": fetch_kb,
     "WRITE_SIZE_raw_KB_per_launch": write_kb,
     "calibration": {"kernel": "pg_calib_stream (4 B per lane, coalesced, 2 GiB > Infinity Cache)",
@@ -42,6 +43,8 @@ out = {
     "fetch_bytes_per_read": fetch_kb * 1024.0 * factor / reads if fetch_kb else None,
     "write_bytes_per_read_uncalibrated": write_kb * 1024.0 / reads if write_kb else None,
     "algorithmic_bytes_per_read": alg,
+    "pack_bytes_per_read": "of the fetched / written bytes the pack inside the launch accounts for len + 19 read and 64 x blocks + 128 written per read "
+                           "(100 bp: 119 + 256), the latter read back by the same wave through L2",
     "note": "FETCH_SIZE on gfx950 counts 64 B per 128-B request (MI355X_MICROARCH.md, HBM): scaled by the "
             "factor of the calibration kernel. WRITE_SIZE is uncalibrated. Separate --pmc passes with --kernel-trace only.",
 }

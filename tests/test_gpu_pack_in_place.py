@@ -85,12 +85,12 @@ def test_window_clusters_and_wide_ids_fall_back_or_pack(engine_factory, ref, pg_
     eng.free_device_batch(db)
 
 
-def test_a_million_reads_one_launch_equals_two(engine_factory):
+def test_two_million_reads_one_launch_equals_two(engine_factory):
     """the size at which the path switches on by itself; characters outside ACGTN in one read in 997"""
     big = synth.make_reference(8_000_000, seed=91)
     eng = engine_factory()
     eng.load_reference([("chrB", big)])
-    batch = synth.make_reads(big, 1_200_000, seed=92)
+    batch = synth.make_reads(big, 2_100_000, seed=92)
     at = batch.seq_off[:-1][::997].astype(np.int64)
     batch.seq[at + (np.arange(len(at)) % 3) * 45] = ord("K")
     db = eng.upload(batch)
