@@ -802,7 +802,7 @@ __device__ __forceinline__ void fold_candidates(const Search &S, const Query<NB>
 // next_rec (first fill of a read only): the NEXT read's record is touched with a one-dword scalar load issued beside the window's
 // HBM loads and waited for with them -- its 64-byte line is then in the scalar cache (or at least in L2) when the next read
 // starts with it.  (Anywhere else an outstanding scalar load would stall the next LDS wait: lgkmcnt counts both.)
-template <int NB>
+template <int NB, bool WIDE = false>
 __device__ __forceinline__ void stage_window(const PgDevRef &ref, Search &S, long long wo, int lo, int hi, int lane,
                                              const PgInRec *next_rec = nullptr)
 {
@@ -818,6 +818,32 @@ __device__ __forceinline__ void stage_window(const PgDevRef &ref, Search &S, lon
         // two window words per lane and pass, all six loads in flight before the first is used: a 2048-base window with its
         // overhangs is 74-78 words, and 64 + 10 in two dependent passes was two HBM round trips.  (Hand-written: the compiler
         // sinks the second set of loads behind the first set's wait however the source is arranged.)
+#ifndef PG_NO_WIDE3
+        if (WIDE && nw > 2 * WAVE) {
+            // TWO chunks of a wide far-end window with their overhangs are 134-142 words: 128 + 10 in two dependent passes was two HBM
+            // round trips per fill, twelve fills per read at -x 5.  Three words per lane, all nine loads in flight together.
+            const int i = lane, j = lane + WAVE, k = lane + 2 * WAVE;
+            const bool three = k < nw;
+            const u32 oi = 4u * (u32)i, oj = 4u * (u32)j, ok = 4u * (u32)(three ? k : i);
+            u64 a, b, c, d, e, f, g, h, m;
+            asm volatile("global_load_dwordx2 %0, %9, %12\n\tglobal_load_dwordx2 %1, %9, %13\n\tglobal_load_dwordx2 %2, %9, %14\n\t"
+                         "global_load_dwordx2 %3, %10, %12\n\tglobal_load_dwordx2 %4, %10, %13\n\tglobal_load_dwordx2 %5, %10, %14\n\t"
+                         "global_load_dwordx2 %6, %11, %12\n\tglobal_load_dwordx2 %7, %11, %13\n\tglobal_load_dwordx2 %8, %11, %14\n\t"
+                         "s_waitcnt vmcnt(0)"
+                         : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e), "=&v"(f), "=&v"(g), "=&v"(h), "=&v"(m)
+                         : "v"(oi), "v"(oj), "v"(ok), "s"(glo), "s"(ghi), "s"(gnn) : "memory");
+            *(uint3 *)__builtin_assume_aligned(&S.win[i], 16) =
+                make_uint3(__builtin_amdgcn_alignbit((u32)(a >> 32), (u32)a, sh), __builtin_amdgcn_alignbit((u32)(b >> 32), (u32)b, sh),
+                           __builtin_amdgcn_alignbit((u32)(c >> 32), (u32)c, sh));
+            *(uint3 *)__builtin_assume_aligned(&S.win[j], 16) =
+                make_uint3(__builtin_amdgcn_alignbit((u32)(d >> 32), (u32)d, sh), __builtin_amdgcn_alignbit((u32)(e >> 32), (u32)e, sh),
+                           __builtin_amdgcn_alignbit((u32)(f >> 32), (u32)f, sh));
+            if (three)
+                *(uint3 *)__builtin_assume_aligned(&S.win[k], 16) =
+                    make_uint3(__builtin_amdgcn_alignbit((u32)(g >> 32), (u32)g, sh), __builtin_amdgcn_alignbit((u32)(h >> 32), (u32)h, sh),
+                               __builtin_amdgcn_alignbit((u32)(m >> 32), (u32)m, sh));
+        } else
+#endif
         for (int i = lane; i < nw; i += 2 * WAVE) {
             const int j = i + WAVE;
             const bool two = j < nw;
@@ -1439,7 +1465,7 @@ __device__ __forceinline__ void seed_filter(const Search &S, const Query<NB> &Q,
 // word per candidate kind (seed_filter); the survivors get queue slots from a wave prefix sum of the
 // per-lane popcounts and go through fold_candidates 64 at a time.  cache*: filter masks of chunk 0 of
 // the far-end window, computed once and reused by the nested ranges.
-template <int NB, int NS, typename Id, bool MIXED>
+template <int NB, int NS, typename Id, bool MIXED, bool W3>
 __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
                                           const Query<NB> &Q, Acc<NB, Id> &A, long long wo, int g0, int s, int e,
                                           int e_max, int xs, int xe, int origin, u32 region, int lane,
@@ -1472,7 +1498,7 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
             const int ne = e < ce ? e : ce;
             const int se = e_max < ce ? e_max : ce;
             if (!(wo == S.win_wo && S.wbase == wb && se + 64 * NB <= S.win_hi))
-                stage_window<NB>(ref, S, wo, wb, se + 64 * NB, lane);
+                stage_window<NB, W3>(ref, S, wo, wb, se + 64 * NB, lane);
             // a half's survivors get queue slots behind what is already waiting; a full queue is folded at once,
             // the rest after the last half
             int h = 0, end = 0, slot = 0;
@@ -1613,7 +1639,10 @@ __device__ __forceinline__ void scan_impl(const PgDevRef &ref, Search &S,
     }
 }
 
-template <int NB, int NS, typename Id>
+// W3: the three-words-per-lane fill of two wide chunks exists in this instantiation (stage_window).  Not in the default-parameter
+// kernels, which never fill two chunks at once -- and whose 150-base class paid for the mere presence of the code with a vector
+// register parked in scratch inside a hot loop (+22 scratch loads per read, 24.1 -> 28.2 ms per 10 M reads).
+template <int NB, int NS, typename Id, bool W3 = false>
 __device__ __forceinline__ void scan_range(const PgDevRef &ref, Search &S,
                                            const Query<NB> &Q, Acc<NB, Id> &A, long long wo, int g0, int s, int e,
                                            int e_max, int xs, int xe, int origin, u32 region, int lane,
@@ -1622,11 +1651,11 @@ __device__ __forceinline__ void scan_range(const PgDevRef &ref, Search &S,
     // window coordinates come out of LDS / per-read loads: tell the compiler they are wave-uniform
     g0 = uni(g0); s = uni(s); e = uni(e); e_max = uni(e_max); xs = uni(xs); xe = uni(xe); origin = uni(origin);
     if (Q.allowF() && Q.allowB())
-        scan_impl<NB, NS, Id, true>(ref, S, Q, A, wo, g0, s, e, e_max, xs, xe, origin, region, lane,
-                                use_cache, cacheF, cacheB, cache_valid);
+        scan_impl<NB, NS, Id, true, W3>(ref, S, Q, A, wo, g0, s, e, e_max, xs, xe, origin, region, lane,
+                                    use_cache, cacheF, cacheB, cache_valid);
     else
-        scan_impl<NB, NS, Id, false>(ref, S, Q, A, wo, g0, s, e, e_max, xs, xe, origin, region, lane,
-                                 use_cache, cacheF, cacheB, cache_valid);
+        scan_impl<NB, NS, Id, false, false>(ref, S, Q, A, wo, g0, s, e, e_max, xs, xe, origin, region, lane,
+                                        use_cache, cacheF, cacheB, cache_valid);
 }
 
 // ---------------------------------------------------------------------------------
@@ -2062,7 +2091,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                 // of the R = 1 window
                 const bool own_grid = att == 0 && !shared_grid;
                 PG_STOP_AT_V(S, 12, true);
-                scan_range<NB, NS, Id>(ref, S, Q, A, chr_wo, own_grid ? s1 : w1s, s1, e1, own_grid ? e1 : w1e, ps, pe, w1s, 0u,
+                scan_range<NB, NS, Id, !DEF>(ref, S, Q, A, chr_wo, own_grid ? s1 : w1s, s1, e1, own_grid ? e1 : w1e, ps, pe, w1s, 0u,
                                    PG_LANE, (att == 1 || att == 2 ? 1u : 0u) | shared_grid, cr0, cr1, vr);
                 PG_STOPPED_V(S, true);
                 PG_STOP_AT_V(S, 19, true);
@@ -2224,7 +2253,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                     const int csz = own_chr ? chr_size : chr_size_of<NB>(ref, S, uni(bw.chr_id));
                     const int s = st < 0 ? 0 : st, e = bw.end > csz ? csz : bw.end;
                     far_bases += (e > s ? e - s : 0) + 2 * len;
-                    scan_range<NB, NS, Id>(ref, S, Q, A, own_chr ? chr_wo : chr_word_off_of<NB>(ref, S, uni(bw.chr_id)), s, s, e, e, 0, 0, st,
+                    scan_range<NB, NS, Id, !DEF>(ref, S, Q, A, own_chr ? chr_wo : chr_word_off_of<NB>(ref, S, uni(bw.chr_id)), s, s, e, e, 0, 0, st,
                                        (u32)w, PG_LANE, false, unused0, unused1, unused_valid);
                     PG_STOPPED(S);
                 }
@@ -2379,7 +2408,7 @@ __device__ __forceinline__ void search_read(const PgDevRef &ref, const PgDevPara
                     int s, e;
                     range_of(span, s, e);
                     if (s < e) {
-                        scan_range<NB, NS, Id>(ref, S, Q, A, chr_wo, g0, s, e, emax, ps, pe, origin, 0u, PG_LANE, true,
+                        scan_range<NB, NS, Id, !DEF>(ref, S, Q, A, chr_wo, g0, s, e, emax, ps, pe, origin, 0u, PG_LANE, true,
                                            cacheF, cacheB, cache_valid);
                         PG_STOPPED(S);
                         if (ps < pe) {
