@@ -2748,7 +2748,6 @@ static void launch_ns(const PgDevRef *ref, const PgDevParams *prm, const PgDevBa
             const uint32_t dflt = prm->max_range_index <= 2 && per_wg >= 32u * PG_PACK_CLAIM_LONG ? PG_PACK_CLAIM_LONG : PG_PACK_CLAIM;
             const uint32_t pc = pg_env_switches()->pack_claim ? pg_env_switches()->pack_claim : dflt;
             with_claim.claim = pc > 64u ? 64u : pc;
-            if (mode != PG_MODE_BOTH || pg_env_switches()->split_launch || batch->plane_blocks != (uint32_t)NB) abort();   // (pg_pack_in_place_ok)
         }
     }
     batch = &with_claim;
@@ -3206,6 +3205,8 @@ extern "C" int pg_launch_search(const PgDevRef *ref, const PgDevParams *prm, con
                                 int mode, uint32_t max_len, uint32_t levels, int small_ids, void *stream)
 {
     if (batch->n_reads == 0) return 0;
+    // a launch that packs in place must be one pg_pack_in_place_ok admits (the kernels run the pack of THEIR class on the batch's planes)
+    if (batch->soa && !pg_pack_in_place_ok(mode, max_len, small_ids, batch->n_reads, batch->plane_blocks)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     // experiment knob: extra dynamic LDS per workgroup (lowers occupancy), bytes
     const unsigned lds_pad = pg_env_switches()->lds_pad;
