@@ -151,12 +151,17 @@ def issue_model(args, kernel_ms, reads_per_launch):
     return out
 
 
-def pack_roofline(batch, pack_ms):
-    """Second roofline entry: the pack kernel (a streaming transpose, HBM-bound by nature)."""
+def pack_bytes(batch):
+    """Bytes the pack moves for a batch: offsets + SoA fields + bases in; bit planes + the 128-byte record out."""
     lens = batch.lengths()
     ml = int(lens.max()) if batch.n else 1
     blocks = 1 if ml <= 64 else 2 if ml <= 128 else 3 if ml <= 192 else 4 if ml <= 256 else 8
-    nbytes = float(lens.sum()) + batch.n * (8 + 11 + 64 * blocks + 128)    # offsets + SoA fields in; bit planes + the 128-byte record out
+    return float(lens.sum()) + batch.n * (8 + 11 + 64 * blocks + 128)
+
+
+def pack_roofline(batch, pack_ms):
+    """Second roofline entry: the pack kernel (a streaming transpose, HBM-bound by nature)."""
+    nbytes = pack_bytes(batch)
     achieved = nbytes / (pack_ms * 1e-3) / 1e9 if pack_ms > 0 else 0.0
     return {"bound": "hbm", "kernel": "pg_pack_kernel", "kernel_ms": pack_ms, "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes, "traffic": None,
@@ -504,6 +509,10 @@ def main():
                 "hbm_achieved_gbs": traffic / (avg_ms * 1e-3) / 1e9 if traffic and avg_ms > 0 else None,
                 "hbm_achieved_frac": traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic and avg_ms > 0 else None,
                 "traffic_over_algorithmic": traffic / alg_bytes if traffic and alg_bytes else None,
+                # the step's launch also packs (two million reads and more): its inputs read + planes and records written, which
+                # `achieved` does not count, beside the counter traffic
+                "traffic_over_algorithmic_incl_pack": (traffic / (alg_bytes + pack_bytes(batch))
+                                                       if traffic and alg_bytes and in_place and all(in_place) else None),
                 # (the step's launch: with the pack inside for batches of two million reads and more; `achieved` counts the SEARCH's
                 # algorithmic bytes only -- the planes and records the pack writes are intermediates, see roofline.pack)
                 "kernel": "pg_search_kernel", "kernel_ms": avg_ms,
