@@ -165,7 +165,7 @@ def pack_roofline(batch, pack_ms):
     achieved = nbytes / (pack_ms * 1e-3) / 1e9 if pack_ms > 0 else 0.0
     return {"bound": "hbm", "kernel": "pg_pack_kernel", "kernel_ms": pack_ms, "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes, "traffic": None,
-            "note": "as a launch of its own, measured outside the timed region; inside the step of a batch of two million reads "
+            "note": "as a launch of its own, measured outside the timed region; inside the step "
                     "and more the same code runs in pg_search_kernel, claim by claim"}
 
 
@@ -371,9 +371,9 @@ def main():
 
     # One step = what the device does for one batch whose raw inputs (ASCII bases, offsets, anchor fields) are resident in HBM:
     # the PACK (bit planes + packed records, the form the search reads -- part of every call of the ABI, so part of `value`
-    # since round 6) and the SEARCH, through pg_device_batch_pack_search: ONE launch for batches of two million reads and more
-    # (pg_search_kernel packs the reads of each claim itself just before it searches them), pg_pack_kernel + pg_search_kernel
-    # for smaller ones.  Synchronous; the HIP-event time covers everything the step put on the device.
+    # since round 6) and the SEARCH, through pg_device_batch_pack_search: ONE launch
+    # (pg_search_kernel packs the reads of each claim itself just before it searches them); pg_pack_kernel + pg_search_kernel
+    # only where the batch's plane layout is not its kernels' (64-bit candidate ids).  Synchronous; the HIP-event time covers everything the step put on the device.
     in_place = []                        # per launch of the timed steps: did the search kernel pack its own reads?
 
     def one_step():
@@ -491,8 +491,8 @@ def main():
                 # `value` covers pack + search; the search alone (rounds 1-5's `value`: inputs already packed) for comparison
                 "step": ("pack + search on raw inputs resident in HBM (pg_device_batch_pack_search): " +
                          ("ONE launch, pg_search_kernel packs the reads of each claim before it searches them" if in_place and all(in_place)
-                          else "pg_pack_kernel + pg_search_kernel (launches under two million reads)" if not any(in_place)
-                          else f"{sum(in_place)} of {len(in_place)} launches pack in place, the smaller ones are pg_pack_kernel + pg_search_kernel")),
+                          else "pg_pack_kernel + pg_search_kernel" if not any(in_place)
+                          else f"{sum(in_place)} of {len(in_place)} launches pack in place, the others are pg_pack_kernel + pg_search_kernel")),
                 "setup_seconds": {"synthetic_inputs": t_setup[1] - t_setup[0], "reference_to_hbm": t_setup[2] - t_setup[1],
                                   "reads_to_hbm": t_setup[3] - t_setup[2]},
                 "device_ms_per_step": avg_ms,
@@ -509,11 +509,11 @@ def main():
                 "hbm_achieved_gbs": traffic / (avg_ms * 1e-3) / 1e9 if traffic and avg_ms > 0 else None,
                 "hbm_achieved_frac": traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic and avg_ms > 0 else None,
                 "traffic_over_algorithmic": traffic / alg_bytes if traffic and alg_bytes else None,
-                # the step's launch also packs (two million reads and more): its inputs read + planes and records written, which
+                # the step's launch also packs: its inputs read + planes and records written, which
                 # `achieved` does not count, beside the counter traffic
                 "traffic_over_algorithmic_incl_pack": (traffic / (alg_bytes + pack_bytes(batch))
                                                        if traffic and alg_bytes and in_place and all(in_place) else None),
-                # (the step's launch: with the pack inside for batches of two million reads and more; `achieved` counts the SEARCH's
+                # (the step's launch: with the pack inside; `achieved` counts the SEARCH's
                 # algorithmic bytes only -- the planes and records the pack writes are intermediates, see roofline.pack)
                 "kernel": "pg_search_kernel", "kernel_ms": avg_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,

@@ -217,8 +217,8 @@ int  pg_device_batch_download(pg_ctx *ctx, pg_device_batch *b, pg_result **out);
  * returns its HIP-event duration in ms (events on the ctx's own stream). */
 int  pg_device_batch_repack(pg_ctx *ctx, pg_device_batch *b, double *pack_ms);
 /* Pack + search of the resident batch as ONE step: the result of pg_device_batch_repack followed by pg_device_batch_search.
- * For batches of two million reads and more the search kernel builds the planes and records of its reads itself, claim by
- * claim (the pack is HBM-bound, the search is not: no launch of its own); smaller ones run the two launches.  Synchronous. */
+ * Wherever the batch's plane layout is that of its search kernels (32-bit candidate ids: always) the search kernel builds the planes
+ * and records of its reads itself, claim by claim (the pack is HBM-bound, the search is not: no launch of its own).  Synchronous. */
 int  pg_device_batch_pack_search(pg_ctx *ctx, pg_device_batch *b);
 void pg_device_batch_free(pg_ctx *ctx, pg_device_batch *b);
 /* HIP-event duration (ms) of the kernel of the last search on this ctx (events recorded on

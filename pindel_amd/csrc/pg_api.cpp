@@ -1798,7 +1798,7 @@ static int search_host(pg_ctx *ctx, const pg_read_batch *reads, int mode, pg_res
             hipStream_t ks = (k & 1u) ? ctx->stream2 : ctx->stream;
             if (e == hipSuccess && k == 1) e = hipStreamWaitEvent(ks, ctx->events[2 * n_chunks], 0);     // (the memsets above)
             if (e == hipSuccess) e = hipStreamWaitEvent(ks, ctx->events[2 * k], 0);
-            // (the chunk's records: packed by its search launch itself where the chunk is large enough, by a launch of their own otherwise)
+            // (the chunk's records: packed by its search launch itself -- pack in place -- or, 64-bit candidate ids, by a launch of their own)
             if (e == hipSuccess) rc = launch_range(ctx, b, mode, lo, cn, ks, (int)(k & 1u), k < 2, true);
             if (e == hipSuccess && rc == PG_OK) {
                 if (k > 0) e = hipStreamWaitEvent(ks, ctx->events[2 * (k - 1) + 1], 0);

@@ -88,7 +88,7 @@ struct PgInRec {
 };
 #define PG_PACK_CLAIM 8u            // ... of a launch that packs in place (PgDevBatch::soa) ...
 #define PG_PACK_CLAIM_LONG 16u      // ... and when a wave takes many of them (pg_launch_search)
-#define PG_PACK_IN_PLACE_MIN 2000000u      // fewest reads of such a launch (a wave then takes dozens of claims)
+#define PG_PACK_IN_PLACE_MIN 1u            // fewest reads of such a launch (measured 20 000 reads .. 10 M: never slower than a pack launch in front)
 #define PG_CLAIM_DEFAULT 8u  // reads a workgroup of the persistent launch claims per atomic, at most
 #define PG_IN_PAD 8u        // records allocated behind the last one (the kernel prefetches the next read's record)
 struct PgOutRec {

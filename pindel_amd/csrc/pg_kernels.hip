@@ -2742,8 +2742,8 @@ static void launch_ns(const PgDevRef *ref, const PgDevParams *prm, const PgDevBa
         // claim lengthens the launch's tail where a wave is busy with it for long.  Measured (ms, pack launch + search launch -> one
         // launch with claims of 8 / 16): 10 M x 100 bp 22.25 -> 21.91 / 21.68; 10 M x 150 bp 25.58 -> 25.24 / 25.07; 2 M 4.60 -> 4.53 / 4.52;
         // 1 M 2.43 -> 2.38 / 2.42; 2 M at -x 5 (79 us per read) 21.95 -> 21.88 / 22.29.  Sixteen where a wave takes at least 32 such
-        // claims and the ranges are the default ones, eight otherwise.  The caller offers the path only for launches that are large
-        // enough (pg_pack_in_place_ok).
+        // claims and the ranges are the default ones, eight otherwise.  With claims of eight the one launch was never slower than
+        // the two at any size measured (20 000 reads 0.222 -> 0.197 ms, 50 000 0.303 -> 0.280, 262 144 0.814 -> 0.782, 500 000 1.345 -> 1.331).
         if (batch->soa) {
             const uint32_t dflt = prm->max_range_index <= 2 && per_wg >= 32u * PG_PACK_CLAIM_LONG ? PG_PACK_CLAIM_LONG : PG_PACK_CLAIM;
             const uint32_t pc = pg_env_switches()->pack_claim ? pg_env_switches()->pack_claim : dflt;
@@ -3193,7 +3193,7 @@ static int search_class_blocks(uint32_t max_len, int small_ids)
     return max_len <= 64 ? 1 : (nb == 2 ? 2 : (max_len <= 192 ? 3 : nb));
 }
 // May a launch of `mode` over n_reads reads build its records itself (PgDevBatch::soa) ?  BOTH mode in one launch, the batch's plane
-// layout that of the kernels' class, and enough reads that every wave takes several claims of PG_PACK_CLAIM.
+// layout that of the kernels' class (PG_PACK_IN_PLACE_MIN reads at least: 1, see pg_device.h; the environment can raise it).
 extern "C" int pg_pack_in_place_ok(int mode, uint32_t max_len, int small_ids, uint32_t n_reads, uint32_t plane_blocks)
 {
     if (mode != PG_MODE_BOTH || pg_env_switches()->split_launch || pg_env_switches()->no_pack_in_place) return 0;
