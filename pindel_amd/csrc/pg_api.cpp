@@ -1480,7 +1480,7 @@ int pg_device_batch_upload(pg_ctx *ctx, const pg_read_batch *reads, pg_device_ba
     return read_exact_count(ctx, *out);
 }
 
-static int attach_windows(pg_ctx *ctx, pg_device_batch *b, const pg_windows *bd_hints);
+static int attach_windows(pg_ctx *ctx, pg_device_batch *b, const pg_windows *bd_hints, bool repack = true);
 
 int pg_device_batch_set_windows(pg_ctx *ctx, pg_device_batch *b, const pg_windows *bd_hints)
 {
@@ -1995,7 +1995,8 @@ int pg_search_batch_multi(pg_ctx *const *ctxs, int32_t n_ctx, const pg_read_batc
 // a cluster -- clusters of more than 127 windows switch the launch to 64-bit candidate ids (29 bits of window index) --
 // and a window of 2^26 positions or more (the width of the position field) is searched as consecutive pieces: the
 // reduction over candidates is additive over disjoint position sets.
-static int attach_windows(pg_ctx *ctx, pg_device_batch *b, const pg_windows *bd_hints)
+// repack = false: the caller's next search launch packs the batch itself (launch_range with pack)
+static int attach_windows(pg_ctx *ctx, pg_device_batch *b, const pg_windows *bd_hints, bool repack)
 {
     const size_t n = b->n;
     if (int stale = stale_batch(ctx, b)) return stale;
@@ -2003,7 +2004,7 @@ static int attach_windows(pg_ctx *ctx, pg_device_batch *b, const pg_windows *bd_
     if (b->bd) { (void)hipFree(b->bd); b->bd = nullptr; }
     b->max_bd_window = 0;
     b->max_bd_cluster = 0;
-    if (!(bd_hints && bd_hints->offset && n)) return n ? pack_reads(ctx, b, 0, b->n) : PG_OK;
+    if (!(bd_hints && bd_hints->offset && n)) return n && repack ? pack_reads(ctx, b, 0, b->n) : PG_OK;
     const uint64_t nw = bd_hints->offset[n];
     const long long piece = (1ll << PG_REL_BITS) - 1;
     bool split = false;
@@ -2052,7 +2053,7 @@ static int attach_windows(pg_ctx *ctx, pg_device_batch *b, const pg_windows *bd_
     }
     int rc;
     if ((rc = dev_upload(ctx, &b->bd_off, off, n + 1)) || (rc = dev_upload(ctx, &b->bd, win, (size_t)nw2))) return rc;
-    return pack_reads(ctx, b, 0, b->n);
+    return repack ? pack_reads(ctx, b, 0, b->n) : PG_OK;
 }
 
 // Far end of `reads` given each read's close-end summary (host arrays; rc_flag may be null = the sequences are
@@ -2069,10 +2070,9 @@ static int far_end_impl(pg_ctx *ctx, const pg_read_batch *reads, const uint8_t *
         delete b;
         return code;
     };
-    if ((rc = pack_reads(ctx, b, 0, b->n))) return bail(rc);
     const size_t n = b->n;
     if (n) {
-        // (the output block of the batch, rc_flag included, was zeroed by alloc_batch)
+        // (the output block of the batch, rc_flag included, was zeroed by alloc_batch; the records are packed by the search launch)
         if ((rc_flag && hipMemcpyAsync(b->rc_flag, rc_flag, n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) ||
             hipMemcpyAsync(b->close_last, close_last, n * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
             hipMemcpyAsync(b->close_max, close_max, n * 2, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
@@ -2083,8 +2083,8 @@ static int far_end_impl(pg_ctx *ctx, const pg_read_batch *reads, const uint8_t *
         if (hipStreamSynchronize(ctx->stream) != hipSuccess)       // the host arrays may be pageable temporaries
             return bail(fail(ctx, PG_E_DEVICE, "upload of close-end summary failed"));
     }
-    if ((rc = attach_windows(ctx, b, bd_hints))) return bail(rc);
-    rc = run_search(ctx, b, PG_MODE_FAR);
+    if ((rc = attach_windows(ctx, b, bd_hints, false))) return bail(rc);
+    rc = run_search(ctx, b, PG_MODE_FAR, true);
     if (rc) return bail(rc);
     pg_result tmp;
     rc = download(ctx, b, &tmp);

@@ -2547,8 +2547,8 @@ __global__ __launch_bounds__(WAVE, PG_WAVES(NB, Id)) void pg_search_kernel(PgDev
         const uint32_t first = lo + got, end = hi - first < claim ? hi : first + claim;
         PG_T(S, 11);
         uint32_t no_touch = ~0u;                          // the read that must not touch its successor's record (none)
-        if (mode == PG_MODE_BOTH) {
-            // PACK IN PLACE (PgDevBatch::soa set): the wave builds the records and bit planes of its claim from the SoA arrays
+        {
+            // PACK IN PLACE (PgDevBatch::soa set; any mode -- the two seams' launches pack their reads too): the wave builds the records and bit planes of its claim from the SoA arrays
             // before it searches them -- the pack kernel's body on the claim's reads.  A streaming transpose (HBM-bound on its own,
             // 3 TB/s) inside a kernel that is bound by instruction issue and leaves 90 % of the HBM bandwidth idle: ~30 instructions
             // per read instead of a launch of its own in front of this one.  What the wave wrote it reads back itself, through the
@@ -3192,11 +3192,13 @@ static int search_class_blocks(uint32_t max_len, int small_ids)
     if (!small_ids) return nb;
     return max_len <= 64 ? 1 : (nb == 2 ? 2 : (max_len <= 192 ? 3 : nb));
 }
-// May a launch of `mode` over n_reads reads build its records itself (PgDevBatch::soa) ?  BOTH mode in one launch, the batch's plane
+// May a launch of `mode` over n_reads reads build its records itself (PgDevBatch::soa) ?  One launch per call, the batch's plane
 // layout that of the kernels' class (PG_PACK_IN_PLACE_MIN reads at least: 1, see pg_device.h; the environment can raise it).
 extern "C" int pg_pack_in_place_ok(int mode, uint32_t max_len, int small_ids, uint32_t n_reads, uint32_t plane_blocks)
 {
-    if (mode != PG_MODE_BOTH || pg_env_switches()->split_launch || pg_env_switches()->no_pack_in_place) return 0;
+    // (one launch per call: close end + far end together, or one seam alone; PG_SPLIT_LAUNCH's two launches over one batch keep the pack launch)
+    if ((mode == PG_MODE_BOTH && pg_env_switches()->split_launch) || pg_env_switches()->no_pack_in_place) return 0;
+    if (mode != PG_MODE_BOTH && mode != PG_MODE_CLOSE && mode != PG_MODE_FAR) return 0;
     if ((uint32_t)search_class_blocks(max_len, small_ids) != plane_blocks) return 0;
     return n_reads >= pg_env_switches()->pack_in_place_min ? 1 : 0;
 }

@@ -29,3 +29,16 @@ for n in [int(a) for a in sys.argv[1:]] or [50000, 4000000]:
         best = dt if best is None else min(best, dt)
         print(f"pg_search_batch {n} reads, call {it}: {dt * 1e3:.3f} ms = {n / dt / 1e6:.1f} M reads/s (kernels {eng.last_stats()[0]:.2f} ms)", flush=True)
     print(f"pg_search_batch {n} reads: best {best * 1e3:.3f} ms = {n / best / 1e6:.1f} M reads/s")
+
+# the two seams (pg_close_end_batch at ReadBuffer::flush, pg_far_end_batch_from_close before the far-end searches), 50 000 reads
+batch = synth.make_reads(ref, 50000, seed=20260928, device=dev)
+tc, tf = [], []
+for it in range(6):
+    t0 = time.perf_counter()
+    close = eng.close_end_batch(batch)
+    t1 = time.perf_counter()
+    eng.far_end_batch(batch, close)
+    t2 = time.perf_counter()
+    tc.append(t1 - t0)
+    tf.append(t2 - t1)
+print(f"seams, 50000 reads (python binding): close end best {min(tc) * 1e3:.3f} ms, far end from close best {min(tf) * 1e3:.3f} ms")
